@@ -1,0 +1,65 @@
+"""ctypes binding of libdynhor_hip.so (include/dynhor_hip.h).  Fails loudly when the library is missing."""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdynhor_hip.so")
+_LIB = None
+
+_vp, _i64, _i32, _f32 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_float
+
+# name -> (restype, argtypes); must list every symbol include/dynhor_hip.h declares (tests check this)
+SIGNATURES = {
+    "dh_version": (_i32, []),
+    "dh_strerror": (ctypes.c_char_p, [_i32]),
+    "dh_num_params": (_i64, []),
+    "dh_packed_floats": (_i64, []),
+    "dh_param_layout": (_i32, [_i32, _i32, ctypes.POINTER(_i64), ctypes.POINTER(_i64), ctypes.POINTER(_i64),
+                               ctypes.POINTER(_i32), ctypes.POINTER(_i32)]),
+    "dh_pack_weights": (_i32, [_vp, _vp, _vp]),
+    "dh_sdf_nograd": (_i32, [_vp, _vp, _i64, _vp, _vp]),
+}
+
+
+class DynhorHipError(RuntimeError):
+    pass
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise DynhorHipError(
+                f"{LIB_PATH} not found: the HIP extension is mandatory (no CPU fallback). "
+                "Build it with: python -c 'import __graft_entry__ as g; g.build()'")
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _LIB = L
+    return _LIB
+
+
+def check(status: int):
+    if status != 0:
+        raise DynhorHipError(f"dynhor_hip status {status}: {lib().dh_strerror(status).decode()}")
+
+
+def ptr(t: torch.Tensor):
+    assert t.is_cuda and t.is_contiguous(), "device-resident contiguous tensor required"
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def param_layout(net: int, layer: int):
+    b, g, v = _i64(), _i64(), _i64()
+    o, i = _i32(), _i32()
+    check(lib().dh_param_layout(net, layer, ctypes.byref(b), ctypes.byref(g), ctypes.byref(v),
+                                ctypes.byref(o), ctypes.byref(i)))
+    return b.value, g.value, v.value, o.value, i.value

@@ -1,0 +1,114 @@
+// Fixed-architecture layout tables shared by every kernel and by the C ABI.
+//
+// Architecture = the NeuS configuration BASELINE.json names:
+//   SDF MLP    39 -> 256 x8 (skip at 4, lin3 out 217) -> 257, softplus(beta=100), weight-norm
+//   colour MLP 289 -> 256 x4 -> 3, ReLU, sigmoid, weight-norm ; variance scalar.
+// Host + device header (plain C++14, constexpr only).
+#pragma once
+#include <stdint.h>
+
+namespace dh {
+
+constexpr int TM = 128;        // points per tile (= rows of every tile GEMM)
+constexpr int HID = 256;       // hidden width == main-tile width
+constexpr int AUXW = 40;       // aux tile logical width (39 embedding / 33 colour extras, zero padded)
+constexpr int LDX = 260;       // LDS row stride (floats) of the main tile: 260 % 64 == 4 -> b128 reads conflict free
+constexpr int LDA = 44;        // LDS row stride of the aux tile
+constexpr int TILE_F = TM * HID;       // floats per native main tile (32768)
+constexpr int AUXT_F = TM * 64;        // floats per native aux tile (8192)
+
+constexpr int N_SDF = 9;       // SDF linears lin0..lin8
+constexpr int N_COL = 5;       // colour linears lin0..lin4
+constexpr int EMB = 39;        // 3 + 6*6
+constexpr int VEMB = 27;       // 3 + 6*4
+constexpr int CAUX = 33;       // p(3) + view-embed(27) + normal(3)
+constexpr int SKIP_OUT = 217;  // lin3 out = 256 - 39
+constexpr float SOFTPLUS_BETA = 100.0f;
+constexpr float INV_SQRT2 = 0.70710678118654752440f;
+
+// ---------------------------------------------------------------- flat parameter vector
+// Order == state_dict order of the python modules: sdf lin0.{bias,weight_g,weight_v} ... lin8, variance,
+// colour lin0.{bias,weight_g,weight_v} ... lin4.  802,491 fp32.
+struct LinDims { int out, in; };
+constexpr LinDims SDF_DIMS[N_SDF] = {{256, 39}, {256, 256}, {256, 256}, {217, 256}, {256, 256},
+                                     {256, 256}, {256, 256}, {256, 256}, {257, 256}};
+constexpr LinDims COL_DIMS[N_COL] = {{256, 289}, {256, 256}, {256, 256}, {256, 256}, {3, 256}};
+
+struct LinOff { int64_t bias, g, v; };
+
+constexpr int64_t lin_size(LinDims d) { return (int64_t)d.out * 2 + (int64_t)d.out * d.in; }
+
+constexpr int64_t sdf_lin_base(int l) {
+    int64_t o = 0;
+    for (int i = 0; i < l; ++i) o += lin_size(SDF_DIMS[i]);
+    return o;
+}
+constexpr int64_t VARIANCE_OFF = sdf_lin_base(N_SDF);
+constexpr int64_t col_lin_base(int l) {
+    int64_t o = VARIANCE_OFF + 1;
+    for (int i = 0; i < l; ++i) o += lin_size(COL_DIMS[i]);
+    return o;
+}
+constexpr int64_t N_PARAMS = col_lin_base(N_COL);
+static_assert(N_PARAMS == 802491, "parameter count must match SURVEY §8 a12");
+
+constexpr LinOff sdf_off(int l) {
+    return LinOff{sdf_lin_base(l), sdf_lin_base(l) + SDF_DIMS[l].out, sdf_lin_base(l) + 2 * (int64_t)SDF_DIMS[l].out};
+}
+constexpr LinOff col_off(int l) {
+    return LinOff{col_lin_base(l), col_lin_base(l) + COL_DIMS[l].out, col_lin_base(l) + 2 * (int64_t)COL_DIMS[l].out};
+}
+
+// ---------------------------------------------------------------- packed (MFMA-operand) weight buffer
+// B-operand packing for v_mfma_f32_32x32x2_f32: a k-group = 8 consecutive k, an n-tile = 32 consecutive n.
+//   float index = ((kg*NT + nt)*64 + lane)*4 + s   holds   M[k = kg*8 + 4*(lane>>5) + s][n = nt*32 + (lane&31)]
+// NT = 8 (256 wide) or 2 (64 wide).  "fwd" = M[k=in][n=out] (x W^T), "rev" = M[k=out][n=in] (g W).
+struct PackOff {
+    int64_t sdf_fwd_main[N_SDF];   // l=1..8 (l=4: 28 k-groups, scaled 1/sqrt2 ; l=8: rows 1..256)
+    int64_t sdf_fwd_aux[N_SDF];    // l=0, l=4 (5 k-groups)
+    int64_t sdf_rev_main[N_SDF];   // l=1..8 (32 k-groups, NT=8)
+    int64_t sdf_rev_aux[N_SDF];    // l=0, l=4 (32 k-groups, NT=2)
+    int64_t sdf_bias[N_SDF];       // 256 each (l=8: bias rows 1..256)
+    int64_t sdf_w8row0;            // 256
+    int64_t sdf_b8_0;              // 4 (first used)
+    int64_t col_fwd_main[N_COL];   // l=0..3
+    int64_t col_fwd_aux0;          // 5 k-groups
+    int64_t col_rev_main[N_COL];   // l=0..3
+    int64_t col_rev_aux0;          // NT=2
+    int64_t col_bias[N_COL];       // 256 each for l<4
+    int64_t col_w4;                // 3*256 row-major
+    int64_t col_b4;                // 4
+    int64_t rowscale;              // g/||v|| per row of every linear: sdf (9*257 padded) then colour (5*256)
+    int64_t total;
+};
+
+constexpr int sdf_kg_main(int l) { return l == 0 ? 0 : (l == 4 ? 28 : 32); }
+
+constexpr PackOff make_pack_off() {
+    PackOff p{};
+    int64_t o = 0;
+    for (int l = 0; l < N_SDF; ++l) {
+        p.sdf_fwd_main[l] = o; o += (int64_t)sdf_kg_main(l) * 8 * HID;
+        p.sdf_fwd_aux[l] = o;  o += (l == 0 || l == 4) ? (int64_t)AUXW * HID : 0;
+        p.sdf_rev_main[l] = o; o += (l >= 1) ? (int64_t)HID * HID : 0;
+        p.sdf_rev_aux[l] = o;  o += (l == 0 || l == 4) ? (int64_t)HID * 64 : 0;
+        p.sdf_bias[l] = o;     o += HID;
+    }
+    p.sdf_w8row0 = o; o += HID;
+    p.sdf_b8_0 = o; o += 4;
+    for (int l = 0; l < N_COL; ++l) {
+        p.col_fwd_main[l] = o; o += (l < 4) ? (int64_t)HID * HID : 0;
+        p.col_rev_main[l] = o; o += (l < 4) ? (int64_t)HID * HID : 0;
+        p.col_bias[l] = o;     o += HID;
+    }
+    p.col_fwd_aux0 = o; o += (int64_t)AUXW * HID;
+    p.col_rev_aux0 = o; o += (int64_t)HID * 64;
+    p.col_w4 = o; o += 3 * HID;
+    p.col_b4 = o; o += 4;
+    p.rowscale = o; o += (int64_t)N_SDF * 260 + (int64_t)N_COL * 256;
+    p.total = (o + 3) / 4 * 4;
+    return p;
+}
+constexpr PackOff PACK = make_pack_off();
+
+}  // namespace dh

@@ -1,0 +1,147 @@
+// Weight preparation: weight-norm row scales, then MFMA-operand packing of every linear (layout.h).
+// Runs once per optimiser step (weights change every iteration); ~5 MB written, L2-resident afterwards.
+#include "tile.h"
+#include "kernels.h"
+
+namespace dh {
+
+// one wave per row: rowscale = g / ||v||_2
+__global__ __launch_bounds__(256) void rowscale_kernel(const float* __restrict__ params, float* __restrict__ packed) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int job = blockIdx.y;                    // 0..8 sdf, 9..13 colour
+    const bool is_sdf = job < N_SDF;
+    const int l = is_sdf ? job : job - N_SDF;
+    int out, in;
+    int64_t goff, voff;
+    if (is_sdf) { out = SDF_DIMS[l].out; in = SDF_DIMS[l].in; goff = sdf_off(l).g; voff = sdf_off(l).v; }
+    else        { out = COL_DIMS[l].out; in = COL_DIMS[l].in; goff = col_off(l).g; voff = col_off(l).v; }
+    const int row = blockIdx.x * 4 + wave;
+    if (row >= out) return;
+    const float* v = params + voff + (int64_t)row * in;
+    float s = 0.f;
+    for (int k = lane; k < in; k += 64) s += v[k] * v[k];
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    if (lane == 0) {
+        const int64_t ro = PACK.rowscale + (is_sdf ? (int64_t)l * 260 : (int64_t)N_SDF * 260 + (int64_t)l * 256);
+        packed[ro + row] = params[goff + row] / sqrtf(s);
+    }
+}
+
+struct PackJob {
+    int64_t dst;        // float offset into packed
+    int64_t voff;       // float offset of weight_v in params
+    int64_t rsoff;      // float offset of the rowscale block in packed
+    int ldv;            // in-dim of the linear
+    int nkg;            // k-groups
+    int nt;             // n-tiles (8 or 2)
+    int rev;            // 0: M[k=in][n=out]   1: M[k=out][n=in]
+    int row_off;        // output-row offset (lin8: 1)
+    int col_off;        // input-col offset
+    int out_valid;      // valid output rows (after row_off)
+    int in_valid;       // valid input cols (after col_off)
+    float scale;
+};
+
+struct PackJobs { PackJob j[32]; int n; };
+
+__global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ params, float* __restrict__ packed, PackJobs jobs) {
+    const PackJob J = jobs.j[blockIdx.y];
+    const int64_t total4 = (int64_t)J.nkg * J.nt * 64;
+    for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)gridDim.x * 256) {
+        const int lane = i & 63;
+        const int nt = (i >> 6) % J.nt;
+        const int kg = (i >> 6) / J.nt;
+        const int n = nt * 32 + (lane & 31);
+        f32x4 v;
+        DH_UNROLL for (int s = 0; s < 4; ++s) {
+            const int k = kg * 8 + 4 * (lane >> 5) + s;
+            const int o = J.rev ? k : n, c = J.rev ? n : k;
+            float x = 0.f;
+            if (o < J.out_valid && c < J.in_valid) {
+                const int row = o + J.row_off;
+                x = J.scale * packed[J.rsoff + row] * params[J.voff + (int64_t)row * J.ldv + J.col_off + c];
+            }
+            v[s] = x;
+        }
+        reinterpret_cast<f32x4*>(packed + J.dst)[i] = v;
+    }
+}
+
+// biases, lin8 row 0, colour lin4 (small vectors)
+__global__ __launch_bounds__(256) void pack_small_kernel(const float* __restrict__ params, float* __restrict__ packed) {
+    const int c = threadIdx.x;   // 0..255
+    const int job = blockIdx.x;
+    if (job < N_SDF) {
+        const int l = job;
+        float b = 0.f;
+        if (l < 8) { if (c < SDF_DIMS[l].out) b = params[sdf_off(l).bias + c]; }
+        else b = params[sdf_off(8).bias + 1 + c];
+        packed[PACK.sdf_bias[l] + c] = b;
+    } else if (job == N_SDF) {
+        const int64_t rs = PACK.rowscale + 8 * 260;
+        packed[PACK.sdf_w8row0 + c] = packed[rs + 0] * params[sdf_off(8).v + c];
+        if (c == 0) packed[PACK.sdf_b8_0] = params[sdf_off(8).bias];
+    } else if (job < N_SDF + 1 + 4) {
+        const int l = job - N_SDF - 1;
+        packed[PACK.col_bias[l] + c] = params[col_off(l).bias + c];
+    } else {
+        const int64_t rs = PACK.rowscale + (int64_t)N_SDF * 260 + 4 * 256;
+        for (int r = 0; r < 3; ++r) packed[PACK.col_w4 + r * 256 + c] = packed[rs + r] * params[col_off(4).v + r * 256 + c];
+        if (c < 3) packed[PACK.col_b4 + c] = params[col_off(4).bias + c];
+    }
+}
+
+static PackJobs build_jobs() {
+    PackJobs J{};
+    int n = 0;
+    auto add = [&](int64_t dst, int64_t voff, int64_t rsoff, int ldv, int nkg, int nt, int rev, int row_off, int col_off,
+                   int out_valid, int in_valid, float scale) {
+        J.j[n++] = PackJob{dst, voff, rsoff, ldv, nkg, nt, rev, row_off, col_off, out_valid, in_valid, scale};
+    };
+    for (int l = 0; l < N_SDF; ++l) {
+        const int64_t rs = PACK.rowscale + (int64_t)l * 260;
+        const int64_t v = sdf_off(l).v;
+        const int in = SDF_DIMS[l].in, out = SDF_DIMS[l].out;
+        if (l == 0) {
+            add(PACK.sdf_fwd_aux[0], v, rs, in, 5, 8, 0, 0, 0, out, EMB, 1.f);
+            add(PACK.sdf_rev_aux[0], v, rs, in, 32, 2, 1, 0, 0, out, EMB, 1.f);
+        } else if (l == 4) {
+            add(PACK.sdf_fwd_main[4], v, rs, in, 28, 8, 0, 0, 0, out, SKIP_OUT, INV_SQRT2);
+            add(PACK.sdf_fwd_aux[4], v, rs, in, 5, 8, 0, 0, SKIP_OUT, out, EMB, INV_SQRT2);
+            add(PACK.sdf_rev_main[4], v, rs, in, 32, 8, 1, 0, 0, out, SKIP_OUT, INV_SQRT2);
+            add(PACK.sdf_rev_aux[4], v, rs, in, 32, 2, 1, 0, SKIP_OUT, out, EMB, INV_SQRT2);
+        } else if (l == 8) {
+            add(PACK.sdf_fwd_main[8], v, rs, in, 32, 8, 0, 1, 0, 256, 256, 1.f);
+            add(PACK.sdf_rev_main[8], v, rs, in, 32, 8, 1, 1, 0, 256, 256, 1.f);
+        } else {
+            add(PACK.sdf_fwd_main[l], v, rs, in, 32, 8, 0, 0, 0, out, in, 1.f);
+            add(PACK.sdf_rev_main[l], v, rs, in, 32, 8, 1, 0, 0, out, in, 1.f);
+        }
+    }
+    for (int l = 0; l < 4; ++l) {
+        const int64_t rs = PACK.rowscale + (int64_t)N_SDF * 260 + (int64_t)l * 256;
+        const int64_t v = col_off(l).v;
+        const int in = COL_DIMS[l].in;
+        if (l == 0) {
+            add(PACK.col_fwd_main[0], v, rs, in, 32, 8, 0, 0, CAUX, 256, 256, 1.f);
+            add(PACK.col_fwd_aux0, v, rs, in, 5, 8, 0, 0, 0, 256, CAUX, 1.f);
+            add(PACK.col_rev_main[0], v, rs, in, 32, 8, 1, 0, CAUX, 256, 256, 1.f);
+            add(PACK.col_rev_aux0, v, rs, in, 32, 2, 1, 0, 0, 256, CAUX, 1.f);
+        } else {
+            add(PACK.col_fwd_main[l], v, rs, in, 32, 8, 0, 0, 0, 256, 256, 1.f);
+            add(PACK.col_rev_main[l], v, rs, in, 32, 8, 1, 0, 0, 256, 256, 1.f);
+        }
+    }
+    J.n = n;
+    return J;
+}
+
+int launch_pack_weights(const float* params, float* packed, hipStream_t stream) {
+    static const PackJobs jobs = build_jobs();
+    hipLaunchKernelGGL(rowscale_kernel, dim3(65, N_SDF + N_COL), dim3(256), 0, stream, params, packed);
+    hipLaunchKernelGGL(pack_kernel, dim3(16, jobs.n), dim3(256), 0, stream, params, packed, jobs);
+    hipLaunchKernelGGL(pack_small_kernel, dim3(N_SDF + 1 + 4 + 1), dim3(256), 0, stream, params, packed);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+}  // namespace dh

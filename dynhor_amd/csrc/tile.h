@@ -1,0 +1,162 @@
+// Device primitives for the tile-resident MLP chains (gfx950 / CDNA4 only).
+//
+// One workgroup = 256 threads = 4 waves (one per SIMD) owns a tile of TM=128 points.  The tile's current
+// activation lives in LDS as a row-major [128 x 256] fp32 image (row stride LDX=260 floats -> ds_read_b128 of
+// 32 consecutive rows is bank-conflict free) plus a [128 x 40] "aux" image (embedding / colour extras).
+// Every layer is  OUT[128 x 256] = X[128 x K] * M[K x 256]  on v_mfma_f32_32x32x2_f32 (exact fp32, fmaf-chain
+// numerics):  wave w owns output columns [64w, 64w+64) = 2 n-tiles x 4 m-tiles = 8 accumulators (128 VGPRs).
+//   A operand (X) : ds_read_b128 from LDS  -> lane (i=l&31, h=l>>5) gets X[m*32+i][kg*8+4h+s], s=0..3
+//   B operand (M) : global_load_dwordx4 from the packed, L2-resident weight image (layout.h)
+// MFMA step s of k-group kg therefore contracts k = kg*8 + s (lanes 0-31) and kg*8 + 4 + s (lanes 32-63).
+//
+// "Native" HBM layout of a saved [128 x 256] tile == the accumulator layout, so stores/loads are 1 KiB coalesced
+// float4 wave-instructions and the dW kernel can consume saved tiles as MFMA operands straight from global:
+//   float4 index = (((w*4 + m)*2 + t)*4 + r4)*64 + lane ; element rr  <->  row m*32 + 8*r4 + 4*(lane>>5) + rr,
+//                                                                           col 64*w + 32*t + (lane&31).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "layout.h"
+
+namespace dh {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define DH_UNROLL _Pragma("unroll")
+
+__device__ __forceinline__ void acc_zero(f32x16 (&acc)[4][2]) {
+    DH_UNROLL for (int m = 0; m < 4; ++m)
+        DH_UNROLL for (int t = 0; t < 2; ++t)
+            DH_UNROLL for (int r = 0; r < 16; ++r) acc[m][t][r] = 0.f;
+}
+
+// acc[m][t] += X[128 x nkg*8] * Mpacked   (P1).  xs: LDS base (row stride ldx floats); wp: packed, NT=8.
+// Two k-groups per trip with ping-pong operand registers (no register-rotation copies -> the next group's
+// LDS/L2 loads stay in flight under the current group's 32 MFMAs).
+__device__ __forceinline__ void mfma_block(f32x16 (&acc)[4][2], const f32x4 (&a)[4], const f32x4 (&b)[2]) {
+    DH_UNROLL for (int s = 0; s < 4; ++s)
+        DH_UNROLL for (int m = 0; m < 4; ++m)
+            DH_UNROLL for (int t = 0; t < 2; ++t)
+                acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m][s], b[t][s], acc[m][t], 0, 0, 0);
+}
+__device__ __forceinline__ void gemm_rows(f32x16 (&acc)[4][2], const float* xs, const int ldx, const int nkg,
+                                          const f32x4* __restrict__ wp, const int wave, const int lane) {
+    const float* xrow = xs + (lane & 31) * ldx + 4 * (lane >> 5);
+    const f32x4* wl = wp + (2 * wave) * 64 + lane;
+    f32x4 a0[4], b0[2], a1[4], b1[2];
+    DH_UNROLL for (int t = 0; t < 2; ++t) b0[t] = wl[t * 64];
+    DH_UNROLL for (int m = 0; m < 4; ++m) a0[m] = *reinterpret_cast<const f32x4*>(xrow + m * 32 * ldx);
+    for (int kg = 0; kg < nkg; kg += 2) {
+        const int k1 = (kg + 1 < nkg) ? kg + 1 : kg;
+        DH_UNROLL for (int t = 0; t < 2; ++t) b1[t] = wl[(k1 * 8 + t) * 64];
+        DH_UNROLL for (int m = 0; m < 4; ++m) a1[m] = *reinterpret_cast<const f32x4*>(xrow + m * 32 * ldx + k1 * 8);
+        mfma_block(acc, a0, b0);
+        if (kg + 1 < nkg) {
+            const int k2 = (kg + 2 < nkg) ? kg + 2 : kg + 1;
+            DH_UNROLL for (int t = 0; t < 2; ++t) b0[t] = wl[(k2 * 8 + t) * 64];
+            DH_UNROLL for (int m = 0; m < 4; ++m) a0[m] = *reinterpret_cast<const f32x4*>(xrow + m * 32 * ldx + k2 * 8);
+            mfma_block(acc, a1, b1);
+        }
+    }
+}
+
+// acc2[t] += X[rows 32w..32w+31][256] * Mpacked(NT=2)   (P2: 64-wide "aux" output, wave owns 32 rows).
+__device__ __forceinline__ void gemm_auxout(f32x16 (&acc2)[2], const float* xs, const int nkg,
+                                            const f32x4* __restrict__ wp, const int wave, const int lane) {
+    const float* xrow = xs + (32 * wave + (lane & 31)) * LDX + 4 * (lane >> 5);
+    const f32x4* wl = wp + lane;
+    f32x4 a = *reinterpret_cast<const f32x4*>(xrow);
+    f32x4 b[2];
+    DH_UNROLL for (int t = 0; t < 2; ++t) b[t] = wl[t * 64];
+    for (int kg = 0; kg < nkg; ++kg) {
+        const int kn = (kg + 1 < nkg) ? kg + 1 : kg;
+        f32x4 an = *reinterpret_cast<const f32x4*>(xrow + kn * 8);
+        f32x4 bn[2];
+        DH_UNROLL for (int t = 0; t < 2; ++t) bn[t] = wl[(kn * 2 + t) * 64];
+        DH_UNROLL for (int s = 0; s < 4; ++s)
+            DH_UNROLL for (int t = 0; t < 2; ++t)
+                acc2[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b[t][s], acc2[t], 0, 0, 0);
+        a = an;
+        DH_UNROLL for (int t = 0; t < 2; ++t) b[t] = bn[t];
+    }
+}
+
+// Row / column of accumulator element (m,t,r) for this lane.
+__device__ __forceinline__ int acc_row(int m, int r, int lane) { return m * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+__device__ __forceinline__ int acc_col(int wave, int t, int lane) { return 64 * wave + 32 * t + (lane & 31); }
+
+// accumulators -> LDS main tile (row-major, stride LDX)
+__device__ __forceinline__ void acc_to_lds(const f32x16 (&acc)[4][2], float* xs, int wave, int lane) {
+    DH_UNROLL for (int m = 0; m < 4; ++m)
+        DH_UNROLL for (int t = 0; t < 2; ++t) {
+            float* base = xs + (m * 32 + 4 * (lane >> 5)) * LDX + acc_col(wave, t, lane);
+            DH_UNROLL for (int r = 0; r < 16; ++r) base[((r & 3) + 8 * (r >> 2)) * LDX] = acc[m][t][r];
+        }
+}
+
+// native tile <-> accumulators
+__device__ __forceinline__ void acc_store_native(const f32x16 (&acc)[4][2], float* __restrict__ tile, int wave, int lane) {
+    f32x4* p = reinterpret_cast<f32x4*>(tile) + (size_t)wave * 32 * 64 + lane;
+    DH_UNROLL for (int m = 0; m < 4; ++m)
+        DH_UNROLL for (int t = 0; t < 2; ++t)
+            DH_UNROLL for (int r4 = 0; r4 < 4; ++r4) {
+                f32x4 v;
+                v[0] = acc[m][t][4 * r4 + 0]; v[1] = acc[m][t][4 * r4 + 1];
+                v[2] = acc[m][t][4 * r4 + 2]; v[3] = acc[m][t][4 * r4 + 3];
+                p[((m * 2 + t) * 4 + r4) * 64] = v;
+            }
+}
+__device__ __forceinline__ void acc_load_native(f32x16 (&acc)[4][2], const float* __restrict__ tile, int wave, int lane) {
+    const f32x4* p = reinterpret_cast<const f32x4*>(tile) + (size_t)wave * 32 * 64 + lane;
+    DH_UNROLL for (int m = 0; m < 4; ++m)
+        DH_UNROLL for (int t = 0; t < 2; ++t)
+            DH_UNROLL for (int r4 = 0; r4 < 4; ++r4) {
+                f32x4 v = p[((m * 2 + t) * 4 + r4) * 64];
+                acc[m][t][4 * r4 + 0] = v[0]; acc[m][t][4 * r4 + 1] = v[1];
+                acc[m][t][4 * r4 + 2] = v[2]; acc[m][t][4 * r4 + 3] = v[3];
+            }
+}
+
+// aux native tile ([128 x 64], wave owns rows 32w..): float4 index = ((w*2 + t)*4 + r4)*64 + lane,
+// element rr <-> row 32w + 8*r4 + 4*(lane>>5) + rr, col 32t + (lane&31).
+__device__ __forceinline__ void aux_store_native(const f32x16 (&a2)[2], float* __restrict__ tile, int wave, int lane) {
+    f32x4* p = reinterpret_cast<f32x4*>(tile) + (size_t)wave * 8 * 64 + lane;
+    DH_UNROLL for (int t = 0; t < 2; ++t)
+        DH_UNROLL for (int r4 = 0; r4 < 4; ++r4) {
+            f32x4 v;
+            v[0] = a2[t][4 * r4 + 0]; v[1] = a2[t][4 * r4 + 1]; v[2] = a2[t][4 * r4 + 2]; v[3] = a2[t][4 * r4 + 3];
+            p[(t * 4 + r4) * 64] = v;
+        }
+}
+// LDS aux image (row stride LDA, cols < 40 valid, others 0) -> aux native tile in HBM
+__device__ __forceinline__ void aux_lds_to_native(const float* aux, float* __restrict__ tile, int wave, int lane) {
+    f32x16 a2[2];
+    DH_UNROLL for (int t = 0; t < 2; ++t) {
+        const int col = 32 * t + (lane & 31);
+        DH_UNROLL for (int r = 0; r < 16; ++r) {
+            const int row = 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            a2[t][r] = (col < AUXW) ? aux[row * LDA + col] : 0.f;
+        }
+    }
+    aux_store_native(a2, tile, wave, lane);
+}
+
+// ---------------------------------------------------------------- activation math
+// softplus(beta=100, threshold=20) with a compensated log1p (matches torch's log1p(exp(bx))/b to ~1 ulp)
+__device__ __forceinline__ float softplus100(float z) {
+    const float t = SOFTPLUS_BETA * z;
+    const float e = __expf(fminf(t, 20.f));
+    const float u = 1.f + e;
+    const float d = u - 1.f;
+    const float l = (d == 0.f) ? e : __logf(u) * (e / d);
+    return t > 20.f ? z : l * (1.f / SOFTPLUS_BETA);
+}
+// From the saved post-activation h = softplus(z): s = sigma'(z) = 1 - exp(-beta h); em = exp(-beta h) = 1 - s.
+__device__ __forceinline__ void softplus_deriv_from_h(float h, float& s, float& em) {
+    const float x = SOFTPLUS_BETA * h;
+    em = __expf(-x);
+    const float series = x * (1.f - x * (0.5f - x * (0.16666667f - x * (0.041666668f - x * 0.0083333338f))));
+    s = (x < 0.0625f) ? series : 1.f - em;
+}
+
+}  // namespace dh
