@@ -20,6 +20,8 @@ SIGNATURES = {
                                ctypes.POINTER(_i32), ctypes.POINTER(_i32)]),
     "dh_pack_weights": (_i32, [_vp, _vp, _vp]),
     "dh_sdf_nograd": (_i32, [_vp, _vp, _i64, _vp, _vp]),
+    "dh_workspace_floats": (_i32, [_i64, ctypes.POINTER(_i64), ctypes.POINTER(_i64)]),
+    "dh_mlp_forward": (_i32, [_vp, _vp, _vp, _i32, _i64, _vp, _vp, _vp, _vp, _vp]),
 }
 
 
@@ -63,3 +65,9 @@ def param_layout(net: int, layer: int):
     check(lib().dh_param_layout(net, layer, ctypes.byref(b), ctypes.byref(g), ctypes.byref(v),
                                 ctypes.byref(o), ctypes.byref(i)))
     return b.value, g.value, v.value, o.value, i.value
+
+
+def workspace_floats(npts: int):
+    f, t = _i64(), _i64()
+    check(lib().dh_workspace_floats(npts, ctypes.byref(f), ctypes.byref(t)))
+    return f.value, t.value

@@ -2,6 +2,7 @@
 #include "../../include/dynhor_hip.h"
 #include "kernels.h"
 #include "layout.h"
+#include "workspace.h"
 
 using namespace dh;
 
@@ -55,6 +56,29 @@ int dh_sdf_nograd(const float* packed, const float* pts, int64_t npts, float* sd
     if (npts == 0) return DH_OK;
     if (!packed || !pts || !sdf || misaligned16(packed)) return DH_ERR_BAD_ARG;
     return launch_sdf_nograd(packed, pts, npts, sdf, DEFAULT_GRID, static_cast<hipStream_t>(stream));
+}
+
+int dh_workspace_floats(int64_t npts, int64_t* fwd_floats, int64_t* total_floats) {
+    if (npts < 0 || !fwd_floats || !total_floats) return DH_ERR_BAD_ARG;
+    const Workspace w = carve_workspace(nullptr, npts);
+    *fwd_floats = w.fwd_floats;
+    *total_floats = w.total_floats;
+    return DH_OK;
+}
+
+int dh_mlp_forward(const float* packed, const float* pts, const float* dirs, int n_per_ray, int64_t npts, float* ws,
+                   float* sdf, float* normals, float* color, void* stream) {
+    if (npts < 0 || n_per_ray <= 0) return DH_ERR_BAD_ARG;
+    if (npts == 0) return DH_OK;
+    if (!packed || !pts || !dirs || !ws || !sdf || !normals || !color || misaligned16(packed) || misaligned16(ws))
+        return DH_ERR_BAD_ARG;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const Workspace w = carve_workspace(ws, npts);
+    int rc = launch_sdf_fwd_train(packed, pts, npts, sdf, w.feat, w.act, w.eaux, DEFAULT_GRID, st);
+    if (rc) return rc;
+    rc = launch_sdf_grad(packed, pts, npts, w.act, w.asave, normals, DEFAULT_GRID, st);
+    if (rc) return rc;
+    return launch_color_fwd(packed, pts, dirs, n_per_ray, normals, w.feat, npts, color, w.cact, w.caux, 1, DEFAULT_GRID, st);
 }
 
 }  // extern "C"

@@ -105,6 +105,235 @@ __global__ __launch_bounds__(256, 1) void sdf_nograd_kernel(SdfPtrs P, const flo
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// K2a: SDF forward for training: saves the embedding (aux native) and every layer input act[l] (l=1..8,
+// post-softplus, native tiles), writes feat = lin8 rows 1..256 (native) and sdf = lin8 row 0 (VALU dot).
+//   act : [8][ntiles][TILE_F]   (act[l-1] <-> input of layer l)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 1) void sdf_fwd_train_kernel(SdfPtrs P, const float* __restrict__ pts, int64_t npts,
+                                                                float* __restrict__ sdf_out, float* __restrict__ feat,
+                                                                float* __restrict__ act, float* __restrict__ eaux) {
+    __shared__ __attribute__((aligned(16))) float smain[TM * LDX];
+    __shared__ __attribute__((aligned(16))) float saux[TM * LDA];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int64_t ntiles = (npts + TM - 1) / TM;
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        embed_tile(pts, tile * TM, npts, saux, tid);
+        __syncthreads();
+        aux_lds_to_native(saux, eaux + tile * AUXT_F, wave, lane);
+        f32x16 acc[4][2];
+        for (int l = 0; l < 8; ++l) {
+            acc_zero(acc);
+            if (l > 0) gemm_rows(acc, smain, LDX, l == 4 ? 28 : 32, P.fwd_main[l], wave, lane);
+            if (l == 0 || l == 4) gemm_rows(acc, saux, LDA, 5, P.fwd_aux[l], wave, lane);
+            const float b0 = P.bias[l][acc_col(wave, 0, lane)], b1 = P.bias[l][acc_col(wave, 1, lane)];
+            acc_map(acc, [&](int, int t, int, float v) { return softplus100(v + (t ? b1 : b0)); });
+            acc_store_native(acc, act + ((int64_t)l * ntiles + tile) * TILE_F, wave, lane);
+            __syncthreads();
+            acc_to_lds(acc, smain, wave, lane);
+            __syncthreads();
+        }
+        const float s = row_dot256(smain, P.w8row0, tid) + P.b8_0[0];
+        const int64_t gp = tile * TM + (tid >> 1);
+        if ((tid & 1) == 0 && gp < npts) sdf_out[gp] = s;
+        acc_zero(acc);
+        gemm_rows(acc, smain, LDX, 32, P.fwd_main[8], wave, lane);
+        const float b0 = P.bias[8][acc_col(wave, 0, lane)], b1 = P.bias[8][acc_col(wave, 1, lane)];
+        acc_map(acc, [&](int, int t, int, float v) { return v + (t ? b1 : b0); });
+        acc_store_native(acc, feat + tile * TILE_F, wave, lane);
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K2b: n = d sdf / d x  (upstream SDFNetwork.gradient, App. A.2), reverse chain through the saved activations.
+//   u_8 = W8[0,:];  a_l = u_{l+1} * sigma'(z_l)  (sigma' from the saved act[l+1]);  u_l = a_l W_l  (l = 7..1)
+//   ge = a_0 W_0 + a_4 W_4[:,217:]/sqrt2 ;  n = J_e(x)^T ge.   Saves a_l (l=0..7) for the backward pass.
+//   asave : [8][ntiles][TILE_F]
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 1) void sdf_grad_kernel(SdfPtrs P, const float* __restrict__ pts, int64_t npts,
+                                                           const float* __restrict__ act, float* __restrict__ asave,
+                                                           float* __restrict__ normals) {
+    __shared__ __attribute__((aligned(16))) float smain[TM * LDX];
+    __shared__ __attribute__((aligned(16))) float saux[TM * LDA];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int64_t ntiles = (npts + TM - 1) / TM;
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        f32x16 acc[4][2];
+        f32x16 ge[2];
+        DH_UNROLL for (int t = 0; t < 2; ++t) DH_UNROLL for (int r = 0; r < 16; ++r) ge[t][r] = 0.f;
+        // a_7 = W8[0,:] * sigma'(z_7)
+        {
+            const float w0 = P.w8row0[acc_col(wave, 0, lane)], w1 = P.w8row0[acc_col(wave, 1, lane)];
+            acc_load_native(acc, act + ((int64_t)7 * ntiles + tile) * TILE_F, wave, lane);
+            acc_map(acc, [&](int, int t, int, float h) { float s, em; softplus_deriv_from_h(h, s, em); return (t ? w1 : w0) * s; });
+            acc_store_native(acc, asave + ((int64_t)7 * ntiles + tile) * TILE_F, wave, lane);
+            acc_to_lds(acc, smain, wave, lane);
+            __syncthreads();
+        }
+        for (int l = 7; l >= 1; --l) {
+            acc_zero(acc);
+            gemm_rows(acc, smain, LDX, 32, P.rev_main[l], wave, lane);              // u_l = a_l W_l
+            if (l == 4) gemm_auxout(ge, smain, 32, P.rev_aux[4], wave, lane);       // skip path -> ge
+            // a_{l-1} = u_l * sigma'(z_{l-1})   (sigma' from act[l-1] == input of layer l)
+            const f32x4* hp = reinterpret_cast<const f32x4*>(act + ((int64_t)(l - 1) * ntiles + tile) * TILE_F) + (size_t)wave * 32 * 64 + lane;
+            DH_UNROLL for (int m = 0; m < 4; ++m) {
+                DH_UNROLL for (int t = 0; t < 2; ++t)
+                    DH_UNROLL for (int r4 = 0; r4 < 4; ++r4) {
+                        const f32x4 h = hp[((m * 2 + t) * 4 + r4) * 64];
+                        DH_UNROLL for (int rr = 0; rr < 4; ++rr) {
+                            float s, em; softplus_deriv_from_h(h[rr], s, em);
+                            acc[m][t][4 * r4 + rr] *= s;
+                        }
+                    }
+                __builtin_amdgcn_sched_barrier(0);     // bound live registers: one m-slab (8 float4) in flight
+            }
+            acc_store_native(acc, asave + ((int64_t)(l - 1) * ntiles + tile) * TILE_F, wave, lane);
+            __syncthreads();
+            acc_to_lds(acc, smain, wave, lane);
+            __syncthreads();
+        }
+        gemm_auxout(ge, smain, 32, P.rev_aux[0], wave, lane);                       // ge += a_0 W_0
+        // ge -> LDS aux image
+        DH_UNROLL for (int t = 0; t < 2; ++t) {
+            const int col = 32 * t + (lane & 31);
+            if (col < AUXW) {
+                DH_UNROLL for (int r = 0; r < 16; ++r)
+                    saux[(32 * wave + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * LDA + col] = ge[t][r];
+            }
+        }
+        __syncthreads();
+        if (tid < TM) {
+            const int64_t gp = tile * TM + tid;
+            if (gp < npts) {
+                const float* g = saux + tid * LDA;
+                float n[3];
+                DH_UNROLL for (int c = 0; c < 3; ++c) {
+                    const float x = pts[gp * 3 + c];
+                    float v = g[c];
+                    DH_UNROLL for (int k = 0; k < 6; ++k) {
+                        const float f = (float)(1 << k);
+                        float s, co; sincosf(x * f, &s, &co);
+                        v += f * (co * g[3 + 6 * k + c] - s * g[3 + 6 * k + 3 + c]);
+                    }
+                    n[c] = v;
+                }
+                normals[gp * 3 + 0] = n[0]; normals[gp * 3 + 1] = n[1]; normals[gp * 3 + 2] = n[2];
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K2c: RenderingNetwork forward (mode idr, App. A.3).  input = [p(3), embed_4(view)(27), n(3) | feat(256)]:
+// the 33 extras live in the aux image, feat in the main image.  Saves caux (aux native), the post-ReLU
+// activations cact[l] (l=1..4 -> slot l-1) and writes colour = sigmoid(lin4).
+//   dirs: [nrays,3], point gp belongs to ray gp / n_per_ray.
+// ------------------------------------------------------------------------------------------------
+struct ColPtrs {
+    const f32x4* fwd_main[4];
+    const f32x4* rev_main[4];
+    const f32x4* fwd_aux0;
+    const f32x4* rev_aux0;
+    const float* bias[4];
+    const float* w4;
+    const float* b4;
+};
+static ColPtrs make_col_ptrs(const float* packed) {
+    ColPtrs C;
+    for (int l = 0; l < 4; ++l) {
+        C.fwd_main[l] = reinterpret_cast<const f32x4*>(packed + PACK.col_fwd_main[l]);
+        C.rev_main[l] = reinterpret_cast<const f32x4*>(packed + PACK.col_rev_main[l]);
+        C.bias[l] = packed + PACK.col_bias[l];
+    }
+    C.fwd_aux0 = reinterpret_cast<const f32x4*>(packed + PACK.col_fwd_aux0);
+    C.rev_aux0 = reinterpret_cast<const f32x4*>(packed + PACK.col_rev_aux0);
+    C.w4 = packed + PACK.col_w4;
+    C.b4 = packed + PACK.col_b4;
+    return C;
+}
+
+__global__ __launch_bounds__(256, 1) void color_fwd_kernel(ColPtrs C, const float* __restrict__ pts, const float* __restrict__ dirs,
+                                                            int n_per_ray, const float* __restrict__ normals,
+                                                            const float* __restrict__ feat, int64_t npts,
+                                                            float* __restrict__ color, float* __restrict__ cact,
+                                                            float* __restrict__ caux, int save) {
+    __shared__ __attribute__((aligned(16))) float smain[TM * LDX];
+    __shared__ __attribute__((aligned(16))) float saux[TM * LDA];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int64_t ntiles = (npts + TM - 1) / TM;
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        if (tid < TM) {
+            const int64_t gp = tile * TM + tid;
+            float* row = saux + tid * LDA;
+            if (gp < npts) {
+                const int64_t ray = gp / n_per_ray;
+                DH_UNROLL for (int c = 0; c < 3; ++c) {
+                    const float d = dirs[ray * 3 + c];
+                    row[c] = pts[gp * 3 + c];
+                    row[3 + c] = d;
+                    DH_UNROLL for (int k = 0; k < 4; ++k) {
+                        float s, co; sincosf(d * (float)(1 << k), &s, &co);
+                        row[6 + 6 * k + c] = s;
+                        row[6 + 6 * k + 3 + c] = co;
+                    }
+                    row[30 + c] = normals[gp * 3 + c];
+                }
+            } else {
+                DH_UNROLL for (int c = 0; c < CAUX; ++c) row[c] = 0.f;
+            }
+            DH_UNROLL for (int c = CAUX; c < LDA; ++c) row[c] = 0.f;
+        }
+        f32x16 acc[4][2];
+        acc_load_native(acc, feat + tile * TILE_F, wave, lane);
+        acc_to_lds(acc, smain, wave, lane);
+        __syncthreads();
+        if (save) aux_lds_to_native(saux, caux + tile * AUXT_F, wave, lane);
+        for (int l = 0; l < 4; ++l) {
+            acc_zero(acc);
+            gemm_rows(acc, smain, LDX, 32, C.fwd_main[l], wave, lane);
+            if (l == 0) gemm_rows(acc, saux, LDA, 5, C.fwd_aux0, wave, lane);
+            const float b0 = C.bias[l][acc_col(wave, 0, lane)], b1 = C.bias[l][acc_col(wave, 1, lane)];
+            acc_map(acc, [&](int, int t, int, float v) { return fmaxf(v + (t ? b1 : b0), 0.f); });
+            if (save) acc_store_native(acc, cact + ((int64_t)l * ntiles + tile) * TILE_F, wave, lane);
+            __syncthreads();
+            acc_to_lds(acc, smain, wave, lane);
+            __syncthreads();
+        }
+        const int64_t gp = tile * TM + (tid >> 1);
+        DH_UNROLL for (int j = 0; j < 3; ++j) {
+            const float raw = row_dot256(smain, C.w4 + j * 256, tid) + C.b4[j];
+            if ((tid & 1) == 0 && gp < npts) color[gp * 3 + j] = 1.f / (1.f + __expf(-raw));
+        }
+        __syncthreads();
+    }
+}
+
+int launch_sdf_fwd_train(const float* packed, const float* pts, int64_t npts, float* sdf, float* feat, float* act,
+                         float* eaux, int grid, hipStream_t stream) {
+    const int64_t ntiles = (npts + TM - 1) / TM;
+    const int g = (int)(ntiles < grid ? ntiles : grid);
+    hipLaunchKernelGGL(sdf_fwd_train_kernel, dim3(g), dim3(256), 0, stream, make_sdf_ptrs(packed), pts, npts, sdf, feat, act, eaux);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+int launch_sdf_grad(const float* packed, const float* pts, int64_t npts, const float* act, float* asave, float* normals,
+                    int grid, hipStream_t stream) {
+    const int64_t ntiles = (npts + TM - 1) / TM;
+    const int g = (int)(ntiles < grid ? ntiles : grid);
+    hipLaunchKernelGGL(sdf_grad_kernel, dim3(g), dim3(256), 0, stream, make_sdf_ptrs(packed), pts, npts, act, asave, normals);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+int launch_color_fwd(const float* packed, const float* pts, const float* dirs, int n_per_ray, const float* normals,
+                     const float* feat, int64_t npts, float* color, float* cact, float* caux, int save, int grid,
+                     hipStream_t stream) {
+    const int64_t ntiles = (npts + TM - 1) / TM;
+    const int g = (int)(ntiles < grid ? ntiles : grid);
+    hipLaunchKernelGGL(color_fwd_kernel, dim3(g), dim3(256), 0, stream, make_col_ptrs(packed), pts, dirs, n_per_ray, normals,
+                       feat, npts, color, cact, caux, save);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
 int launch_sdf_nograd(const float* packed, const float* pts, int64_t npts, float* sdf, int grid, hipStream_t stream) {
     if (npts <= 0) return 0;
     const int64_t ntiles = (npts + TM - 1) / TM;

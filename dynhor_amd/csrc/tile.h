@@ -46,7 +46,7 @@ __device__ __forceinline__ void gemm_rows(f32x16 (&acc)[4][2], const float* xs, 
     f32x4 a0[4], b0[2], a1[4], b1[2];
     DH_UNROLL for (int t = 0; t < 2; ++t) b0[t] = wl[t * 64];
     DH_UNROLL for (int m = 0; m < 4; ++m) a0[m] = *reinterpret_cast<const f32x4*>(xrow + m * 32 * ldx);
-    for (int kg = 0; kg < nkg; kg += 2) {
+    _Pragma("unroll 1") for (int kg = 0; kg < nkg; kg += 2) {
         const int k1 = (kg + 1 < nkg) ? kg + 1 : kg;
         DH_UNROLL for (int t = 0; t < 2; ++t) b1[t] = wl[(k1 * 8 + t) * 64];
         DH_UNROLL for (int m = 0; m < 4; ++m) a1[m] = *reinterpret_cast<const f32x4*>(xrow + m * 32 * ldx + k1 * 8);
@@ -68,7 +68,7 @@ __device__ __forceinline__ void gemm_auxout(f32x16 (&acc2)[2], const float* xs, 
     f32x4 a = *reinterpret_cast<const f32x4*>(xrow);
     f32x4 b[2];
     DH_UNROLL for (int t = 0; t < 2; ++t) b[t] = wl[t * 64];
-    for (int kg = 0; kg < nkg; ++kg) {
+    _Pragma("unroll 2") for (int kg = 0; kg < nkg; ++kg) {
         const int kn = (kg + 1 < nkg) ? kg + 1 : kg;
         f32x4 an = *reinterpret_cast<const f32x4*>(xrow + kn * 8);
         f32x4 bn[2];

@@ -1,0 +1,56 @@
+// Workspace carving for one render call (caller-allocated, SURVEY §8b ownership rule).  All saved tiles are
+// "native" accumulator-layout tiles (tile.h); offsets in floats, every block 16-byte aligned.
+#pragma once
+#include "layout.h"
+
+namespace dh {
+
+constexpr int N_TILE_PART = 20;   // per-tile partial-sum slots of 256 floats (bias grads, lin8 row 0, colour lin4)
+
+struct Workspace {
+    int64_t ntiles;
+    float* base;
+    // forward (saved for backward)
+    float* act;     // [8][nt][TILE_F]   inputs of SDF layers 1..8 (post-softplus)
+    float* eaux;    // [nt][AUXT_F]      positional embedding (aux native)
+    float* feat;    // [nt][TILE_F]      lin8 rows 1..256
+    float* asave;   // [8][nt][TILE_F]   a_l = u_{l+1} * sigma'(z_l) of the input-gradient pass
+    float* cact;    // [4][nt][TILE_F]   colour post-ReLU activations (inputs of colour layers 1..4)
+    float* caux;    // [nt][AUXT_F]      colour extras [p, embed(view), n]
+    // backward
+    float* featbar; // [nt][TILE_F]      d loss / d feat
+    float* tsave;   // [7][nt][TILE_F]   tangents t_1..t_7 (inputs of the tangent GEMM of layers 1..7)
+    float* t0aux;   // [nt][AUXT_F]      t_0 = J_e nbar
+    float* rsave;   // [8][nt][TILE_F]   second-order contribution to zbar_l
+    float* zbar;    // [8][nt][TILE_F]   d loss / d z_l, l = 0..7
+    float* czbar;   // [4][nt][TILE_F]   colour d loss / d z_l
+    float* tpart;   // [nt][N_TILE_PART][256]
+    int64_t fwd_floats, total_floats;
+};
+
+inline Workspace carve_workspace(float* base, int64_t npts) {
+    Workspace w{};
+    const int64_t nt = (npts + TM - 1) / TM;
+    w.ntiles = nt;
+    w.base = base;
+    int64_t o = 0;
+    auto take = [&](int64_t n) { float* p = base ? base + o : nullptr; o += n; return p; };
+    w.act = take(8 * nt * TILE_F);
+    w.eaux = take(nt * AUXT_F);
+    w.feat = take(nt * TILE_F);
+    w.asave = take(8 * nt * TILE_F);
+    w.cact = take(4 * nt * TILE_F);
+    w.caux = take(nt * AUXT_F);
+    w.fwd_floats = o;
+    w.featbar = take(nt * TILE_F);
+    w.tsave = take(7 * nt * TILE_F);
+    w.t0aux = take(nt * AUXT_F);
+    w.rsave = take(8 * nt * TILE_F);
+    w.zbar = take(8 * nt * TILE_F);
+    w.czbar = take(4 * nt * TILE_F);
+    w.tpart = take(nt * N_TILE_PART * 256);
+    w.total_floats = o;
+    return w;
+}
+
+}  // namespace dh

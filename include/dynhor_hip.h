@@ -47,6 +47,17 @@ int dh_pack_weights(const float* params, float* packed, void* stream);
  * pts [npts,3] -> sdf [npts]. */
 int dh_sdf_nograd(const float* packed, const float* pts, int64_t npts, float* sdf, void* stream);
 
+/* Workspace size (floats) for a render call over npts fine sample points: fwd_floats is what the forward pass
+ * writes (saved activations), total_floats additionally covers the backward pass. */
+int dh_workspace_floats(int64_t npts, int64_t* fwd_floats, int64_t* total_floats);
+
+/* The MLP part of upstream NeuSRenderer.render_core (App. A.7) on npts points (point i belongs to ray
+ * i / n_per_ray): sdf_network(pts) -> sdf [npts], feature (kept in ws); sdf_network.gradient(pts) -> normals
+ * [npts,3]; color_network(pts, normals, dirs, feature) -> color [npts,3] (post-sigmoid).  Saves what
+ * dh_mlp_backward needs into ws. */
+int dh_mlp_forward(const float* packed, const float* pts, const float* dirs, int n_per_ray, int64_t npts, float* ws,
+                   float* sdf, float* normals, float* color, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
