@@ -81,4 +81,77 @@ int dh_mlp_forward(const float* packed, const float* pts, const float* dirs, int
     return launch_color_fwd(packed, pts, dirs, n_per_ray, normals, w.feat, npts, color, w.cact, w.caux, 1, DEFAULT_GRID, st);
 }
 
+int dh_gen_rays(const uint8_t* rgb, const int8_t* label, const uint8_t* normal, const float* R, const float* T,
+                const float* Kinv, int H, int W, int n_frames, int frame, const int64_t* px, const int64_t* py, int64_t B,
+                float* rays, float* near, float* far, void* stream) {
+    if (B < 0 || H <= 0 || W <= 0 || frame < 0 || frame >= n_frames) return DH_ERR_BAD_ARG;
+    if (B == 0) return DH_OK;
+    if (!rgb || !label || !normal || !R || !T || !Kinv || !px || !py || !rays || !near || !far) return DH_ERR_BAD_ARG;
+    return launch_gen_rays(rgb, label, normal, R, T, Kinv, H, W, frame, px, py, B, rays, near, far, static_cast<hipStream_t>(stream));
+}
+
+int dh_coarse_samples(const float* rays_o, const float* rays_d, const float* near, const float* far, const float* t_rand,
+                      int64_t B, int n_samples, float* z, float* pts, void* stream) {
+    if (B < 0 || n_samples <= 0) return DH_ERR_BAD_ARG;
+    if (B == 0) return DH_OK;
+    if (!rays_o || !rays_d || !near || !far || !z || !pts) return DH_ERR_BAD_ARG;
+    return launch_coarse_samples(rays_o, rays_d, near, far, t_rand, B, n_samples, z, pts, static_cast<hipStream_t>(stream));
+}
+
+int dh_upsample_step(const float* rays_o, const float* rays_d, const float* z, const float* sdf, int64_t B, int n_cur,
+                     int n_new, float inv_s, float* z_new, float* pts_new, void* stream) {
+    if (B < 0 || n_cur < 2 || n_new <= 0) return DH_ERR_BAD_ARG;
+    if (n_cur > 128 || n_new > 64) return DH_ERR_UNSUPPORTED;
+    if (B == 0) return DH_OK;
+    if (!rays_o || !rays_d || !z || !sdf || !z_new || !pts_new) return DH_ERR_BAD_ARG;
+    return launch_upsample(rays_o, rays_d, z, sdf, B, n_cur, n_new, inv_s, z_new, pts_new, static_cast<hipStream_t>(stream));
+}
+
+int dh_merge_samples(const float* z, const float* z_new, const float* sdf, const float* sdf_new, int64_t B, int n_cur,
+                     int n_new, float* z_out, float* sdf_out, void* stream) {
+    if (B < 0 || n_cur <= 0 || n_new <= 0) return DH_ERR_BAD_ARG;
+    if (n_cur > 128 || n_new > 64) return DH_ERR_UNSUPPORTED;
+    if (B == 0) return DH_OK;
+    if (!z || !z_new || !z_out) return DH_ERR_BAD_ARG;
+    if (sdf_out && (!sdf || !sdf_new)) return DH_ERR_BAD_ARG;
+    return launch_merge(z, z_new, sdf, sdf_new, B, n_cur, n_new, z_out, sdf_out, static_cast<hipStream_t>(stream));
+}
+
+int dh_midpoints(const float* rays_o, const float* rays_d, const float* z, int64_t B, int n, float sample_dist, float* pts,
+                 void* stream) {
+    if (B < 0 || n <= 0) return DH_ERR_BAD_ARG;
+    if (B == 0) return DH_OK;
+    if (!rays_o || !rays_d || !z || !pts) return DH_ERR_BAD_ARG;
+    return launch_midpoints(rays_o, rays_d, z, B, n, sample_dist, pts, static_cast<hipStream_t>(stream));
+}
+
+int dh_render_scan_fwd(const float* rays_o, const float* rays_d, const float* z, const float* sdf, const float* normals,
+                       const float* colors, const float* inv_s, float cos_anneal_ratio, float sample_dist,
+                       const float* background_rgb, int64_t B, int n, float* weights, float* color, float* weight_sum,
+                       float* weight_max, float* cdf, float* inside_sphere, float* eik_partial, void* stream) {
+    if (B < 0 || n <= 0) return DH_ERR_BAD_ARG;
+    if (n > 128) return DH_ERR_UNSUPPORTED;
+    if (B == 0) return DH_OK;
+    if (!rays_o || !rays_d || !z || !sdf || !normals || !colors || !inv_s || !weights || !color || !weight_sum ||
+        !weight_max || !cdf || !inside_sphere || !eik_partial) return DH_ERR_BAD_ARG;
+    return launch_render_fwd(rays_o, rays_d, z, sdf, normals, colors, inv_s, cos_anneal_ratio, sample_dist, background_rgb,
+                             B, n, weights, color, weight_sum, weight_max, cdf, inside_sphere, eik_partial,
+                             static_cast<hipStream_t>(stream));
+}
+
+int dh_render_scan_bwd(const float* rays_o, const float* rays_d, const float* z, const float* sdf, const float* normals,
+                       const float* colors, const float* inv_s, float cos_anneal_ratio, float sample_dist,
+                       const float* background_rgb, int64_t B, int n, const float* d_color, const float* d_weight_sum,
+                       const float* d_weights, const float* d_gradients, const float* eik_coef, float* d_sdf,
+                       float* d_normals, float* d_colors, float* d_inv_s, void* stream) {
+    if (B < 0 || n <= 0) return DH_ERR_BAD_ARG;
+    if (n > 128) return DH_ERR_UNSUPPORTED;
+    if (B == 0) return DH_OK;
+    if (!rays_o || !rays_d || !z || !sdf || !normals || !colors || !inv_s || !d_color || !eik_coef || !d_sdf ||
+        !d_normals || !d_colors || !d_inv_s) return DH_ERR_BAD_ARG;
+    return launch_render_bwd(rays_o, rays_d, z, sdf, normals, colors, inv_s, cos_anneal_ratio, sample_dist, background_rgb,
+                             B, n, d_color, d_weight_sum, d_weights, d_gradients, eik_coef, d_sdf, d_normals, d_colors,
+                             d_inv_s, static_cast<hipStream_t>(stream));
+}
+
 }  // extern "C"

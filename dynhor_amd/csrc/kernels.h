@@ -19,4 +19,26 @@ int launch_color_fwd(const float* packed, const float* pts, const float* dirs, i
                      const float* feat, int64_t npts, float* color, float* cact, float* caux, int save, int grid,
                      hipStream_t stream);
 
+// per-ray kernels (kernels_ray.hip)
+int launch_gen_rays(const uint8_t* rgb, const int8_t* label, const uint8_t* normal, const float* R, const float* T,
+                    const float* Kinv, int H, int W, int frame, const int64_t* px, const int64_t* py, int64_t B,
+                    float* rays, float* near, float* far, hipStream_t st);
+int launch_coarse_samples(const float* o, const float* d, const float* near, const float* far, const float* t_rand,
+                          int64_t B, int n, float* z, float* pts, hipStream_t st);
+int launch_upsample(const float* o, const float* d, const float* z, const float* sdf, int64_t B, int n, int n_new,
+                    float inv_s, float* z_new, float* pts_new, hipStream_t st);
+int launch_merge(const float* z, const float* z_new, const float* sdf, const float* sdf_new, int64_t B, int n, int n_new,
+                 float* z_out, float* sdf_out, hipStream_t st);
+int launch_midpoints(const float* o, const float* d, const float* z, int64_t B, int n, float sample_dist, float* pts,
+                     hipStream_t st);
+int launch_render_fwd(const float* o, const float* d, const float* z, const float* sdf, const float* normals,
+                      const float* colors, const float* inv_s, float car, float sample_dist, const float* bg, int64_t B,
+                      int n, float* weights, float* color, float* wsum, float* wmax, float* cdf, float* inside, float* eik,
+                      hipStream_t st);
+int launch_render_bwd(const float* o, const float* d, const float* z, const float* sdf, const float* normals,
+                      const float* colors, const float* inv_s, float car, float sample_dist, const float* bg, int64_t B,
+                      int n, const float* d_color, const float* d_wsum, const float* d_weights, const float* d_gradients,
+                      const float* eik_coef, float* d_sdf, float* d_normals, float* d_colors, float* d_inv_s,
+                      hipStream_t st);
+
 }  // namespace dh

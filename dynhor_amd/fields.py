@@ -1,0 +1,154 @@
+"""Network parameter containers with the upstream-NeuS constructor signatures and state_dict keys
+(SURVEY.md App. A.2/A.3, §5 checkpoint row): ``lin{l}.bias / lin{l}.weight_g / lin{l}.weight_v`` (legacy
+weight_norm names), ``variance``.
+
+These modules hold parameters only: every evaluation goes through the HIP kernels (dynhor_amd.renderer); there is
+no eager forward.  All parameters of a model live in ONE flat fp32 device vector (ParamStore) in the order of
+include/dynhor_hip.h:dh_param_layout, so the weight packer, the fused Adam and the RCCL gradient all-reduce each
+touch a single contiguous buffer.
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _lib
+
+
+class _WNLinearParams(nn.Module):
+    """bias, weight_g, weight_v of a weight-normed Linear (registration order == legacy weight_norm state_dict)."""
+
+    def __init__(self, weight: torch.Tensor, bias: torch.Tensor):
+        super().__init__()
+        self.bias = nn.Parameter(bias.clone())
+        self.weight_g = nn.Parameter(weight.norm(dim=1, keepdim=True).clone())
+        self.weight_v = nn.Parameter(weight.clone())
+
+    def forward(self, *a, **k):  # pragma: no cover
+        raise RuntimeError("dynhor_amd modules have no eager forward; use NeuSRenderer (HIP path)")
+
+
+class SDFNetwork(nn.Module):
+    """Upstream SDFNetwork(d_in, d_out, d_hidden, n_layers, skip_in, multires, bias, scale, geometric_init,
+    weight_norm, inside_outside) -- parameters + geometric init only (App. A.2)."""
+
+    def __init__(self, d_in=3, d_out=257, d_hidden=256, n_layers=8, skip_in=(4,), multires=6, bias=0.5, scale=1.0,
+                 geometric_init=True, weight_norm=True, inside_outside=False):
+        super().__init__()
+        if (d_in, d_out, d_hidden, n_layers, tuple(skip_in), multires, scale, weight_norm, inside_outside) != \
+                (3, 257, 256, 8, (4,), 6, 1.0, True, False):
+            raise ValueError("unsupported SDFNetwork configuration for the gfx950 kernels (DH_ERR_UNSUPPORTED): "
+                             "only the NeuS wmask configuration d_hidden=256, n_layers=8, skip_in=(4,), multires=6")
+        d0 = d_in + 2 * d_in * multires
+        dims = [d0] + [d_hidden] * n_layers + [d_out]
+        self.num_layers = len(dims)
+        self.skip_in = tuple(skip_in)
+        self.scale = scale
+        for l in range(self.num_layers - 1):
+            out_dim = dims[l + 1] - dims[0] if (l + 1) in self.skip_in else dims[l + 1]
+            w = torch.empty(out_dim, dims[l])
+            b = torch.empty(out_dim)
+            if geometric_init:
+                if l == self.num_layers - 2:
+                    nn.init.normal_(w, mean=np.sqrt(np.pi) / np.sqrt(dims[l]), std=0.0001)
+                    nn.init.constant_(b, -bias)
+                elif l == 0:
+                    nn.init.constant_(b, 0.0)
+                    nn.init.constant_(w[:, 3:], 0.0)
+                    nn.init.normal_(w[:, :3], 0.0, np.sqrt(2) / np.sqrt(out_dim))
+                elif l in self.skip_in:
+                    nn.init.constant_(b, 0.0)
+                    nn.init.normal_(w, 0.0, np.sqrt(2) / np.sqrt(out_dim))
+                    nn.init.constant_(w[:, -(dims[0] - 3):], 0.0)
+                else:
+                    nn.init.constant_(b, 0.0)
+                    nn.init.normal_(w, 0.0, np.sqrt(2) / np.sqrt(out_dim))
+            else:
+                lin = nn.Linear(dims[l], out_dim)
+                w, b = lin.weight.data, lin.bias.data
+            setattr(self, "lin" + str(l), _WNLinearParams(w, b))
+
+
+class RenderingNetwork(nn.Module):
+    """Upstream RenderingNetwork(d_feature, mode, d_in, d_out, d_hidden, n_layers, weight_norm, multires_view,
+    squeeze_out) -- parameters only (App. A.3)."""
+
+    def __init__(self, d_feature=256, mode="idr", d_in=9, d_out=3, d_hidden=256, n_layers=4, weight_norm=True,
+                 multires_view=4, squeeze_out=True):
+        super().__init__()
+        if (d_feature, mode, d_in, d_out, d_hidden, n_layers, weight_norm, multires_view, squeeze_out) != \
+                (256, "idr", 9, 3, 256, 4, True, 4, True):
+            raise ValueError("unsupported RenderingNetwork configuration for the gfx950 kernels (DH_ERR_UNSUPPORTED)")
+        d0 = d_in + d_feature + 2 * 3 * multires_view
+        dims = [d0] + [d_hidden] * n_layers + [d_out]
+        self.num_layers = len(dims)
+        for l in range(self.num_layers - 1):
+            lin = nn.Linear(dims[l], dims[l + 1])
+            setattr(self, "lin" + str(l), _WNLinearParams(lin.weight.data, lin.bias.data))
+
+
+class SingleVarianceNetwork(nn.Module):
+    def __init__(self, init_val=0.3):
+        super().__init__()
+        self.register_parameter("variance", nn.Parameter(torch.tensor(float(init_val))))
+
+
+class ParamStore:
+    """One flat fp32 device vector holding every parameter (views handed back to the modules), its packed
+    MFMA-operand image, the last flat gradient and the fused-Adam moments."""
+
+    def __init__(self, sdf_network: SDFNetwork, deviation_network: SingleVarianceNetwork, color_network: RenderingNetwork,
+                 device):
+        L = _lib.lib()
+        self.device = torch.device(device)
+        self.n = int(L.dh_num_params())
+        self.modules = (sdf_network, deviation_network, color_network)
+        self.flat = torch.empty(self.n, device=self.device, dtype=torch.float32)
+        self.slices = []          # (param, offset, numel)
+        for net, mod in ((0, sdf_network), (2, color_network)):
+            n_layers = 9 if net == 0 else 5
+            for l in range(n_layers):
+                b, g, v, out_dim, in_dim = _lib.param_layout(net, l)
+                lin = getattr(mod, "lin" + str(l))
+                assert tuple(lin.weight_v.shape) == (out_dim, in_dim), (net, l, lin.weight_v.shape)
+                self.slices += [(lin.bias, b, out_dim), (lin.weight_g, g, out_dim), (lin.weight_v, v, out_dim * in_dim)]
+        _, _, voff, _, _ = _lib.param_layout(1, 0)
+        self.var_off = voff
+        self.slices.append((deviation_network.variance, voff, 1))
+        self.slices.sort(key=lambda s: s[1])
+        end = 0
+        for p, off, n in self.slices:
+            assert off == end, "flat layout must be dense"
+            end = off + n
+            self.flat[off:off + n].copy_(p.detach().reshape(-1).to(self.device, torch.float32))
+            p.data = self.flat[off:off + n].view(p.shape)
+        assert end == self.n
+        self.packed = torch.empty(int(L.dh_packed_floats()), device=self.device, dtype=torch.float32)
+        self._packed_version = None
+        self.grad_flat = None
+        self.exp_avg = torch.zeros_like(self.flat)
+        self.exp_avg_sq = torch.zeros_like(self.flat)
+        self.step_count = 0
+        self._manual_version = 0
+
+    def params(self):
+        return [p for p, _, _ in self.slices]
+
+    def bump(self):
+        """Call after any write to ``flat`` that bypasses torch (the fused Adam kernel)."""
+        self._manual_version += 1
+
+    def ensure_packed(self):
+        # p.data aliases flat but keeps its own version counter, so fold every counter in
+        ver = (self.flat._version, self._manual_version, sum(p._version for p, _, _ in self.slices))
+        if ver != self._packed_version:
+            _lib.check(_lib.lib().dh_pack_weights(_lib.ptr(self.flat), _lib.ptr(self.packed), _lib.stream()))
+            self._packed_version = ver
+        return self.packed
+
+    def inv_s(self) -> torch.Tensor:
+        """clip(exp(10 variance), 1e-6, 1e6) as a 1-element device tensor (App. A.7)."""
+        return torch.exp(self.flat[self.var_off:self.var_off + 1] * 10.0).clip(1e-6, 1e6)

@@ -58,6 +58,52 @@ int dh_workspace_floats(int64_t npts, int64_t* fwd_floats, int64_t* total_floats
 int dh_mlp_forward(const float* packed, const float* pts, const float* dirs, int n_per_ray, int64_t npts, float* ws,
                    float* sdf, float* normals, float* color, void* stream);
 
+/* ---- per-ray stages ---------------------------------------------------------------------------------------
+ * Mask-conditioned ray generation = upstream Dataset.gen_random_rays_at + near_far_from_sphere (App. A.8) under the
+ * reference's hand-off conventions: K per ObjTracker/run.py:119-123 (Kinv = its inverse, row-major [9]); pose
+ * x_cam = R x_obj + T per run.py:166 / vis.py:52 (R [F,9] row-major, T [F,3]); label map 1 object / 0 background /
+ * -1 hand per run.py:66 and utils/maskutils.py:24-28; obj = label>0, keep = label>=0 per pose_initializtion.py:60-61.
+ * Frames stay resident in HBM: rgb u8 [F,H,W,3], label i8 [F,H,W], normal u8 [F,H,W,3] (n = u8/255*2-1, camera frame).
+ * rays [B,14] = o(3) d(3) rgb(3) obj(1) keep(1) mono_normal(3); near/far [B]. */
+int dh_gen_rays(const uint8_t* rgb, const int8_t* label, const uint8_t* normal, const float* R, const float* T,
+                const float* Kinv, int H, int W, int n_frames, int frame, const int64_t* px, const int64_t* py, int64_t B,
+                float* rays, float* near, float* far, void* stream);
+
+/* coarse z = near + (far-near) linspace(0,1,n) + (t_rand-0.5)*2/n (t_rand [B] or NULL) and pts = o + d z
+ * (upstream NeuSRenderer.render, App. A.5). */
+int dh_coarse_samples(const float* rays_o, const float* rays_d, const float* near, const float* far, const float* t_rand,
+                      int64_t B, int n_samples, float* z, float* pts, void* stream);
+
+/* upstream NeuSRenderer.up_sample + sample_pdf(det=True) (App. A.6): z,sdf [B,n_cur] -> z_new [B,n_new] and
+ * pts_new [B*n_new,3].  n_cur <= 128, n_new <= 64. */
+int dh_upsample_step(const float* rays_o, const float* rays_d, const float* z, const float* sdf, int64_t B, int n_cur,
+                     int n_new, float inv_s, float* z_new, float* pts_new, void* stream);
+
+/* upstream NeuSRenderer.cat_z_vals (App. A.6): stable sorted merge; sdf gathered alongside unless sdf_out is NULL
+ * (the `last` step). */
+int dh_merge_samples(const float* z, const float* z_new, const float* sdf, const float* sdf_new, int64_t B, int n_cur,
+                     int n_new, float* z_out, float* sdf_out, void* stream);
+
+/* section mid-points of render_core (App. A.7): pts [B*n,3] = o + d (z + dists/2). */
+int dh_midpoints(const float* rays_o, const float* rays_d, const float* z, int64_t B, int n, float sample_dist, float* pts,
+                 void* stream);
+
+/* render_core tail (App. A.7): alpha from (sdf, normals, inv_s[0], cos_anneal), transmittance scan, compositing.
+ * weights/cdf/inside_sphere [B,n]; color [B,3]; weight_sum/weight_max [B]; eik_partial [B,2] = per-ray
+ * (sum relax*(|n|-1)^2, sum relax).  n <= 128.  background_rgb [3] or NULL. */
+int dh_render_scan_fwd(const float* rays_o, const float* rays_d, const float* z, const float* sdf, const float* normals,
+                       const float* colors, const float* inv_s, float cos_anneal_ratio, float sample_dist,
+                       const float* background_rgb, int64_t B, int n, float* weights, float* color, float* weight_sum,
+                       float* weight_max, float* cdf, float* inside_sphere, float* eik_partial, void* stream);
+
+/* adjoint of dh_render_scan_fwd.  d_weight_sum, d_weights [B,n], d_gradients [B*n,3] may be NULL; eik_coef[0] =
+ * d(loss)/d(gradient_error) / (sum relax + 1e-5).  d_inv_s [B] holds per-ray partial sums. */
+int dh_render_scan_bwd(const float* rays_o, const float* rays_d, const float* z, const float* sdf, const float* normals,
+                       const float* colors, const float* inv_s, float cos_anneal_ratio, float sample_dist,
+                       const float* background_rgb, int64_t B, int n, const float* d_color, const float* d_weight_sum,
+                       const float* d_weights, const float* d_gradients, const float* eik_coef, float* d_sdf,
+                       float* d_normals, float* d_colors, float* d_inv_s, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,83 @@
+import pytest
+import torch
+
+from oracle import neus_oracle as O
+from tests.util import randomized_models
+
+pytestmark = pytest.mark.gpu
+
+
+def make_pair(seed=5, jitter=0.05, n_samples=64, n_importance=64, dev="cuda:0"):
+    """(oracle renderer, product renderer) with identical weights."""
+    from dynhor_amd.fields import RenderingNetwork, SDFNetwork, SingleVarianceNetwork
+    from dynhor_amd.renderer import NeuSRenderer
+    sdf, col, var = randomized_models(seed=seed, device=dev, jitter=jitter)
+    o_r = O.NeuSRenderer(None, sdf, var, col, n_samples, n_importance, 0, 4, 1.0)
+    psdf, pcol, pvar = SDFNetwork(), RenderingNetwork(), SingleVarianceNetwork(0.3)
+    psdf.load_state_dict(sdf.state_dict()); pcol.load_state_dict(col.state_dict()); pvar.load_state_dict(var.state_dict())
+    p_r = NeuSRenderer(None, psdf, pvar, pcol, n_samples, n_importance, 0, 4, 1.0, device=dev)
+    return o_r, p_r
+
+
+def make_rays(B, seed=0, dev="cuda:0"):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    o = torch.nn.functional.normalize(torch.randn(B, 3, generator=g), dim=-1) * 2.3
+    tgt = (torch.rand(B, 3, generator=g) - 0.5) * 0.8
+    d = torch.nn.functional.normalize(tgt - o, dim=-1)
+    o, d = o.to(dev), d.to(dev)
+    near, far = O.near_far_from_sphere(o, d)
+    t_rand = torch.rand(B, 1, generator=g).to(dev)
+    return o, d, near, far, t_rand
+
+
+def test_state_dict_keys_match_oracle():
+    o_r, p_r = make_pair()
+    assert list(o_r.sdf_network.state_dict().keys()) == list(p_r.sdf_network.state_dict().keys())
+    assert list(o_r.color_network.state_dict().keys()) == list(p_r.color_network.state_dict().keys())
+    assert list(o_r.deviation_network.state_dict().keys()) == list(p_r.deviation_network.state_dict().keys())
+
+
+@pytest.mark.parametrize("B,ns,ni", [(5, 64, 64), (257, 64, 64), (64, 32, 32), (33, 64, 0)])
+def test_sample_z_matches_oracle(B, ns, ni):
+    o_r, p_r = make_pair(n_samples=ns, n_importance=ni)
+    o, d, near, far, t_rand = make_rays(B, seed=B)
+    z_ref = o_r.sample_z(o, d, near, far, t_rand=t_rand)
+    z_hip = p_r.sample_z(o, d, near, far, t_rand=t_rand)
+    # fp64 oracle: where alpha sits at the 1e-5 floor (rays through empty space) the inverse-CDF sample is
+    # ill-conditioned in fp32, for torch's own fp32 evaluation as much as for ours -- measure both against fp64.
+    o64 = O.NeuSRenderer(None, o_r.sdf_network.double(), o_r.deviation_network.double(), o_r.color_network.double(),
+                         ns, ni, 0, 4, 1.0)
+    z64 = o64.sample_z(o.double(), d.double(), near.double(), far.double(), t_rand=t_rand.double())
+    o_r.sdf_network.float(); o_r.deviation_network.float(); o_r.color_network.float()
+    assert z_hip.shape == z_ref.shape
+    assert torch.isfinite(z_hip).all()
+    assert (z_hip[:, 1:] >= z_hip[:, :-1]).all(), "sortedness"
+    e_hip = (z_hip.double() - z64).abs()
+    e_t32 = (z_ref.double() - z64).abs()
+    bad_hip = (e_hip > 1e-4).float().mean().item()
+    bad_t32 = (e_t32 > 1e-4).float().mean().item()
+    print(f"B={B} ns={ns} ni={ni}: hip max|dz|={e_hip.max().item():.3e} frac>1e-4={bad_hip:.2e} median={e_hip.median().item():.2e}"
+          f" | torch32 max={e_t32.max().item():.3e} frac={bad_t32:.2e} median={e_t32.median().item():.2e}")
+    # stated tolerance: |dz| <= 1e-4 on z in [~1.3, ~3.3], except for a fraction of ill-conditioned samples no
+    # larger than 2x what torch-fp32 itself shows against fp64 (+1e-3)
+    assert bad_hip <= 2.0 * bad_t32 + 1e-3
+    assert e_hip.median().item() < 1e-5
+
+
+@pytest.mark.parametrize("B,ns,ni,bg,car", [(7, 64, 64, False, 0.0), (130, 64, 64, True, 0.37), (64, 32, 32, False, 1.0)])
+def test_render_forward_matches_oracle(B, ns, ni, bg, car):
+    o_r, p_r = make_pair(n_samples=ns, n_importance=ni)
+    o, d, near, far, t_rand = make_rays(B, seed=100 + B)
+    z = o_r.sample_z(o, d, near, far, t_rand=t_rand)
+    bg_rgb = torch.ones(1, 3, device=o.device) if bg else None
+    ref = o_r.render(o, d, near, far, background_rgb=bg_rgb, cos_anneal_ratio=car, z_vals=z)
+    with torch.no_grad():
+        got = p_r.render(o, d, near, far, background_rgb=bg_rgb, cos_anneal_ratio=car, z_vals=z)
+    for k, tol in (("color_fine", 2e-5), ("weight_sum", 2e-5), ("weights", 2e-5), ("weight_max", 2e-5),
+                   ("cdf_fine", 2e-5), ("gradients", 2e-4), ("gradient_error", 2e-5), ("s_val", 1e-7),
+                   ("inside_sphere", 0.5)):
+        a, b = got[k].float(), ref[k].detach().float()
+        assert a.shape == b.shape, (k, a.shape, b.shape)
+        e = (a - b).abs().max().item()
+        print(f"{k}: max err {e:.3e}")
+        assert e < tol, k
