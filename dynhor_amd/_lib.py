@@ -22,6 +22,7 @@ SIGNATURES = {
     "dh_sdf_nograd": (_i32, [_vp, _vp, _i64, _vp, _vp]),
     "dh_workspace_floats": (_i32, [_i64, ctypes.POINTER(_i64), ctypes.POINTER(_i64)]),
     "dh_mlp_forward": (_i32, [_vp, _vp, _vp, _i32, _i64, _vp, _vp, _vp, _vp, _vp]),
+    "dh_mlp_backward": (_i32, [_vp, _vp, _vp, _i64] + [_vp] * 7),
     "dh_gen_rays": (_i32, [_vp] * 6 + [_i32, _i32, _i32, _i32, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),
     "dh_coarse_samples": (_i32, [_vp] * 5 + [_i64, _i32, _vp, _vp, _vp]),
     "dh_upsample_step": (_i32, [_vp] * 4 + [_i64, _i32, _i32, _f32, _vp, _vp, _vp]),

@@ -154,4 +154,21 @@ int dh_render_scan_bwd(const float* rays_o, const float* rays_d, const float* z,
                              d_inv_s, static_cast<hipStream_t>(stream));
 }
 
+int dh_mlp_backward(const float* packed, const float* params, const float* pts, int64_t npts, float* ws,
+                    const float* colors, const float* d_sdf, float* d_normals, const float* d_colors, float* grad_flat,
+                    void* stream) {
+    if (npts <= 0) return DH_ERR_BAD_ARG;
+    if (!packed || !params || !pts || !ws || !colors || !d_sdf || !d_normals || !d_colors || !grad_flat ||
+        misaligned16(packed) || misaligned16(ws)) return DH_ERR_BAD_ARG;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const Workspace w = carve_workspace(ws, npts);
+    int rc = launch_color_bwd(packed, colors, d_colors, npts, w.cact, w.czbar, w.featbar, d_normals, w.tpart, DEFAULT_GRID, st);
+    if (rc) return rc;
+    rc = launch_sdf_tangent(packed, pts, d_normals, npts, w.act, w.asave, w.t0aux, w.tsave, w.rsave, w.tpart, DEFAULT_GRID, st);
+    if (rc) return rc;
+    rc = launch_sdf_bwd(packed, d_sdf, npts, w.act, w.rsave, w.featbar, w.zbar, w.tpart, DEFAULT_GRID, st);
+    if (rc) return rc;
+    return launch_weight_grads(w, w.slabs, w.tred, DW_G, DW_NS, params, packed, grad_flat, st);
+}
+
 }  // extern "C"

@@ -41,4 +41,15 @@ int launch_render_bwd(const float* o, const float* d, const float* z, const floa
                       const float* eik_coef, float* d_sdf, float* d_normals, float* d_colors, float* d_inv_s,
                       hipStream_t st);
 
+// backward chains (kernels_mlp_bwd.hip) and weight gradients (dw.hip)
+int launch_color_bwd(const float* packed, const float* colors, const float* d_colors, int64_t npts, const float* cact,
+                     float* czbar, float* featbar, float* d_normals, float* tpart, int grid, hipStream_t st);
+int launch_sdf_tangent(const float* packed, const float* pts, const float* d_normals, int64_t npts, const float* act,
+                       const float* asave, float* t0aux, float* tsave, float* rsave, float* tpart, int grid, hipStream_t st);
+int launch_sdf_bwd(const float* packed, const float* d_sdf, int64_t npts, const float* act, const float* rsave,
+                   const float* featbar, float* zbar, float* tpart, int grid, hipStream_t st);
+struct Workspace;
+int launch_weight_grads(const Workspace& w, float* slabs, float* tred, int G, int nS, const float* params,
+                        const float* packed, float* grad, hipStream_t st);
+
 }  // namespace dh

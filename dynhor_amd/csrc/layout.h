@@ -78,7 +78,8 @@ struct PackOff {
     int64_t col_bias[N_COL];       // 256 each for l<4
     int64_t col_w4;                // 3*256 row-major
     int64_t col_b4;                // 4
-    int64_t rowscale;              // g/||v|| per row of every linear: sdf (9*257 padded) then colour (5*256)
+    int64_t rowscale;              // g/||v|| per row of every linear: sdf (9 x 260) then colour (5 x 256)
+    int64_t invnorm;               // 1/||v|| per row, same indexing
     int64_t total;
 };
 
@@ -106,6 +107,7 @@ constexpr PackOff make_pack_off() {
     p.col_w4 = o; o += 3 * HID;
     p.col_b4 = o; o += 4;
     p.rowscale = o; o += (int64_t)N_SDF * 260 + (int64_t)N_COL * 256;
+    p.invnorm = o; o += (int64_t)N_SDF * 260 + (int64_t)N_COL * 256;
     p.total = (o + 3) / 4 * 4;
     return p;
 }

@@ -1,0 +1,111 @@
+// Helpers shared by the forward and backward MLP chain kernels.
+#pragma once
+#include "tile.h"
+
+namespace dh {
+
+// ------------------------------------------------------------------------------------------------
+// positional embedding of 128 points into the LDS aux image: [x, sin(2^k x), cos(2^k x)]_{k<6}  (App. A.1)
+// 256 threads: thread handles point tid&127 and frequencies 3*(tid>>7) .. +2.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void embed_tile(const float* __restrict__ pts, int64_t base, int64_t npts, float* aux, int tid) {
+    const int p = tid & 127, half = tid >> 7;
+    const int64_t gp = base + p;
+    float x[3] = {0.f, 0.f, 0.f};
+    if (gp < npts) { x[0] = pts[gp * 3 + 0]; x[1] = pts[gp * 3 + 1]; x[2] = pts[gp * 3 + 2]; }
+    float* row = aux + p * LDA;
+    if (half == 0) { row[0] = x[0]; row[1] = x[1]; row[2] = x[2]; }
+    else           { row[39] = 0.f; row[40] = 0.f; row[41] = 0.f; row[42] = 0.f; row[43] = 0.f; }
+    DH_UNROLL for (int kk = 0; kk < 3; ++kk) {
+        const int k = half * 3 + kk;
+        const float f = (float)(1 << k);
+        DH_UNROLL for (int c = 0; c < 3; ++c) {
+            float s, co;
+            sincosf(x[c] * f, &s, &co);
+            row[3 + 6 * k + c] = s;
+            row[3 + 6 * k + 3 + c] = co;
+        }
+    }
+}
+
+template <class F>
+__device__ __forceinline__ void acc_map(f32x16 (&acc)[4][2], F f) {
+    DH_UNROLL for (int m = 0; m < 4; ++m)
+        DH_UNROLL for (int t = 0; t < 2; ++t)
+            DH_UNROLL for (int r = 0; r < 16; ++r) acc[m][t][r] = f(m, t, r, acc[m][t][r]);
+}
+
+// per-point dot of the LDS main tile rows with a 256-vector: 2 threads per point, result valid on even threads
+__device__ __forceinline__ float row_dot256(const float* main, const float* __restrict__ w, int tid) {
+    const int p = tid >> 1, half = tid & 1;
+    const f32x4* xr = reinterpret_cast<const f32x4*>(main + p * LDX + half * 128);
+    const f32x4* wr = reinterpret_cast<const f32x4*>(w + half * 128);
+    float s = 0.f;
+    DH_UNROLL for (int i = 0; i < 32; ++i) {
+        const f32x4 a = xr[i], b = wr[i];
+        s = fmaf(a[0], b[0], s); s = fmaf(a[1], b[1], s); s = fmaf(a[2], b[2], s); s = fmaf(a[3], b[3], s);
+    }
+    s += __shfl_xor(s, 1);
+    return s;
+}
+
+struct SdfPtrs {
+    const f32x4* fwd_main[N_SDF];
+    const f32x4* fwd_aux[N_SDF];
+    const f32x4* rev_main[N_SDF];
+    const f32x4* rev_aux[N_SDF];
+    const float* bias[N_SDF];
+    const float* w8row0;
+    const float* b8_0;
+};
+
+static inline SdfPtrs make_sdf_ptrs(const float* packed) {
+    SdfPtrs P;
+    for (int l = 0; l < N_SDF; ++l) {
+        P.fwd_main[l] = reinterpret_cast<const f32x4*>(packed + PACK.sdf_fwd_main[l]);
+        P.fwd_aux[l] = reinterpret_cast<const f32x4*>(packed + PACK.sdf_fwd_aux[l]);
+        P.rev_main[l] = reinterpret_cast<const f32x4*>(packed + PACK.sdf_rev_main[l]);
+        P.rev_aux[l] = reinterpret_cast<const f32x4*>(packed + PACK.sdf_rev_aux[l]);
+        P.bias[l] = packed + PACK.sdf_bias[l];
+    }
+    P.w8row0 = packed + PACK.sdf_w8row0;
+    P.b8_0 = packed + PACK.sdf_b8_0;
+    return P;
+}
+
+struct ColPtrs {
+    const f32x4* fwd_main[4];
+    const f32x4* rev_main[4];
+    const f32x4* fwd_aux0;
+    const f32x4* rev_aux0;
+    const float* bias[4];
+    const float* w4;
+    const float* b4;
+};
+static inline ColPtrs make_col_ptrs(const float* packed) {
+    ColPtrs C;
+    for (int l = 0; l < 4; ++l) {
+        C.fwd_main[l] = reinterpret_cast<const f32x4*>(packed + PACK.col_fwd_main[l]);
+        C.rev_main[l] = reinterpret_cast<const f32x4*>(packed + PACK.col_rev_main[l]);
+        C.bias[l] = packed + PACK.col_bias[l];
+    }
+    C.fwd_aux0 = reinterpret_cast<const f32x4*>(packed + PACK.col_fwd_aux0);
+    C.rev_aux0 = reinterpret_cast<const f32x4*>(packed + PACK.col_rev_aux0);
+    C.w4 = packed + PACK.col_w4;
+    C.b4 = packed + PACK.col_b4;
+    return C;
+}
+
+
+// column sums of a [128 x 256] accumulator tile -> dst[256]
+__device__ __forceinline__ void tile_colsum(const f32x16 (&acc)[4][2], float* __restrict__ dst, int wave, int lane) {
+    DH_UNROLL for (int t = 0; t < 2; ++t) {
+        float s = 0.f;
+        DH_UNROLL for (int m = 0; m < 4; ++m)
+            DH_UNROLL for (int r = 0; r < 16; ++r) s += acc[m][t][r];
+        s += __shfl_xor(s, 32);
+        if (lane < 32) dst[64 * wave + 32 * t + lane] = s;
+    }
+}
+
+}  // namespace dh

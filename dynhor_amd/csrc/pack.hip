@@ -23,7 +23,9 @@ __global__ __launch_bounds__(256) void rowscale_kernel(const float* __restrict__
     for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
     if (lane == 0) {
         const int64_t ro = PACK.rowscale + (is_sdf ? (int64_t)l * 260 : (int64_t)N_SDF * 260 + (int64_t)l * 256);
-        packed[ro + row] = params[goff + row] / sqrtf(s);
+        const float inv = 1.f / sqrtf(s);
+        packed[ro + row] = params[goff + row] * inv;
+        packed[ro + row + (PACK.invnorm - PACK.rowscale)] = inv;
     }
 }
 

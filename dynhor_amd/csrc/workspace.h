@@ -5,7 +5,10 @@
 
 namespace dh {
 
-constexpr int N_TILE_PART = 20;   // per-tile partial-sum slots of 256 floats (bias grads, lin8 row 0, colour lin4)
+constexpr int N_TILE_PART = 20;
+constexpr int DW_G = 32;          // split-K factor of the weight-gradient GEMMs
+constexpr int DW_NS = 16;         // split factor of the tile-partial reduction
+int64_t dw_slab_floats(int G);   // per-tile partial-sum slots of 256 floats (bias grads, lin8 row 0, colour lin4)
 
 struct Workspace {
     int64_t ntiles;
@@ -25,6 +28,8 @@ struct Workspace {
     float* zbar;    // [8][nt][TILE_F]   d loss / d z_l, l = 0..7
     float* czbar;   // [4][nt][TILE_F]   colour d loss / d z_l
     float* tpart;   // [nt][N_TILE_PART][256]
+    float* tred;    // [DW_NS][N_TILE_PART][256]
+    float* slabs;   // dW split-K slabs (dw.hip)
     int64_t fwd_floats, total_floats;
 };
 
@@ -49,6 +54,8 @@ inline Workspace carve_workspace(float* base, int64_t npts) {
     w.zbar = take(8 * nt * TILE_F);
     w.czbar = take(4 * nt * TILE_F);
     w.tpart = take(nt * N_TILE_PART * 256);
+    w.tred = take((int64_t)DW_NS * N_TILE_PART * 256);
+    w.slabs = take(dw_slab_floats(DW_G));
     w.total_floats = o;
     return w;
 }

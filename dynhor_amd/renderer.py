@@ -59,6 +59,9 @@ class _RenderCoreFn(torch.autograd.Function):
         eik_sum = eik.sum(dim=0)
         gradient_error = eik_sum[0] / (eik_sum[1] + 1e-5)
         gradients = normals.view(B, n, 3)
+        ctx.set_materialize_grads(False)
+        renderer._ws_token += 1
+        ctx.ws_token = renderer._ws_token
         ctx.renderer = renderer
         ctx.meta = (B, n, float(cos_anneal_ratio), sample_dist)
         ctx.save_for_backward(rays_o, rays_d, z_vals, pts, sdf, normals, colors, inv_s, eik_sum, background_rgb
@@ -97,6 +100,7 @@ class NeuSRenderer:
         self.perturb = perturb
         self.store = store if store is not None else ParamStore(sdf_network, deviation_network, color_network, device)
         self._ws = None
+        self._ws_token = 0
 
     # ------------------------------------------------------------------ workspace (caller-owned, reused)
     def _workspace(self, npts: int) -> torch.Tensor:
@@ -187,4 +191,39 @@ class NeuSRenderer:
 
     # ------------------------------------------------------------------ backward (filled in by renderer_bwd)
     def _backward(self, ctx, d_color, d_wsum, d_ge, d_weights, d_gradients, d_sdf_out):
-        raise NotImplementedError
+        L = _lib.lib()
+        st = self.store
+        if ctx.ws_token != self._ws_token:
+            raise RuntimeError("NeuSRenderer workspace was overwritten by a later render() call before backward(); "
+                               "call backward() before rendering again (one live graph per renderer)")
+        rays_o, rays_d, z_vals, pts, sdf, normals, colors, inv_s, eik_sum, bg = ctx.saved_tensors
+        bg = bg if ctx.has_bg else None
+        B, n, car, sample_dist = ctx.meta
+        P = B * n
+        dev = rays_o.device
+        zero = lambda *s: torch.zeros(*s, device=dev)
+        d_color = d_color.contiguous() if d_color is not None else zero(B, 3)
+        d_wsum = d_wsum.contiguous() if d_wsum is not None else None
+        d_weights = d_weights.contiguous() if d_weights is not None else None
+        d_gradients = d_gradients.contiguous() if d_gradients is not None else None
+        d_ge = d_ge if d_ge is not None else zero(())
+        eik_coef = (d_ge / (eik_sum[1] + 1e-5)).reshape(1).contiguous()
+        d_sdf = torch.empty(P, device=dev)
+        d_normals = torch.empty(P, 3, device=dev)
+        d_colors = torch.empty(P, 3, device=dev)
+        d_inv_s = torch.empty(B, device=dev)
+        _lib.check(L.dh_render_scan_bwd(_p(rays_o), _p(rays_d), _p(z_vals), _p(sdf), _p(normals), _p(colors), _p(inv_s),
+                                        car, sample_dist, _p(bg), B, n, _p(d_color), _p(d_wsum), _p(d_weights),
+                                        _p(d_gradients), _p(eik_coef), _p(d_sdf), _p(d_normals), _p(d_colors),
+                                        _p(d_inv_s), _lib.stream()))
+        if d_sdf_out is not None:
+            d_sdf = d_sdf + d_sdf_out.reshape(-1)
+        grad = torch.empty(st.n, device=dev)
+        _lib.check(L.dh_mlp_backward(_p(st.packed), _p(st.flat), _p(pts), P, _p(ctx.ws), _p(colors), _p(d_sdf),
+                                     _p(d_normals), _p(d_colors), _p(grad), _lib.stream()))
+        # variance: inv_s = clip(exp(10 v), 1e-6, 1e6)
+        raw = torch.exp(st.flat[st.var_off] * 10.0)
+        passthrough = ((raw >= 1e-6) & (raw <= 1e6)).float()
+        grad[st.var_off] = d_inv_s.sum() * 10.0 * raw * passthrough
+        st.grad_flat = grad
+        return tuple(grad[off:off + cnt].view(p.shape) for p, off, cnt in st.slices)

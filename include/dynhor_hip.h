@@ -58,6 +58,15 @@ int dh_workspace_floats(int64_t npts, int64_t* fwd_floats, int64_t* total_floats
 int dh_mlp_forward(const float* packed, const float* pts, const float* dirs, int n_per_ray, int64_t npts, float* ws,
                    float* sdf, float* normals, float* color, void* stream);
 
+/* Adjoint of dh_mlp_forward (autograd of upstream render_core's network calls, incl. the second-order path through
+ * sdf_network.gradient's create_graph=True): given d_sdf [npts], d_normals [npts,3] (updated in place with the colour
+ * network's contribution) and d_colors [npts,3] (wrt the post-sigmoid colour), writes the gradient of every network
+ * parameter (weight-norm folded: bias, weight_g, weight_v) into grad_flat [dh_num_params()] (the variance entry is
+ * left untouched).  ws must be the workspace dh_mlp_forward filled; packed/params the weights it used. */
+int dh_mlp_backward(const float* packed, const float* params, const float* pts, int64_t npts, float* ws,
+                    const float* colors, const float* d_sdf, float* d_normals, const float* d_colors, float* grad_flat,
+                    void* stream);
+
 /* ---- per-ray stages ---------------------------------------------------------------------------------------
  * Mask-conditioned ray generation = upstream Dataset.gen_random_rays_at + near_far_from_sphere (App. A.8) under the
  * reference's hand-off conventions: K per ObjTracker/run.py:119-123 (Kinv = its inverse, row-major [9]); pose
