@@ -23,13 +23,15 @@ SIGNATURES = {
     "dh_workspace_floats": (_i32, [_i64, ctypes.POINTER(_i64), ctypes.POINTER(_i64)]),
     "dh_mlp_forward": (_i32, [_vp, _vp, _vp, _i32, _i64, _vp, _vp, _vp, _vp, _vp]),
     "dh_mlp_backward": (_i32, [_vp, _vp, _vp, _i64] + [_vp] * 7),
+    "dh_adam_step": (_i32, [_vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _i64, _f32, _vp]),
     "dh_gen_rays": (_i32, [_vp] * 6 + [_i32, _i32, _i32, _i32, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),
     "dh_coarse_samples": (_i32, [_vp] * 5 + [_i64, _i32, _vp, _vp, _vp]),
     "dh_upsample_step": (_i32, [_vp] * 4 + [_i64, _i32, _i32, _f32, _vp, _vp, _vp]),
     "dh_merge_samples": (_i32, [_vp] * 4 + [_i64, _i32, _i32, _vp, _vp, _vp]),
     "dh_midpoints": (_i32, [_vp] * 3 + [_i64, _i32, _f32, _vp, _vp]),
-    "dh_render_scan_fwd": (_i32, [_vp] * 7 + [_f32, _f32, _vp, _i64, _i32] + [_vp] * 8),
-    "dh_render_scan_bwd": (_i32, [_vp] * 7 + [_f32, _f32, _vp, _i64, _i32] + [_vp] * 10),
+    "dh_render_scan_fwd": (_i32, [_vp] * 7 + [_f32, _f32, _vp, _i64, _i32] + [_vp] * 9),
+    "dh_render_scan_bwd": (_i32, [_vp] * 7 + [_f32, _f32, _vp, _i64, _i32] + [_vp] * 11),
+    "dh_neus_loss": (_i32, [_vp] * 6 + [_i64, _f32, _f32, _f32] + [_vp] * 6),
 }
 
 

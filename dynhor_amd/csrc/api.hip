@@ -128,29 +128,30 @@ int dh_midpoints(const float* rays_o, const float* rays_d, const float* z, int64
 int dh_render_scan_fwd(const float* rays_o, const float* rays_d, const float* z, const float* sdf, const float* normals,
                        const float* colors, const float* inv_s, float cos_anneal_ratio, float sample_dist,
                        const float* background_rgb, int64_t B, int n, float* weights, float* color, float* weight_sum,
-                       float* weight_max, float* cdf, float* inside_sphere, float* eik_partial, void* stream) {
+                       float* weight_max, float* cdf, float* inside_sphere, float* eik_partial, float* normal_map,
+                       void* stream) {
     if (B < 0 || n <= 0) return DH_ERR_BAD_ARG;
     if (n > 128) return DH_ERR_UNSUPPORTED;
     if (B == 0) return DH_OK;
     if (!rays_o || !rays_d || !z || !sdf || !normals || !colors || !inv_s || !weights || !color || !weight_sum ||
         !weight_max || !cdf || !inside_sphere || !eik_partial) return DH_ERR_BAD_ARG;
     return launch_render_fwd(rays_o, rays_d, z, sdf, normals, colors, inv_s, cos_anneal_ratio, sample_dist, background_rgb,
-                             B, n, weights, color, weight_sum, weight_max, cdf, inside_sphere, eik_partial,
+                             B, n, weights, color, weight_sum, weight_max, cdf, inside_sphere, eik_partial, normal_map,
                              static_cast<hipStream_t>(stream));
 }
 
 int dh_render_scan_bwd(const float* rays_o, const float* rays_d, const float* z, const float* sdf, const float* normals,
                        const float* colors, const float* inv_s, float cos_anneal_ratio, float sample_dist,
                        const float* background_rgb, int64_t B, int n, const float* d_color, const float* d_weight_sum,
-                       const float* d_weights, const float* d_gradients, const float* eik_coef, float* d_sdf,
-                       float* d_normals, float* d_colors, float* d_inv_s, void* stream) {
+                       const float* d_weights, const float* d_gradients, const float* d_normal_map, const float* eik_coef,
+                       float* d_sdf, float* d_normals, float* d_colors, float* d_inv_s, void* stream) {
     if (B < 0 || n <= 0) return DH_ERR_BAD_ARG;
     if (n > 128) return DH_ERR_UNSUPPORTED;
     if (B == 0) return DH_OK;
     if (!rays_o || !rays_d || !z || !sdf || !normals || !colors || !inv_s || !d_color || !eik_coef || !d_sdf ||
         !d_normals || !d_colors || !d_inv_s) return DH_ERR_BAD_ARG;
     return launch_render_bwd(rays_o, rays_d, z, sdf, normals, colors, inv_s, cos_anneal_ratio, sample_dist, background_rgb,
-                             B, n, d_color, d_weight_sum, d_weights, d_gradients, eik_coef, d_sdf, d_normals, d_colors,
+                             B, n, d_color, d_weight_sum, d_weights, d_gradients, d_normal_map, eik_coef, d_sdf, d_normals, d_colors,
                              d_inv_s, static_cast<hipStream_t>(stream));
 }
 
@@ -169,6 +170,26 @@ int dh_mlp_backward(const float* packed, const float* params, const float* pts, 
     rc = launch_sdf_bwd(packed, d_sdf, npts, w.act, w.rsave, w.featbar, w.zbar, w.tpart, DEFAULT_GRID, st);
     if (rc) return rc;
     return launch_weight_grads(w, w.slabs, w.tred, DW_G, DW_NS, params, packed, grad_flat, st);
+}
+
+int dh_adam_step(float* params, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
+                 float beta2, float eps, int64_t step, float grad_scale, void* stream) {
+    if (n < 0 || step < 1) return DH_ERR_BAD_ARG;
+    if (n == 0) return DH_OK;
+    if (!params || !grad || !exp_avg || !exp_avg_sq) return DH_ERR_BAD_ARG;
+    return launch_adam(params, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, step, grad_scale,
+                       static_cast<hipStream_t>(stream));
+}
+
+int dh_neus_loss(const float* color, const float* weight_sum, const float* normal_map, const float* eik_partial,
+                 const float* rays, const float* R, int64_t B, float igr_weight, float mask_weight, float normal_weight,
+                 float* stats, float* d_color, float* d_weight_sum, float* d_normal_map, float* eik_coef, void* stream) {
+    if (B <= 0) return DH_ERR_BAD_ARG;
+    if (!color || !weight_sum || !eik_partial || !rays || !stats || !d_color || !d_weight_sum || !eik_coef)
+        return DH_ERR_BAD_ARG;
+    if (normal_weight > 0.f && (!normal_map || !R || !d_normal_map)) return DH_ERR_BAD_ARG;
+    return launch_loss(color, weight_sum, normal_map, eik_partial, rays, R, B, igr_weight, mask_weight, normal_weight, stats,
+                       d_color, d_weight_sum, d_normal_map, eik_coef, static_cast<hipStream_t>(stream));
 }
 
 }  // extern "C"

@@ -34,12 +34,15 @@ int launch_midpoints(const float* o, const float* d, const float* z, int64_t B, 
 int launch_render_fwd(const float* o, const float* d, const float* z, const float* sdf, const float* normals,
                       const float* colors, const float* inv_s, float car, float sample_dist, const float* bg, int64_t B,
                       int n, float* weights, float* color, float* wsum, float* wmax, float* cdf, float* inside, float* eik,
-                      hipStream_t st);
+                      float* nmap, hipStream_t st);
 int launch_render_bwd(const float* o, const float* d, const float* z, const float* sdf, const float* normals,
                       const float* colors, const float* inv_s, float car, float sample_dist, const float* bg, int64_t B,
                       int n, const float* d_color, const float* d_wsum, const float* d_weights, const float* d_gradients,
-                      const float* eik_coef, float* d_sdf, float* d_normals, float* d_colors, float* d_inv_s,
-                      hipStream_t st);
+                      const float* d_nmap, const float* eik_coef, float* d_sdf, float* d_normals, float* d_colors,
+                      float* d_inv_s, hipStream_t st);
+int launch_loss(const float* color, const float* wsum, const float* nmap, const float* eik, const float* rays,
+                const float* R, int64_t B, float igr_w, float mask_w, float normal_w, float* stats, float* d_color,
+                float* d_wsum, float* d_nmap, float* eik_coef, hipStream_t st);
 
 // backward chains (kernels_mlp_bwd.hip) and weight gradients (dw.hip)
 int launch_color_bwd(const float* packed, const float* colors, const float* d_colors, int64_t npts, const float* cact,
@@ -51,5 +54,8 @@ int launch_sdf_bwd(const float* packed, const float* d_sdf, int64_t npts, const 
 struct Workspace;
 int launch_weight_grads(const Workspace& w, float* slabs, float* tred, int G, int nS, const float* params,
                         const float* packed, float* grad, hipStream_t st);
+
+int launch_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2, float eps,
+                int64_t step, float grad_scale, hipStream_t st);
 
 }  // namespace dh

@@ -291,7 +291,7 @@ __global__ __launch_bounds__(256) void render_fwd_kernel(const float* __restrict
                                                          float* __restrict__ weights, float* __restrict__ color_out,
                                                          float* __restrict__ wsum_out, float* __restrict__ wmax_out,
                                                          float* __restrict__ cdf_out, float* __restrict__ inside_out,
-                                                         float* __restrict__ eik_out) {
+                                                         float* __restrict__ eik_out, float* __restrict__ nmap_out) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int64_t ray = (int64_t)blockIdx.x * 4 + wave;
     if (ray >= B) return;
@@ -309,8 +309,9 @@ __global__ __launch_bounds__(256) void render_fwd_kernel(const float* __restrict
     const float w0 = A.alpha * excl, w1 = Bq.alpha * excl * tA;
     const float ws = wave_sum(w0 + w1);
     const float wm = wave_max(fmaxf(w0, w1));
-    float col[3];
+    float col[3], nm[3];
     DH_UNROLL for (int c = 0; c < 3; ++c) col[c] = wave_sum(w0 * A.c[c] + w1 * Bq.c[c]);
+    DH_UNROLL for (int c = 0; c < 3; ++c) nm[c] = wave_sum(w0 * A.n[c] + w1 * Bq.n[c]);
     const float g0 = (A.nn - 1.f) * (A.nn - 1.f) * A.relax, g1 = (Bq.nn - 1.f) * (Bq.nn - 1.f) * Bq.relax;
     const float en = wave_sum(g0 + g1), ed = wave_sum(A.relax + Bq.relax);
     if (e0 < n) { weights[ray * n + e0] = w0; cdf_out[ray * n + e0] = A.prev; inside_out[ray * n + e0] = in0; }
@@ -321,6 +322,7 @@ __global__ __launch_bounds__(256) void render_fwd_kernel(const float* __restrict
         wmax_out[ray] = wm;
         eik_out[ray * 2 + 0] = en;
         eik_out[ray * 2 + 1] = ed;
+        if (nmap_out) { DH_UNROLL for (int c = 0; c < 3; ++c) nmap_out[ray * 3 + c] = nm[c]; }
     }
 }
 
@@ -335,6 +337,7 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(const float* __restrict
                                                          const float* __restrict__ bg_rgb, int64_t B, int n,
                                                          const float* __restrict__ d_color, const float* __restrict__ d_wsum,
                                                          const float* __restrict__ d_weights, const float* __restrict__ d_gradients,
+                                                         const float* __restrict__ d_nmap,
                                                          const float* __restrict__ eik_coef, float* __restrict__ d_sdf,
                                                          float* __restrict__ d_normals, float* __restrict__ d_colors,
                                                          float* __restrict__ d_inv_s) {
@@ -345,6 +348,8 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(const float* __restrict
     const float ec = eik_coef[0];
     float o[3], d[3], dC[3];
     DH_UNROLL for (int c = 0; c < 3; ++c) { o[c] = rays_o[ray * 3 + c]; d[c] = rays_d[ray * 3 + c]; dC[c] = d_color[ray * 3 + c]; }
+    float dN[3] = {0.f, 0.f, 0.f};
+    if (d_nmap) { DH_UNROLL for (int c = 0; c < 3; ++c) dN[c] = d_nmap[ray * 3 + c]; }
     float dws = d_wsum ? d_wsum[ray] : 0.f;
     if (bg_rgb) dws -= dC[0] * bg_rgb[0] + dC[1] * bg_rgb[1] + dC[2] * bg_rgb[2];
     const int e0 = 2 * lane, e1 = e0 + 1;
@@ -358,8 +363,8 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(const float* __restrict
     const float excl = wave_excl_prod(tA * tB, lane);
     const float T0 = excl, T1 = excl * tA;
     const float w0 = A.alpha * T0, w1 = Bq.alpha * T1;
-    float wb0 = dws + dC[0] * A.c[0] + dC[1] * A.c[1] + dC[2] * A.c[2];
-    float wb1 = dws + dC[0] * Bq.c[0] + dC[1] * Bq.c[1] + dC[2] * Bq.c[2];
+    float wb0 = dws + dC[0] * A.c[0] + dC[1] * A.c[1] + dC[2] * A.c[2] + dN[0] * A.n[0] + dN[1] * A.n[1] + dN[2] * A.n[2];
+    float wb1 = dws + dC[0] * Bq.c[0] + dC[1] * Bq.c[1] + dC[2] * Bq.c[2] + dN[0] * Bq.n[0] + dN[1] * Bq.n[1] + dN[2] * Bq.n[2];
     if (d_weights) { if (v0) wb0 += d_weights[ray * n + e0]; if (v1) wb1 += d_weights[ray * n + e1]; }
     const float q0 = v0 ? wb0 * w0 : 0.f, q1 = v1 ? wb1 * w1 : 0.f;
     const float suf = wave_excl_suffix_sum(q0 + q1, lane);
@@ -378,7 +383,7 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(const float* __restrict
         const float tcb = icb * E.dtc;
         const float ek = (E.nn > 0.f) ? ec * E.relax * 2.f * (E.nn - 1.f) / E.nn : 0.f;
         DH_UNROLL for (int c = 0; c < 3; ++c) {
-            float g = tcb * d[c] + ek * E.n[c];
+            float g = tcb * d[c] + ek * E.n[c] + w * dN[c];
             if (d_gradients) g += d_gradients[gp * 3 + c];
             d_normals[gp * 3 + c] = g;
             d_colors[gp * 3 + c] = w * dC[c];
@@ -426,18 +431,18 @@ int launch_midpoints(const float* o, const float* d, const float* z, int64_t B, 
 int launch_render_fwd(const float* o, const float* d, const float* z, const float* sdf, const float* normals,
                       const float* colors, const float* inv_s, float car, float sample_dist, const float* bg, int64_t B,
                       int n, float* weights, float* color, float* wsum, float* wmax, float* cdf, float* inside, float* eik,
-                      hipStream_t st) {
+                      float* nmap, hipStream_t st) {
     hipLaunchKernelGGL(render_fwd_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, st, o, d, z, sdf, normals, colors, inv_s,
-                       car, sample_dist, bg, B, n, weights, color, wsum, wmax, cdf, inside, eik);
+                       car, sample_dist, bg, B, n, weights, color, wsum, wmax, cdf, inside, eik, nmap);
     return ok();
 }
 int launch_render_bwd(const float* o, const float* d, const float* z, const float* sdf, const float* normals,
                       const float* colors, const float* inv_s, float car, float sample_dist, const float* bg, int64_t B,
                       int n, const float* d_color, const float* d_wsum, const float* d_weights, const float* d_gradients,
-                      const float* eik_coef, float* d_sdf, float* d_normals, float* d_colors, float* d_inv_s,
-                      hipStream_t st) {
+                      const float* d_nmap, const float* eik_coef, float* d_sdf, float* d_normals, float* d_colors,
+                      float* d_inv_s, hipStream_t st) {
     hipLaunchKernelGGL(render_bwd_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, st, o, d, z, sdf, normals, colors, inv_s,
-                       car, sample_dist, bg, B, n, d_color, d_wsum, d_weights, d_gradients, eik_coef, d_sdf, d_normals,
+                       car, sample_dist, bg, B, n, d_color, d_wsum, d_weights, d_gradients, d_nmap, eik_coef, d_sdf, d_normals,
                        d_colors, d_inv_s);
     return ok();
 }

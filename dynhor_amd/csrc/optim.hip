@@ -1,0 +1,115 @@
+// Fused Adam over the flat parameter vector (torch.optim.Adam semantics) and the fused loss.
+#include "tile.h"
+#include "kernels.h"
+
+namespace dh {
+
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                   float* __restrict__ v, int64_t n, float lr, float b1, float b2, float eps,
+                                                   float bc1, float bc2_sqrt, float grad_scale) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float gi = g[i] * grad_scale;
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    p[i] -= (lr / bc1) * (mi / denom);
+}
+
+// ---------------------------------------------------------------- a11: losses + their adjoints, one workgroup
+__device__ __forceinline__ float block_sum(float v, float* s_red) {
+    DH_UNROLL for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float t = 0.f;
+    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t += s_red[i];     // fixed order -> deterministic
+    return t;
+}
+
+__global__ __launch_bounds__(1024) void loss_kernel(const float* __restrict__ color, const float* __restrict__ wsum,
+                                                    const float* __restrict__ nmap, const float* __restrict__ eik,
+                                                    const float* __restrict__ rays, const float* __restrict__ R, int64_t B,
+                                                    float igr_w, float mask_w, float normal_w, float* __restrict__ stats,
+                                                    float* __restrict__ d_color, float* __restrict__ d_wsum,
+                                                    float* __restrict__ d_nmap, float* __restrict__ eik_coef) {
+    __shared__ float s_red[16];
+    const int tid = threadIdx.x;
+    float a_m = 0.f, a_k = 0.f, a_en = 0.f, a_ed = 0.f;
+    for (int64_t b = tid; b < B; b += blockDim.x) {
+        const float obj = rays[b * 14 + 9], keep = rays[b * 14 + 10];
+        a_m += obj * keep; a_k += keep; a_en += eik[b * 2]; a_ed += eik[b * 2 + 1];
+    }
+    const float msum = block_sum(a_m, s_red) + 1e-5f;
+    const float ksum = block_sum(a_k, s_red) + 1e-5f;
+    const float en = block_sum(a_en, s_red), ed = block_sum(a_ed, s_red);
+    float Rm[9];
+    if (normal_w > 0.f) { DH_UNROLL for (int i = 0; i < 9; ++i) Rm[i] = R[i]; }
+    float a_c = 0.f, a_sq = 0.f, a_bce = 0.f, a_n = 0.f;
+    for (int64_t b = tid; b < B; b += blockDim.x) {
+        const float obj = rays[b * 14 + 9], keep = rays[b * 14 + 10];
+        const float m = obj * keep;
+        DH_UNROLL for (int c = 0; c < 3; ++c) {
+            const float e = color[b * 3 + c] - rays[b * 14 + 6 + c];
+            a_c += fabsf(e) * m;
+            a_sq += e * e * m;
+            d_color[b * 3 + c] = (e > 0.f ? 1.f : (e < 0.f ? -1.f : 0.f)) * m / msum;
+        }
+        const float ws = wsum[b];
+        const float wc = fminf(fmaxf(ws, 1e-3f), 1.f - 1e-3f);
+        a_bce += -(obj * logf(wc) + (1.f - obj) * logf(1.f - wc)) * keep;
+        const float pass = (ws >= 1e-3f && ws <= 1.f - 1e-3f) ? 1.f : 0.f;
+        d_wsum[b] = mask_w * keep / ksum * (-obj / wc + (1.f - obj) / (1.f - wc)) * pass;
+        if (normal_w > 0.f) {
+            float no[3], nc[3], mono[3], nh[3], dnh[3];
+            DH_UNROLL for (int c = 0; c < 3; ++c) { no[c] = nmap[b * 3 + c]; mono[c] = rays[b * 14 + 11 + c]; }
+            DH_UNROLL for (int i = 0; i < 3; ++i) nc[i] = Rm[i * 3] * no[0] + Rm[i * 3 + 1] * no[1] + Rm[i * 3 + 2] * no[2];
+            const float nn = sqrtf(nc[0] * nc[0] + nc[1] * nc[1] + nc[2] * nc[2]);
+            const float nrm = nn + 1e-6f;
+            float l1 = 0.f, cs = 0.f, dd = 0.f;
+            DH_UNROLL for (int i = 0; i < 3; ++i) {
+                nh[i] = nc[i] / nrm;
+                const float e = nh[i] - mono[i];
+                l1 += fabsf(e);
+                cs += nh[i] * mono[i];
+                dnh[i] = normal_w * m / msum * ((e > 0.f ? 1.f : (e < 0.f ? -1.f : 0.f)) - mono[i]);
+                dd += dnh[i] * nc[i];
+            }
+            a_n += (l1 + 1.f - cs) * m;
+            float dnc[3];
+            DH_UNROLL for (int i = 0; i < 3; ++i) dnc[i] = dnh[i] / nrm - (nn > 0.f ? nc[i] * dd / (nn * nrm * nrm) : 0.f);
+            DH_UNROLL for (int j = 0; j < 3; ++j) d_nmap[b * 3 + j] = Rm[j] * dnc[0] + Rm[3 + j] * dnc[1] + Rm[6 + j] * dnc[2];
+        }
+    }
+    const float csum = block_sum(a_c, s_red), sq = block_sum(a_sq, s_red), bce = block_sum(a_bce, s_red);
+    const float nsum = block_sum(a_n, s_red);
+    if (tid == 0) {
+        const float closs = csum / msum, ge = en / (ed + 1e-5f), mloss = bce / ksum, nloss = nsum / msum;
+        stats[0] = closs + igr_w * ge + mask_w * mloss + (normal_w > 0.f ? normal_w * nloss : 0.f);
+        stats[1] = closs; stats[2] = ge; stats[3] = mloss; stats[4] = nloss;
+        stats[5] = 20.f * log10f(1.f / sqrtf(sq / (msum * 3.f)));
+        stats[6] = msum; stats[7] = ksum;
+        eik_coef[0] = igr_w / (ed + 1e-5f);
+    }
+}
+
+int launch_loss(const float* color, const float* wsum, const float* nmap, const float* eik, const float* rays,
+                const float* R, int64_t B, float igr_w, float mask_w, float normal_w, float* stats, float* d_color,
+                float* d_wsum, float* d_nmap, float* eik_coef, hipStream_t st) {
+    hipLaunchKernelGGL(loss_kernel, dim3(1), dim3(1024), 0, st, color, wsum, nmap, eik, rays, R, B, igr_w, mask_w, normal_w,
+                       stats, d_color, d_wsum, d_nmap, eik_coef);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+int launch_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2, float eps,
+                int64_t step, float grad_scale, hipStream_t st) {
+    const double bc1 = 1.0 - pow((double)b1, (double)step);
+    const double bc2 = 1.0 - pow((double)b2, (double)step);
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p, g, m, v, n, lr, b1, b2, eps,
+                       (float)bc1, (float)sqrt(bc2), grad_scale);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+}  // namespace dh

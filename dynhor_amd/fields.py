@@ -152,3 +152,43 @@ class ParamStore:
     def inv_s(self) -> torch.Tensor:
         """clip(exp(10 variance), 1e-6, 1e6) as a 1-element device tensor (App. A.7)."""
         return torch.exp(self.flat[self.var_off:self.var_off + 1] * 10.0).clip(1e-6, 1e6)
+
+    # ------------------------------------------------------------------ fused Adam (App. A.8)
+    def adam_step(self, lr: float, betas=(0.9, 0.999), eps=1e-8, grad: torch.Tensor | None = None, grad_scale=1.0):
+        """One torch.optim.Adam-equivalent step on the flat vector using the flat gradient of the last backward."""
+        g = grad if grad is not None else self.grad_flat
+        if g is None:
+            raise RuntimeError("adam_step: no gradient (call backward() first)")
+        self.step_count += 1
+        _lib.check(_lib.lib().dh_adam_step(_lib.ptr(self.flat), _lib.ptr(g), _lib.ptr(self.exp_avg),
+                                           _lib.ptr(self.exp_avg_sq), self.n, float(lr), float(betas[0]), float(betas[1]),
+                                           float(eps), self.step_count, float(grad_scale), _lib.stream()))
+        self.bump()
+
+    def zero_grad(self):
+        for p, _, _ in self.slices:
+            p.grad = None
+        self.grad_flat = None
+
+    # torch.optim.Adam-compatible optimizer state (checkpoint key 'optimizer', App. A.8)
+    def optimizer_state_dict(self, lr: float, betas=(0.9, 0.999), eps=1e-8):
+        state = {}
+        for i, (p, off, cnt) in enumerate(self.slices):
+            state[i] = {"step": torch.tensor(float(self.step_count)),
+                        "exp_avg": self.exp_avg[off:off + cnt].view(p.shape).clone(),
+                        "exp_avg_sq": self.exp_avg_sq[off:off + cnt].view(p.shape).clone()}
+        group = {"lr": lr, "betas": tuple(betas), "eps": eps, "weight_decay": 0, "amsgrad": False,
+                 "maximize": False, "foreach": None, "capturable": False, "differentiable": False, "fused": None,
+                 "params": list(range(len(self.slices)))}
+        return {"state": state if self.step_count > 0 else {}, "param_groups": [group]}
+
+    def load_optimizer_state_dict(self, sd):
+        st = sd.get("state", {})
+        if not st:
+            self.exp_avg.zero_(); self.exp_avg_sq.zero_(); self.step_count = 0
+            return
+        for i, (p, off, cnt) in enumerate(self.slices):
+            s = st[i] if i in st else st[str(i)]
+            self.exp_avg[off:off + cnt].copy_(s["exp_avg"].reshape(-1))
+            self.exp_avg_sq[off:off + cnt].copy_(s["exp_avg_sq"].reshape(-1))
+            self.step_count = int(float(s["step"]))

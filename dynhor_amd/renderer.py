@@ -5,13 +5,17 @@ whose every stage runs as hand-written HIP on gfx950 through the C ABI (include/
                             n_samples=64, n_importance=64, n_outside=0, up_sample_steps=4, perturb=1.0)
     out = renderer.render(rays_o, rays_d, near, far, cos_anneal_ratio=r)     # dict, same keys as upstream
 
-The returned tensors take part in autograd: ``loss.backward()`` runs the HIP backward (render scan adjoint ->
-colour MLP -> SDF MLP incl. the second-order path through d sdf/d x -> weight-norm fold) and deposits gradients on
-the modules' parameters as views of one flat buffer (ParamStore.grad_flat).
+Two ways to train through it:
+  * autograd (drop-in): the tensors returned by render() take part in autograd; ``loss.backward()`` runs the HIP
+    backward (render-scan adjoint -> colour MLP -> SDF MLP incl. the second-order path through d sdf/d x ->
+    weight-norm fold) and deposits gradients on the modules' parameters as views of ParamStore.grad_flat.
+  * fused (Runner hot loop): ``train_step_core`` = sample -> render -> HIP loss kernel -> HIP backward with no
+    autograd graph and no host synchronisation; the flat gradient is then all-reduced (RCCL) and fed to the fused Adam.
 """
 from __future__ import annotations
 
 import ctypes
+from types import SimpleNamespace
 
 import torch
 
@@ -30,52 +34,24 @@ class _RenderCoreFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, renderer, rays_o, rays_d, z_vals, cos_anneal_ratio, background_rgb, *params):
-        L = _lib.lib()
-        st = renderer.store
-        packed = st.ensure_packed()
-        dev = rays_o.device
-        B, n = z_vals.shape
-        P = B * n
-        sample_dist = 2.0 / renderer.n_samples
-        ws = renderer._workspace(P)
-        pts = torch.empty(P, 3, device=dev)
-        sdf = torch.empty(P, device=dev)
-        normals = torch.empty(P, 3, device=dev)
-        colors = torch.empty(P, 3, device=dev)
-        _lib.check(L.dh_midpoints(_p(rays_o), _p(rays_d), _p(z_vals), B, n, sample_dist, _p(pts), _lib.stream()))
-        _lib.check(L.dh_mlp_forward(_p(packed), _p(pts), _p(rays_d), n, P, _p(ws), _p(sdf), _p(normals), _p(colors),
-                                    _lib.stream()))
-        inv_s = st.inv_s()
-        weights = torch.empty(B, n, device=dev)
-        color = torch.empty(B, 3, device=dev)
-        wsum = torch.empty(B, 1, device=dev)
-        wmax = torch.empty(B, 1, device=dev)
-        cdf = torch.empty(B, n, device=dev)
-        inside = torch.empty(B, n, device=dev)
-        eik = torch.empty(B, 2, device=dev)
-        _lib.check(L.dh_render_scan_fwd(_p(rays_o), _p(rays_d), _p(z_vals), _p(sdf), _p(normals), _p(colors), _p(inv_s),
-                                        float(cos_anneal_ratio), sample_dist, _p(background_rgb), B, n, _p(weights),
-                                        _p(color), _p(wsum), _p(wmax), _p(cdf), _p(inside), _p(eik), _lib.stream()))
-        eik_sum = eik.sum(dim=0)
-        gradient_error = eik_sum[0] / (eik_sum[1] + 1e-5)
-        gradients = normals.view(B, n, 3)
+        s = renderer._forward_core(rays_o, rays_d, z_vals, cos_anneal_ratio, background_rgb, want_nmap=False)
         ctx.set_materialize_grads(False)
-        renderer._ws_token += 1
-        ctx.ws_token = renderer._ws_token
+        ctx.state = s
         ctx.renderer = renderer
-        ctx.meta = (B, n, float(cos_anneal_ratio), sample_dist)
-        ctx.save_for_backward(rays_o, rays_d, z_vals, pts, sdf, normals, colors, inv_s, eik_sum, background_rgb
-                              if background_rgb is not None else torch.empty(0, device=dev))
-        ctx.has_bg = background_rgb is not None
-        ctx.ws = ws
-        ctx.mark_non_differentiable(wmax, cdf, inside)
-        return color, wsum, gradient_error, weights, gradients, wmax, cdf, inside, sdf.view(P, 1)
+        ctx.mark_non_differentiable(s.wmax, s.cdf, s.inside)
+        B, n = z_vals.shape
+        return (s.color, s.wsum, s.gradient_error, s.weights, s.normals.view(B, n, 3), s.wmax, s.cdf, s.inside,
+                s.sdf.view(B * n, 1))
 
     @staticmethod
     def backward(ctx, d_color, d_wsum, d_ge, d_weights, d_gradients, _wmax, _cdf, _inside, d_sdf_out):
-        renderer = ctx.renderer
-        return (None, None, None, None, None, None) + renderer._backward(ctx, d_color, d_wsum, d_ge, d_weights,
-                                                                         d_gradients, d_sdf_out)
+        r = ctx.renderer
+        s = ctx.state
+        dev = s.color.device
+        eik_coef = ((d_ge if d_ge is not None else torch.zeros((), device=dev)) / (s.eik_sum[1] + 1e-5)).reshape(1)
+        grad = r._backward_core(s, d_color, d_wsum, d_weights, d_gradients, None, eik_coef.contiguous(), d_sdf_out)
+        return (None, None, None, None, None, None) + tuple(grad[off:off + cnt].view(p.shape)
+                                                           for p, off, cnt in r.store.slices)
 
 
 class NeuSRenderer:
@@ -164,6 +140,78 @@ class NeuSRenderer:
                 n_cur += n_new
         return z
 
+    # ------------------------------------------------------------------ render_core forward / backward (no autograd)
+    @torch.no_grad()
+    def _forward_core(self, rays_o, rays_d, z_vals, cos_anneal_ratio, background_rgb, want_nmap):
+        L = _lib.lib()
+        st = self.store
+        packed = st.ensure_packed()
+        dev = rays_o.device
+        B, n = z_vals.shape
+        P = B * n
+        s = SimpleNamespace()
+        s.B, s.n, s.car, s.sample_dist = B, n, float(cos_anneal_ratio), 2.0 / self.n_samples
+        s.rays_o, s.rays_d, s.z_vals, s.bg = rays_o, rays_d, z_vals, background_rgb
+        s.ws = self._workspace(P)
+        self._ws_token += 1
+        s.ws_token = self._ws_token
+        s.pts = torch.empty(P, 3, device=dev)
+        s.sdf = torch.empty(P, device=dev)
+        s.normals = torch.empty(P, 3, device=dev)
+        s.colors = torch.empty(P, 3, device=dev)
+        _lib.check(L.dh_midpoints(_p(rays_o), _p(rays_d), _p(z_vals), B, n, s.sample_dist, _p(s.pts), _lib.stream()))
+        _lib.check(L.dh_mlp_forward(_p(packed), _p(s.pts), _p(rays_d), n, P, _p(s.ws), _p(s.sdf), _p(s.normals),
+                                    _p(s.colors), _lib.stream()))
+        s.inv_s = st.inv_s()
+        s.weights = torch.empty(B, n, device=dev)
+        s.color = torch.empty(B, 3, device=dev)
+        s.wsum = torch.empty(B, 1, device=dev)
+        s.wmax = torch.empty(B, 1, device=dev)
+        s.cdf = torch.empty(B, n, device=dev)
+        s.inside = torch.empty(B, n, device=dev)
+        s.eik = torch.empty(B, 2, device=dev)
+        s.nmap = torch.empty(B, 3, device=dev) if want_nmap else None
+        _lib.check(L.dh_render_scan_fwd(_p(rays_o), _p(rays_d), _p(z_vals), _p(s.sdf), _p(s.normals), _p(s.colors),
+                                        _p(s.inv_s), s.car, s.sample_dist, _p(background_rgb), B, n, _p(s.weights),
+                                        _p(s.color), _p(s.wsum), _p(s.wmax), _p(s.cdf), _p(s.inside), _p(s.eik),
+                                        _p(s.nmap), _lib.stream()))
+        s.eik_sum = s.eik.sum(dim=0)
+        s.gradient_error = s.eik_sum[0] / (s.eik_sum[1] + 1e-5)
+        return s
+
+    @torch.no_grad()
+    def _backward_core(self, s, d_color, d_wsum, d_weights, d_gradients, d_nmap, eik_coef, d_sdf_out=None):
+        """Adjoint of _forward_core: returns the flat parameter gradient (also kept as store.grad_flat)."""
+        L = _lib.lib()
+        st = self.store
+        if s.ws_token != self._ws_token:
+            raise RuntimeError("NeuSRenderer workspace was overwritten by a later render() call before backward(); "
+                               "call backward() before rendering again (one live graph per renderer)")
+        B, n = s.B, s.n
+        P = B * n
+        dev = s.color.device
+        c = lambda t: None if t is None else t.contiguous()
+        d_color = c(d_color) if d_color is not None else torch.zeros(B, 3, device=dev)
+        d_sdf = torch.empty(P, device=dev)
+        d_normals = torch.empty(P, 3, device=dev)
+        d_colors = torch.empty(P, 3, device=dev)
+        d_inv_s = torch.empty(B, device=dev)
+        _lib.check(L.dh_render_scan_bwd(_p(s.rays_o), _p(s.rays_d), _p(s.z_vals), _p(s.sdf), _p(s.normals), _p(s.colors),
+                                        _p(s.inv_s), s.car, s.sample_dist, _p(s.bg), B, n, _p(d_color), _p(c(d_wsum)),
+                                        _p(c(d_weights)), _p(c(d_gradients)), _p(c(d_nmap)), _p(eik_coef), _p(d_sdf),
+                                        _p(d_normals), _p(d_colors), _p(d_inv_s), _lib.stream()))
+        if d_sdf_out is not None:
+            d_sdf = (d_sdf + d_sdf_out.reshape(-1)).contiguous()
+        grad = torch.empty(st.n, device=dev)
+        _lib.check(L.dh_mlp_backward(_p(st.packed), _p(st.flat), _p(s.pts), P, _p(s.ws), _p(s.colors), _p(d_sdf),
+                                     _p(d_normals), _p(d_colors), _p(grad), _lib.stream()))
+        # variance: inv_s = clip(exp(10 v), 1e-6, 1e6)
+        raw = torch.exp(st.flat[st.var_off] * 10.0)
+        passthrough = ((raw >= 1e-6) & (raw <= 1e6)).float()
+        grad[st.var_off] = d_inv_s.sum() * 10.0 * raw * passthrough
+        st.grad_flat = grad
+        return grad
+
     # ------------------------------------------------------------------ render (App. A.5)
     def render(self, rays_o, rays_d, near, far, perturb_overwrite=-1, background_rgb=None, cos_anneal_ratio=0.0,
                t_rand=None, z_vals=None):
@@ -177,7 +225,6 @@ class NeuSRenderer:
         if z_vals is None:
             z_vals = self.sample_z(rays_o, rays_d, near, far, perturb_overwrite, t_rand)
         z_vals = z_vals.contiguous()
-        n = z_vals.shape[1]
         bg = None if background_rgb is None else background_rgb.reshape(-1).contiguous().float()
         outs = _RenderCoreFn.apply(self, rays_o, rays_d, z_vals, cos_anneal_ratio, bg, *self.store.params())
         color, wsum, gradient_error, weights, gradients, wmax, cdf, inside, sdf = outs
@@ -189,41 +236,30 @@ class NeuSRenderer:
             "z_vals": z_vals, "sdf": sdf,
         }
 
-    # ------------------------------------------------------------------ backward (filled in by renderer_bwd)
-    def _backward(self, ctx, d_color, d_wsum, d_ge, d_weights, d_gradients, d_sdf_out):
+    # ------------------------------------------------------------------ fused training step (Runner hot loop)
+    @torch.no_grad()
+    def train_step_core(self, rays, near, far, R, cos_anneal_ratio, igr_weight=0.1, mask_weight=0.1, normal_weight=0.0,
+                        background_rgb=None, t_rand=None):
+        """rays [B,14] (dh_gen_rays layout), R [3,3] object->camera of the frame.  Returns stats [8] on device:
+        loss, colour, eikonal, mask, normal, psnr, sum(obj*keep), sum(keep); leaves the flat gradient in
+        store.grad_flat.  No host synchronisation."""
         L = _lib.lib()
-        st = self.store
-        if ctx.ws_token != self._ws_token:
-            raise RuntimeError("NeuSRenderer workspace was overwritten by a later render() call before backward(); "
-                               "call backward() before rendering again (one live graph per renderer)")
-        rays_o, rays_d, z_vals, pts, sdf, normals, colors, inv_s, eik_sum, bg = ctx.saved_tensors
-        bg = bg if ctx.has_bg else None
-        B, n, car, sample_dist = ctx.meta
-        P = B * n
-        dev = rays_o.device
-        zero = lambda *s: torch.zeros(*s, device=dev)
-        d_color = d_color.contiguous() if d_color is not None else zero(B, 3)
-        d_wsum = d_wsum.contiguous() if d_wsum is not None else None
-        d_weights = d_weights.contiguous() if d_weights is not None else None
-        d_gradients = d_gradients.contiguous() if d_gradients is not None else None
-        d_ge = d_ge if d_ge is not None else zero(())
-        eik_coef = (d_ge / (eik_sum[1] + 1e-5)).reshape(1).contiguous()
-        d_sdf = torch.empty(P, device=dev)
-        d_normals = torch.empty(P, 3, device=dev)
-        d_colors = torch.empty(P, 3, device=dev)
-        d_inv_s = torch.empty(B, device=dev)
-        _lib.check(L.dh_render_scan_bwd(_p(rays_o), _p(rays_d), _p(z_vals), _p(sdf), _p(normals), _p(colors), _p(inv_s),
-                                        car, sample_dist, _p(bg), B, n, _p(d_color), _p(d_wsum), _p(d_weights),
-                                        _p(d_gradients), _p(eik_coef), _p(d_sdf), _p(d_normals), _p(d_colors),
-                                        _p(d_inv_s), _lib.stream()))
-        if d_sdf_out is not None:
-            d_sdf = d_sdf + d_sdf_out.reshape(-1)
-        grad = torch.empty(st.n, device=dev)
-        _lib.check(L.dh_mlp_backward(_p(st.packed), _p(st.flat), _p(pts), P, _p(ctx.ws), _p(colors), _p(d_sdf),
-                                     _p(d_normals), _p(d_colors), _p(grad), _lib.stream()))
-        # variance: inv_s = clip(exp(10 v), 1e-6, 1e6)
-        raw = torch.exp(st.flat[st.var_off] * 10.0)
-        passthrough = ((raw >= 1e-6) & (raw <= 1e6)).float()
-        grad[st.var_off] = d_inv_s.sum() * 10.0 * raw * passthrough
-        st.grad_flat = grad
-        return tuple(grad[off:off + cnt].view(p.shape) for p, off, cnt in st.slices)
+        dev = rays.device
+        B = rays.shape[0]
+        rays_o = rays[:, 0:3].contiguous()
+        rays_d = rays[:, 3:6].contiguous()
+        z_vals = self.sample_z(rays_o, rays_d, near, far, t_rand=t_rand)
+        bg = None if background_rgb is None else background_rgb.reshape(-1).contiguous().float()
+        s = self._forward_core(rays_o, rays_d, z_vals, cos_anneal_ratio, bg, want_nmap=normal_weight > 0.0)
+        stats = torch.empty(8, device=dev)
+        d_color = torch.empty(B, 3, device=dev)
+        d_wsum = torch.empty(B, device=dev)
+        d_nmap = torch.empty(B, 3, device=dev) if normal_weight > 0.0 else None
+        eik_coef = torch.empty(1, device=dev)
+        Rc = R.contiguous().float() if R is not None else None
+        _lib.check(L.dh_neus_loss(_p(s.color), _p(s.wsum), _p(s.nmap), _p(s.eik), _p(rays), _p(Rc), B, float(igr_weight),
+                                  float(mask_weight), float(normal_weight), _p(stats), _p(d_color), _p(d_wsum),
+                                  _p(d_nmap), _p(eik_coef), _lib.stream()))
+        self._backward_core(s, d_color, d_wsum, None, None, d_nmap, eik_coef)
+        self.last_state = s
+        return stats

@@ -99,19 +99,40 @@ int dh_midpoints(const float* rays_o, const float* rays_d, const float* z, int64
 
 /* render_core tail (App. A.7): alpha from (sdf, normals, inv_s[0], cos_anneal), transmittance scan, compositing.
  * weights/cdf/inside_sphere [B,n]; color [B,3]; weight_sum/weight_max [B]; eik_partial [B,2] = per-ray
- * (sum relax*(|n|-1)^2, sum relax).  n <= 128.  background_rgb [3] or NULL. */
+ * (sum relax*(|n|-1)^2, sum relax); normal_map [B,3] = sum_j w_j n_j (object frame) or NULL.  n <= 128.
+ * background_rgb [3] or NULL. */
 int dh_render_scan_fwd(const float* rays_o, const float* rays_d, const float* z, const float* sdf, const float* normals,
                        const float* colors, const float* inv_s, float cos_anneal_ratio, float sample_dist,
                        const float* background_rgb, int64_t B, int n, float* weights, float* color, float* weight_sum,
-                       float* weight_max, float* cdf, float* inside_sphere, float* eik_partial, void* stream);
+                       float* weight_max, float* cdf, float* inside_sphere, float* eik_partial, float* normal_map,
+                       void* stream);
 
-/* adjoint of dh_render_scan_fwd.  d_weight_sum, d_weights [B,n], d_gradients [B*n,3] may be NULL; eik_coef[0] =
+/* adjoint of dh_render_scan_fwd.  d_weight_sum, d_weights [B,n], d_gradients [B*n,3], d_normal_map [B,3] may be NULL; eik_coef[0] =
  * d(loss)/d(gradient_error) / (sum relax + 1e-5).  d_inv_s [B] holds per-ray partial sums. */
 int dh_render_scan_bwd(const float* rays_o, const float* rays_d, const float* z, const float* sdf, const float* normals,
                        const float* colors, const float* inv_s, float cos_anneal_ratio, float sample_dist,
                        const float* background_rgb, int64_t B, int n, const float* d_color, const float* d_weight_sum,
-                       const float* d_weights, const float* d_gradients, const float* eik_coef, float* d_sdf,
-                       float* d_normals, float* d_colors, float* d_inv_s, void* stream);
+                       const float* d_weights, const float* d_gradients, const float* d_normal_map, const float* eik_coef,
+                       float* d_sdf, float* d_normals, float* d_colors, float* d_inv_s, void* stream);
+
+/* Loss stack of the training step (upstream Runner.train, App. A.8, with Dynhor's hand gating): rays [B,14] as
+ * written by dh_gen_rays; m = obj*keep (the keep-mask gating precedent: reference ObjTracker/utils/losses.py:69-71,
+ * pose_initializtion.py:60-65,148-150).
+ *   colour L1 over m / (sum m + 1e-5); eikonal = sum eik_partial[:,0] / (sum eik_partial[:,1] + 1e-5);
+ *   mask BCE(clip(weight_sum,1e-3,1-1e-3), obj) over keep / (sum keep + 1e-5);
+ *   normal (if normal_weight > 0): L1 + (1 - cos) between normalize(R normal_map) and the monocular normal over m.
+ * stats[8] = loss, colour, eikonal, mask, normal, psnr, sum m, sum keep.  Also writes the adjoints d_color [B,3],
+ * d_weight_sum [B], d_normal_map [B,3] and eik_coef[0] = igr_weight / (sum relax + 1e-5) for dh_render_scan_bwd. */
+int dh_neus_loss(const float* color, const float* weight_sum, const float* normal_map, const float* eik_partial,
+                 const float* rays, const float* R, int64_t B, float igr_weight, float mask_weight, float normal_weight,
+                 float* stats, float* d_color, float* d_weight_sum, float* d_normal_map, float* eik_coef, void* stream);
+
+/* ---- optimiser -----------------------------------------------------------------------------------------
+ * torch.optim.Adam step (upstream Runner uses Adam, App. A.8; the reference's own optimisers are Adam too:
+ * ObjTracker/pose_initializtion.py:346, jointopt.py:135-141) fused over the flat vector; step counts from 1;
+ * grad_scale multiplies the gradient first (1/world_size after a sum all-reduce). */
+int dh_adam_step(float* params, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
+                 float beta2, float eps, int64_t step, float grad_scale, void* stream);
 
 #ifdef __cplusplus
 }
