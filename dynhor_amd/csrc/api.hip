@@ -66,19 +66,81 @@ int dh_workspace_floats(int64_t npts, int64_t* fwd_floats, int64_t* total_floats
     return DH_OK;
 }
 
-int dh_mlp_forward(const float* packed, const float* pts, const float* dirs, int n_per_ray, int64_t npts, float* ws,
-                   float* sdf, float* normals, float* color, void* stream) {
+int dh_sdf_forward(const float* packed, const float* pts, int64_t npts, float* ws, float* sdf, void* stream) {
+    if (npts <= 0) return npts == 0 ? DH_OK : DH_ERR_BAD_ARG;
+    if (!packed || !pts || !ws || !sdf || misaligned16(packed) || misaligned16(ws)) return DH_ERR_BAD_ARG;
+    const Workspace w = carve_workspace(ws, npts);
+    return launch_sdf_fwd_train(packed, pts, npts, sdf, w.feat, w.act, w.eaux, DEFAULT_GRID, static_cast<hipStream_t>(stream));
+}
+
+int dh_sdf_gradient(const float* packed, const float* pts, int64_t npts, float* ws, float* normals, void* stream) {
+    if (npts <= 0) return npts == 0 ? DH_OK : DH_ERR_BAD_ARG;
+    if (!packed || !pts || !ws || !normals || misaligned16(packed) || misaligned16(ws)) return DH_ERR_BAD_ARG;
+    const Workspace w = carve_workspace(ws, npts);
+    return launch_sdf_grad(packed, pts, npts, w.act, w.asave, normals, DEFAULT_GRID, static_cast<hipStream_t>(stream));
+}
+
+int dh_color_forward(const float* packed, const float* pts, const float* dirs, int n_per_ray, const float* normals,
+                     int64_t npts, float* ws, float* color, void* stream) {
     if (npts < 0 || n_per_ray <= 0) return DH_ERR_BAD_ARG;
     if (npts == 0) return DH_OK;
-    if (!packed || !pts || !dirs || !ws || !sdf || !normals || !color || misaligned16(packed) || misaligned16(ws))
-        return DH_ERR_BAD_ARG;
-    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (!packed || !pts || !dirs || !normals || !ws || !color || misaligned16(packed) || misaligned16(ws)) return DH_ERR_BAD_ARG;
     const Workspace w = carve_workspace(ws, npts);
-    int rc = launch_sdf_fwd_train(packed, pts, npts, sdf, w.feat, w.act, w.eaux, DEFAULT_GRID, st);
+    return launch_color_fwd(packed, pts, dirs, n_per_ray, normals, w.feat, npts, color, w.cact, w.caux, 1, DEFAULT_GRID,
+                            static_cast<hipStream_t>(stream));
+}
+
+int dh_mlp_forward(const float* packed, const float* pts, const float* dirs, int n_per_ray, int64_t npts, float* ws,
+                   float* sdf, float* normals, float* color, void* stream) {
+    int rc = dh_sdf_forward(packed, pts, npts, ws, sdf, stream);
     if (rc) return rc;
-    rc = launch_sdf_grad(packed, pts, npts, w.act, w.asave, normals, DEFAULT_GRID, st);
+    rc = dh_sdf_gradient(packed, pts, npts, ws, normals, stream);
     if (rc) return rc;
-    return launch_color_fwd(packed, pts, dirs, n_per_ray, normals, w.feat, npts, color, w.cact, w.caux, 1, DEFAULT_GRID, st);
+    return dh_color_forward(packed, pts, dirs, n_per_ray, normals, npts, ws, color, stream);
+}
+
+int dh_color_backward(const float* packed, const float* colors, const float* d_colors, int64_t npts, float* ws,
+                      float* d_normals, void* stream) {
+    if (npts <= 0) return DH_ERR_BAD_ARG;
+    if (!packed || !colors || !d_colors || !ws || !d_normals || misaligned16(packed) || misaligned16(ws)) return DH_ERR_BAD_ARG;
+    const Workspace w = carve_workspace(ws, npts);
+    return launch_color_bwd(packed, colors, d_colors, npts, w.cact, w.czbar, w.featbar, d_normals, w.tpart, DEFAULT_GRID,
+                            static_cast<hipStream_t>(stream));
+}
+
+int dh_sdf_tangent(const float* packed, const float* pts, const float* d_normals, int64_t npts, float* ws, void* stream) {
+    if (npts <= 0) return DH_ERR_BAD_ARG;
+    if (!packed || !pts || !d_normals || !ws || misaligned16(packed) || misaligned16(ws)) return DH_ERR_BAD_ARG;
+    const Workspace w = carve_workspace(ws, npts);
+    return launch_sdf_tangent(packed, pts, d_normals, npts, w.act, w.asave, w.t0aux, w.tsave, w.rsave, w.tpart, DEFAULT_GRID,
+                              static_cast<hipStream_t>(stream));
+}
+
+int dh_sdf_backward(const float* packed, const float* d_sdf, int64_t npts, float* ws, void* stream) {
+    if (npts <= 0) return DH_ERR_BAD_ARG;
+    if (!packed || !d_sdf || !ws || misaligned16(packed) || misaligned16(ws)) return DH_ERR_BAD_ARG;
+    const Workspace w = carve_workspace(ws, npts);
+    return launch_sdf_bwd(packed, d_sdf, npts, w.act, w.rsave, w.featbar, w.zbar, w.tpart, DEFAULT_GRID,
+                          static_cast<hipStream_t>(stream));
+}
+
+int dh_weight_grads(const float* packed, const float* params, int64_t npts, float* ws, float* grad_flat, void* stream) {
+    if (npts <= 0) return DH_ERR_BAD_ARG;
+    if (!packed || !params || !ws || !grad_flat || misaligned16(packed) || misaligned16(ws)) return DH_ERR_BAD_ARG;
+    const Workspace w = carve_workspace(ws, npts);
+    return launch_weight_grads(w, w.slabs, w.tred, DW_G, DW_NS, params, packed, grad_flat, static_cast<hipStream_t>(stream));
+}
+
+int dh_mlp_backward(const float* packed, const float* params, const float* pts, int64_t npts, float* ws,
+                    const float* colors, const float* d_sdf, float* d_normals, const float* d_colors, float* grad_flat,
+                    void* stream) {
+    int rc = dh_color_backward(packed, colors, d_colors, npts, ws, d_normals, stream);
+    if (rc) return rc;
+    rc = dh_sdf_tangent(packed, pts, d_normals, npts, ws, stream);
+    if (rc) return rc;
+    rc = dh_sdf_backward(packed, d_sdf, npts, ws, stream);
+    if (rc) return rc;
+    return dh_weight_grads(packed, params, npts, ws, grad_flat, stream);
 }
 
 int dh_gen_rays(const uint8_t* rgb, const int8_t* label, const uint8_t* normal, const float* R, const float* T,
@@ -153,23 +215,6 @@ int dh_render_scan_bwd(const float* rays_o, const float* rays_d, const float* z,
     return launch_render_bwd(rays_o, rays_d, z, sdf, normals, colors, inv_s, cos_anneal_ratio, sample_dist, background_rgb,
                              B, n, d_color, d_weight_sum, d_weights, d_gradients, d_normal_map, eik_coef, d_sdf, d_normals, d_colors,
                              d_inv_s, static_cast<hipStream_t>(stream));
-}
-
-int dh_mlp_backward(const float* packed, const float* params, const float* pts, int64_t npts, float* ws,
-                    const float* colors, const float* d_sdf, float* d_normals, const float* d_colors, float* grad_flat,
-                    void* stream) {
-    if (npts <= 0) return DH_ERR_BAD_ARG;
-    if (!packed || !params || !pts || !ws || !colors || !d_sdf || !d_normals || !d_colors || !grad_flat ||
-        misaligned16(packed) || misaligned16(ws)) return DH_ERR_BAD_ARG;
-    hipStream_t st = static_cast<hipStream_t>(stream);
-    const Workspace w = carve_workspace(ws, npts);
-    int rc = launch_color_bwd(packed, colors, d_colors, npts, w.cact, w.czbar, w.featbar, d_normals, w.tpart, DEFAULT_GRID, st);
-    if (rc) return rc;
-    rc = launch_sdf_tangent(packed, pts, d_normals, npts, w.act, w.asave, w.t0aux, w.tsave, w.rsave, w.tpart, DEFAULT_GRID, st);
-    if (rc) return rc;
-    rc = launch_sdf_bwd(packed, d_sdf, npts, w.act, w.rsave, w.featbar, w.zbar, w.tpart, DEFAULT_GRID, st);
-    if (rc) return rc;
-    return launch_weight_grads(w, w.slabs, w.tred, DW_G, DW_NS, params, packed, grad_flat, st);
 }
 
 int dh_adam_step(float* params, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,

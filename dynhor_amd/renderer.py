@@ -29,6 +29,32 @@ def _p(t):
     return _NULL if t is None else _lib.ptr(t)
 
 
+class StageTimer:
+    """Calls a C-ABI stage; when enabled, brackets it with HIP events on the launch stream (torch's current stream) so
+    bench.py can report per-kernel durations measured inside the timed region."""
+
+    def __init__(self):
+        self.enabled = False
+        self.records = {}
+
+    def __call__(self, name, fn, *args):
+        if self.enabled:
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            _lib.check(fn(*args))
+            b.record()
+            self.records.setdefault(name, []).append((a, b))
+        else:
+            _lib.check(fn(*args))
+
+    def summary(self):
+        """name -> (mean ms, count); call after a device synchronise."""
+        return {k: (sum(a.elapsed_time(b) for a, b in v) / len(v), len(v)) for k, v in self.records.items()}
+
+    def reset(self):
+        self.records = {}
+
+
 class _RenderCoreFn(torch.autograd.Function):
     """render_core (App. A.7) on fixed z_vals.  Inputs: every parameter (flat order) so autograd routes grads."""
 
@@ -77,6 +103,7 @@ class NeuSRenderer:
         self.store = store if store is not None else ParamStore(sdf_network, deviation_network, color_network, device)
         self._ws = None
         self._ws_token = 0
+        self.timer = StageTimer()
 
     # ------------------------------------------------------------------ workspace (caller-owned, reused)
     def _workspace(self, npts: int) -> torch.Tensor:
@@ -116,7 +143,7 @@ class NeuSRenderer:
                                        B, ns, _p(z), _p(pts), _lib.stream()))
         if self.n_importance > 0:
             sdf = torch.empty(B * ns, device=dev)
-            _lib.check(L.dh_sdf_nograd(_p(packed), _p(pts), B * ns, _p(sdf), _lib.stream()))
+            self.timer("sdf_nograd_coarse", L.dh_sdf_nograd, _p(packed), _p(pts), B * ns, _p(sdf), _lib.stream())
             n_new = self.n_importance // self.up_sample_steps
             n_cur = ns
             for i in range(self.up_sample_steps):
@@ -128,7 +155,8 @@ class NeuSRenderer:
                 z_out = torch.empty(B, n_cur + n_new, device=dev)
                 if not last:
                     sdf_new = torch.empty(B * n_new, device=dev)
-                    _lib.check(L.dh_sdf_nograd(_p(packed), _p(pts_new), B * n_new, _p(sdf_new), _lib.stream()))
+                    self.timer("sdf_nograd_fine", L.dh_sdf_nograd, _p(packed), _p(pts_new), B * n_new, _p(sdf_new),
+                               _lib.stream())
                     sdf_out = torch.empty(B * (n_cur + n_new), device=dev)
                     _lib.check(L.dh_merge_samples(_p(z), _p(z_new), _p(sdf), _p(sdf_new), B, n_cur, n_new, _p(z_out),
                                                   _p(sdf_out), _lib.stream()))
@@ -160,8 +188,11 @@ class NeuSRenderer:
         s.normals = torch.empty(P, 3, device=dev)
         s.colors = torch.empty(P, 3, device=dev)
         _lib.check(L.dh_midpoints(_p(rays_o), _p(rays_d), _p(z_vals), B, n, s.sample_dist, _p(s.pts), _lib.stream()))
-        _lib.check(L.dh_mlp_forward(_p(packed), _p(s.pts), _p(rays_d), n, P, _p(s.ws), _p(s.sdf), _p(s.normals),
-                                    _p(s.colors), _lib.stream()))
+        T = self.timer
+        T("sdf_forward", L.dh_sdf_forward, _p(packed), _p(s.pts), P, _p(s.ws), _p(s.sdf), _lib.stream())
+        T("sdf_gradient", L.dh_sdf_gradient, _p(packed), _p(s.pts), P, _p(s.ws), _p(s.normals), _lib.stream())
+        T("color_forward", L.dh_color_forward, _p(packed), _p(s.pts), _p(rays_d), n, _p(s.normals), P, _p(s.ws),
+          _p(s.colors), _lib.stream())
         s.inv_s = st.inv_s()
         s.weights = torch.empty(B, n, device=dev)
         s.color = torch.empty(B, 3, device=dev)
@@ -203,8 +234,12 @@ class NeuSRenderer:
         if d_sdf_out is not None:
             d_sdf = (d_sdf + d_sdf_out.reshape(-1)).contiguous()
         grad = torch.empty(st.n, device=dev)
-        _lib.check(L.dh_mlp_backward(_p(st.packed), _p(st.flat), _p(s.pts), P, _p(s.ws), _p(s.colors), _p(d_sdf),
-                                     _p(d_normals), _p(d_colors), _p(grad), _lib.stream()))
+        T = self.timer
+        T("color_backward", L.dh_color_backward, _p(st.packed), _p(s.colors), _p(d_colors), P, _p(s.ws), _p(d_normals),
+          _lib.stream())
+        T("sdf_tangent", L.dh_sdf_tangent, _p(st.packed), _p(s.pts), _p(d_normals), P, _p(s.ws), _lib.stream())
+        T("sdf_backward", L.dh_sdf_backward, _p(st.packed), _p(d_sdf), P, _p(s.ws), _lib.stream())
+        T("weight_grads", L.dh_weight_grads, _p(st.packed), _p(st.flat), P, _p(s.ws), _p(grad), _lib.stream())
         # variance: inv_s = clip(exp(10 v), 1e-6, 1e6)
         raw = torch.exp(st.flat[st.var_off] * 10.0)
         passthrough = ((raw >= 1e-6) & (raw <= 1e6)).float()

@@ -1,0 +1,243 @@
+"""Runner -- mirror of upstream ``exp_runner.py:Runner`` in the reference's config style
+(flat yaml.safe_load dict, ObjTracker/configs/custom_shoes.yaml:1-18; experiment directory exps/<seq>/<exp>/ with the
+config copied in, ObjTracker/run.py:125-128; one scalar per loss key per step as jointopt.py:151-153 logs them).
+
+Data-parallel: one process per GPU (torch.distributed, backend nccl == RCCL over xGMI).  Rank r takes frame
+perm[(iter*world + r) % n_images]; the only exchange is ONE all-reduce of the flat 802,491-float gradient per
+iteration, then every rank applies the same fused Adam step.
+"""
+from __future__ import annotations
+
+import json
+import math
+import os
+import shutil
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import yaml
+
+from .dataset import Dataset
+from .fields import ParamStore, RenderingNetwork, SDFNetwork, SingleVarianceNetwork
+from .renderer import NeuSRenderer
+
+DEFAULT_CONF = {
+    "seq_name": "synthetic", "exp_name": "neus",
+    "data_info": {"dataroot": None, "synthetic": {"n_frames": 64, "H": 512, "W": 512, "seed": 4321}},
+    "train": {"learning_rate": 5e-4, "learning_rate_alpha": 0.05, "end_iter": 300000, "batch_size": 2048,
+              "warm_up_end": 5000, "anneal_end": 50000, "igr_weight": 0.1, "mask_weight": 0.1, "normal_weight": 0.0,
+              "save_freq": 10000, "val_freq": 2500, "report_freq": 100, "use_white_bkgd": False, "keep_only": False,
+              "seed": 1234, "ray_seed": 4321},
+    "model": {"sdf_network": {}, "variance_network": {"init_val": 0.3}, "rendering_network": {},
+              "neus_renderer": {"n_samples": 64, "n_importance": 64, "n_outside": 0, "up_sample_steps": 4, "perturb": 1.0}},
+}
+
+
+def _merge(base, over):
+    out = dict(base)
+    for k, v in (over or {}).items():
+        out[k] = _merge(base[k], v) if isinstance(v, dict) and isinstance(base.get(k), dict) else v
+    return out
+
+
+class Runner:
+    def __init__(self, conf_path=None, mode="train", case=None, is_continue=False, conf: dict | None = None,
+                 dataset: Dataset | None = None, device=None, exp_root="exps"):
+        if conf is None:
+            with open(conf_path, "r") as f:
+                conf = yaml.safe_load(f)
+        self.conf = _merge(DEFAULT_CONF, conf)
+        if case is not None:
+            self.conf["seq_name"] = case
+        self.mode = mode
+        self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        self.rank = dist.get_rank() if self.world > 1 else 0
+        self.device = torch.device(device if device is not None else f"cuda:{int(os.environ.get('LOCAL_RANK', 0))}")
+        self.base_exp_dir = os.path.join(exp_root, self.conf["seq_name"], self.conf["exp_name"])
+        if self.rank == 0:
+            os.makedirs(self.base_exp_dir, exist_ok=True)
+            if conf_path is not None:
+                shutil.copy(conf_path, os.path.join(self.base_exp_dir, "config.yaml"))
+            else:
+                with open(os.path.join(self.base_exp_dir, "config.yaml"), "w") as f:
+                    yaml.safe_dump(self.conf, f)
+        tr = self.conf["train"]
+        self.end_iter = tr["end_iter"]; self.batch_size = tr["batch_size"]
+        self.learning_rate = tr["learning_rate"]; self.learning_rate_alpha = tr["learning_rate_alpha"]
+        self.warm_up_end = tr["warm_up_end"]; self.anneal_end = tr["anneal_end"]
+        self.igr_weight = tr["igr_weight"]; self.mask_weight = tr["mask_weight"]; self.normal_weight = tr["normal_weight"]
+        self.save_freq = tr["save_freq"]; self.val_freq = tr["val_freq"]; self.report_freq = tr["report_freq"]
+        self.use_white_bkgd = tr["use_white_bkgd"]; self.keep_only = tr["keep_only"]
+        self.iter_step = 0
+
+        if dataset is None:
+            di = self.conf["data_info"]
+            if di.get("dataroot"):
+                dataset = Dataset(di, device=self.device)
+            else:
+                dataset = Dataset.from_synthetic(device=self.device, **di["synthetic"])
+        self.dataset = dataset
+
+        with torch.random.fork_rng(devices=[]):
+            torch.manual_seed(tr["seed"])          # identical initial weights on every rank
+            self.sdf_network = SDFNetwork(**self.conf["model"]["sdf_network"])
+            self.color_network = RenderingNetwork(**self.conf["model"]["rendering_network"])
+            self.deviation_network = SingleVarianceNetwork(**self.conf["model"]["variance_network"])
+        self.nerf_outside = None
+        self.store = ParamStore(self.sdf_network, self.deviation_network, self.color_network, self.device)
+        self.renderer = NeuSRenderer(self.nerf_outside, self.sdf_network, self.deviation_network, self.color_network,
+                                     store=self.store, device=self.device, **self.conf["model"]["neus_renderer"])
+        self.ray_gen = torch.Generator(device=self.device)
+        self.ray_gen.manual_seed(tr["ray_seed"] * 1000003 + self.rank)
+        self.perm_gen = torch.Generator(device="cpu")
+        self.perm_gen.manual_seed(tr["ray_seed"])   # same permutation on every rank
+        self.image_perm = self.get_image_perm()
+        self.scalars = []
+        if is_continue:
+            ck = sorted(f for f in os.listdir(os.path.join(self.base_exp_dir, "checkpoints")) if f.endswith(".pth"))
+            if ck:
+                self.load_checkpoint(ck[-1])
+
+    # ------------------------------------------------------------------ schedules (App. A.8)
+    def get_image_perm(self):
+        return torch.randperm(self.dataset.n_images, generator=self.perm_gen)
+
+    def get_cos_anneal_ratio(self):
+        if self.anneal_end == 0.0:
+            return 1.0
+        return float(np.min([1.0, self.iter_step / self.anneal_end]))
+
+    def current_lr(self):
+        if self.iter_step < self.warm_up_end:
+            factor = self.iter_step / self.warm_up_end
+        else:
+            alpha = self.learning_rate_alpha
+            progress = (self.iter_step - self.warm_up_end) / (self.end_iter - self.warm_up_end)
+            factor = (math.cos(math.pi * progress) + 1.0) * 0.5 * (1 - alpha) + alpha
+        return self.learning_rate * factor
+
+    def update_learning_rate(self):
+        self.lr = self.current_lr()
+        return self.lr
+
+    # ------------------------------------------------------------------ one iteration (the hot loop)
+    def train_iteration(self):
+        n = self.dataset.n_images
+        slot = self.iter_step * self.world + self.rank
+        if self.world == 1 and slot % n == 0 and slot > 0:
+            self.image_perm = self.get_image_perm()
+        frame = int(self.image_perm[slot % n])
+        rays = self.dataset.gen_random_rays_at(frame, self.batch_size, keep_only=self.keep_only, generator=self.ray_gen)
+        near, far = self.dataset._last_near_far
+        bg = torch.ones(3, device=self.device) if self.use_white_bkgd else None
+        stats = self.renderer.train_step_core(rays, near, far, self.dataset.R[frame], self.get_cos_anneal_ratio(),
+                                              self.igr_weight, self.mask_weight, self.normal_weight, background_rgb=bg)
+        grad = self.store.grad_flat
+        if self.world > 1:
+            dist.all_reduce(grad, op=dist.ReduceOp.SUM)          # RCCL over xGMI: one 3.2 MB bucket
+        lr = self.current_lr() if self.iter_step > 0 else self.learning_rate / max(self.warm_up_end, 1)
+        self.store.adam_step(lr, grad=grad, grad_scale=1.0 / self.world)
+        self.iter_step += 1
+        return stats
+
+    def train(self, n_iters=None):
+        end = self.end_iter if n_iters is None else min(self.end_iter, self.iter_step + n_iters)
+        while self.iter_step < end:
+            stats = self.train_iteration()
+            if self.iter_step % self.report_freq == 0:
+                self.report(stats)
+            if self.rank == 0 and self.iter_step % self.save_freq == 0:
+                self.save_checkpoint()
+            if self.rank == 0 and self.val_freq and self.iter_step % self.val_freq == 0:
+                self.validate_image()
+        return self
+
+    def report(self, stats):
+        s = stats.clone()
+        if self.world > 1:
+            dist.all_reduce(s, op=dist.ReduceOp.SUM)
+            s /= self.world
+        v = s.tolist()
+        rec = {"iter": self.iter_step, "Loss/loss": v[0], "Loss/color_loss": v[1], "Loss/eikonal_loss": v[2],
+               "Loss/mask_loss": v[3], "Loss/normal_loss": v[4], "Statistics/psnr": v[5],
+               "Statistics/s_val": float(1.0 / self.store.inv_s().item()), "lr": self.current_lr()}
+        if self.rank == 0:
+            self.scalars.append(rec)
+            with open(os.path.join(self.base_exp_dir, "scalars.jsonl"), "a") as f:
+                f.write(json.dumps(rec) + "\n")
+        return rec
+
+    # ------------------------------------------------------------------ checkpoints (App. A.8 layout)
+    def save_checkpoint(self):
+        ck = {"nerf": {}, "sdf_network_fine": self.sdf_network.state_dict(),
+              "variance_network_fine": self.deviation_network.state_dict(),
+              "color_network_fine": self.color_network.state_dict(),
+              "optimizer": self.store.optimizer_state_dict(self.current_lr()), "iter_step": self.iter_step}
+        d = os.path.join(self.base_exp_dir, "checkpoints")
+        os.makedirs(d, exist_ok=True)
+        path = os.path.join(d, "ckpt_{:0>6d}.pth".format(self.iter_step))
+        torch.save({k: (v if not isinstance(v, dict) else _to_cpu(v)) for k, v in ck.items()}, path)
+        return path
+
+    def load_checkpoint(self, checkpoint_name):
+        path = checkpoint_name if os.path.isabs(checkpoint_name) or os.path.exists(checkpoint_name) else \
+            os.path.join(self.base_exp_dir, "checkpoints", checkpoint_name)
+        ck = torch.load(path, map_location=self.device, weights_only=False)
+        self.sdf_network.load_state_dict(ck["sdf_network_fine"])
+        self.deviation_network.load_state_dict(ck["variance_network_fine"])
+        self.color_network.load_state_dict(ck["color_network_fine"])
+        opt = ck.get("optimizer")
+        if opt:
+            st = opt.get("state", {})
+            extra = len(st) - len(self.store.slices)
+            if extra > 0:   # upstream checkpoints list the (unused here) NeRF++ background parameters first
+                opt = {"state": {i - extra: v for i, v in st.items() if i >= extra}, "param_groups": opt["param_groups"]}
+            self.store.load_optimizer_state_dict(opt)
+        self.iter_step = ck["iter_step"]
+        self.store.bump()
+
+    # ------------------------------------------------------------------ validation
+    @torch.no_grad()
+    def render_image(self, idx, resolution_level=4, chunk=4096):
+        rays, h, w = self.dataset.gen_rays_at(idx, resolution_level)
+        near, far = self.dataset._last_near_far
+        cols, nrms = [], []
+        bg = torch.ones(3, device=self.device) if self.use_white_bkgd else None
+        for s in range(0, rays.shape[0], chunk):
+            r = rays[s:s + chunk]
+            o, d = r[:, :3].contiguous(), r[:, 3:6].contiguous()
+            z = self.renderer.sample_z(o, d, near[s:s + chunk], far[s:s + chunk], perturb_overwrite=0)
+            st = self.renderer._forward_core(o, d, z, self.get_cos_anneal_ratio(), bg, want_nmap=True)
+            cols.append(st.color); nrms.append(st.nmap)
+        return torch.cat(cols).view(h, w, 3), torch.cat(nrms).view(h, w, 3), rays.view(h, w, 14)
+
+    @torch.no_grad()
+    def validate_image(self, idx=-1, resolution_level=4):
+        if idx < 0:
+            idx = int(np.random.randint(self.dataset.n_images))
+        img, nrm, rays = self.render_image(idx, resolution_level)
+        m = (rays[..., 9:10] * rays[..., 10:11])
+        mse = (((img - rays[..., 6:9]) ** 2) * m).sum() / (m.sum() * 3.0 + 1e-5)
+        psnr = float(20.0 * torch.log10(1.0 / mse.sqrt()))
+        d = os.path.join(self.base_exp_dir, "validations_fine")
+        os.makedirs(d, exist_ok=True)
+        np.save(os.path.join(d, "{:0>8d}_{}.npy".format(self.iter_step, idx)), (img.clamp(0, 1) * 255).byte().cpu().numpy())
+        return psnr
+
+    @torch.no_grad()
+    def validate_mesh(self, resolution=64, threshold=0.0):
+        """SDF on a regular grid over the unit cube (upstream extract_fields); returns the [-sdf] volume u and the
+        vertex count of the threshold crossing (host marching cubes is 'next')."""
+        N = resolution
+        xs = torch.linspace(-1.01, 1.01, N, device=self.device)
+        g = torch.stack(torch.meshgrid(xs, xs, xs, indexing="ij"), dim=-1).reshape(-1, 3)
+        u = -self.renderer.sdf(g).view(N, N, N)
+        crossings = ((u[1:] > threshold) != (u[:-1] > threshold)).sum() + \
+            ((u[:, 1:] > threshold) != (u[:, :-1] > threshold)).sum() + \
+            ((u[:, :, 1:] > threshold) != (u[:, :, :-1] > threshold)).sum()
+        return u, int(crossings)
+
+
+def _to_cpu(d):
+    return {k: (_to_cpu(v) if isinstance(v, dict) else (v.detach().cpu() if torch.is_tensor(v) else v)) for k, v in d.items()}

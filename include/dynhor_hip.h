@@ -58,6 +58,12 @@ int dh_workspace_floats(int64_t npts, int64_t* fwd_floats, int64_t* total_floats
 int dh_mlp_forward(const float* packed, const float* pts, const float* dirs, int n_per_ray, int64_t npts, float* ws,
                    float* sdf, float* normals, float* color, void* stream);
 
+/* The three stages of dh_mlp_forward as separate single-kernel launches (same ws): */
+int dh_sdf_forward(const float* packed, const float* pts, int64_t npts, float* ws, float* sdf, void* stream);
+int dh_sdf_gradient(const float* packed, const float* pts, int64_t npts, float* ws, float* normals, void* stream);
+int dh_color_forward(const float* packed, const float* pts, const float* dirs, int n_per_ray, const float* normals,
+                     int64_t npts, float* ws, float* color, void* stream);
+
 /* Adjoint of dh_mlp_forward (autograd of upstream render_core's network calls, incl. the second-order path through
  * sdf_network.gradient's create_graph=True): given d_sdf [npts], d_normals [npts,3] (updated in place with the colour
  * network's contribution) and d_colors [npts,3] (wrt the post-sigmoid colour), writes the gradient of every network
@@ -66,6 +72,15 @@ int dh_mlp_forward(const float* packed, const float* pts, const float* dirs, int
 int dh_mlp_backward(const float* packed, const float* params, const float* pts, int64_t npts, float* ws,
                     const float* colors, const float* d_sdf, float* d_normals, const float* d_colors, float* grad_flat,
                     void* stream);
+
+/* The four stages of dh_mlp_backward as separate launches (same ws, in this order): colour-network backward
+ * (adds its d/d normal into d_normals), the forward-mode tangent chain of the second-order path, the SDF backward
+ * chain, and the weight-gradient GEMMs + reduction + weight-norm fold into grad_flat. */
+int dh_color_backward(const float* packed, const float* colors, const float* d_colors, int64_t npts, float* ws,
+                      float* d_normals, void* stream);
+int dh_sdf_tangent(const float* packed, const float* pts, const float* d_normals, int64_t npts, float* ws, void* stream);
+int dh_sdf_backward(const float* packed, const float* d_sdf, int64_t npts, float* ws, void* stream);
+int dh_weight_grads(const float* packed, const float* params, int64_t npts, float* ws, float* grad_flat, void* stream);
 
 /* ---- per-ray stages ---------------------------------------------------------------------------------------
  * Mask-conditioned ray generation = upstream Dataset.gen_random_rays_at + near_far_from_sphere (App. A.8) under the
