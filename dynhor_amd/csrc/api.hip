@@ -8,7 +8,7 @@ using namespace dh;
 
 namespace {
 inline bool misaligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) != 0; }
-constexpr int DEFAULT_GRID = 256;   // one persistent workgroup per CU
+constexpr int DEFAULT_GRID = 256 * (TM == 128 ? 1 : 2);   // persistent workgroups: all that are co-resident
 }  // namespace
 
 extern "C" {

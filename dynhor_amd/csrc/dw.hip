@@ -24,7 +24,7 @@ template <int NB>
 __device__ __forceinline__ void dw_body(const DwJob& J, int64_t t0, int64_t t1, int g, int wave, int lane) {
     f32x16 acc[NB];
     DH_UNROLL for (int j = 0; j < NB; ++j) DH_UNROLL for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-    const int abase = (((wave >> 1) * 4) * 2 + (wave & 1)) * 4 * 64 + lane;
+    const int abase = (((wave >> 1) * MT) * 2 + (wave & 1)) * 4 * 64 + lane;
     for (int pair = 0; pair < 2; ++pair) {
         const float* A = pair ? J.A2 : J.A1;
         const float* Bm = pair ? J.B2 : J.B1;
@@ -32,12 +32,12 @@ __device__ __forceinline__ void dw_body(const DwJob& J, int64_t t0, int64_t t1, 
         for (int64_t tile = t0; tile < t1; ++tile) {
             const f32x4* ap = reinterpret_cast<const f32x4*>(A + tile * TILE_F) + abase;
             const f32x4* bp = reinterpret_cast<const f32x4*>(Bm + tile * (NB == 8 ? TILE_F : AUXT_F)) + lane;
-            _Pragma("unroll 2") for (int kq = 0; kq < 16; ++kq) {
+            _Pragma("unroll 2") for (int kq = 0; kq < MT * 4; ++kq) {
                 const int m = kq >> 2, r4 = kq & 3;
                 const f32x4 a = ap[(m * 8 + r4) * 64];
                 f32x4 b[NB];
                 DH_UNROLL for (int j = 0; j < NB; ++j) {
-                    const int bi = (NB == 8) ? ((j >> 1) * 32 + m * 8 + (j & 1) * 4 + r4) : ((m * 2 + j) * 4 + r4);
+                    const int bi = (NB == 8) ? ((j >> 1) * MT * 8 + m * 8 + (j & 1) * 4 + r4) : ((m * 2 + j) * 4 + r4);
                     b[j] = bp[bi * 64];
                 }
                 DH_UNROLL for (int rr = 0; rr < 4; ++rr)

@@ -10,7 +10,7 @@ namespace dh {
 // K1: SDF forward, no grad, sdf only (hierarchical up-sampling evaluations; SURVEY §8 a5 "no-grad").
 // lin8 reduces to its row 0: a 256-long dot per point, done on the VALU.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 1) void sdf_nograd_kernel(SdfPtrs P, const float* __restrict__ pts, int64_t npts,
+__global__ __launch_bounds__(256, TM == 128 ? 1 : 2) void sdf_nograd_kernel(SdfPtrs P, const float* __restrict__ pts, int64_t npts,
                                                              float* __restrict__ sdf_out) {
     __shared__ __attribute__((aligned(16))) float smain[TM * LDX];
     __shared__ __attribute__((aligned(16))) float saux[TM * LDA];
@@ -19,7 +19,7 @@ __global__ __launch_bounds__(256, 1) void sdf_nograd_kernel(SdfPtrs P, const flo
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         embed_tile(pts, tile * TM, npts, saux, tid);
         __syncthreads();
-        f32x16 acc[4][2];
+        f32x16 acc[MT][2];
         for (int l = 0; l < 8; ++l) {
             acc_zero(acc);
             if (l > 0) gemm_rows(acc, smain, LDX, l == 4 ? 28 : 32, P.fwd_main[l], wave, lane);
@@ -31,8 +31,8 @@ __global__ __launch_bounds__(256, 1) void sdf_nograd_kernel(SdfPtrs P, const flo
             __syncthreads();
         }
         const float s = row_dot256(smain, P.w8row0, tid) + P.b8_0[0];
-        const int64_t gp = tile * TM + (tid >> 1);
-        if ((tid & 1) == 0 && gp < npts) sdf_out[gp] = s;
+        const int64_t gp = tile * TM + tid / TPP;
+        if (tid % TPP == 0 && gp < npts) sdf_out[gp] = s;
         __syncthreads();                     // smain/saux are rewritten by the next tile
     }
 }
@@ -42,7 +42,7 @@ __global__ __launch_bounds__(256, 1) void sdf_nograd_kernel(SdfPtrs P, const flo
 // post-softplus, native tiles), writes feat = lin8 rows 1..256 (native) and sdf = lin8 row 0 (VALU dot).
 //   act : [8][ntiles][TILE_F]   (act[l-1] <-> input of layer l)
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 1) void sdf_fwd_train_kernel(SdfPtrs P, const float* __restrict__ pts, int64_t npts,
+__global__ __launch_bounds__(256, TM == 128 ? 1 : 2) void sdf_fwd_train_kernel(SdfPtrs P, const float* __restrict__ pts, int64_t npts,
                                                                 float* __restrict__ sdf_out, float* __restrict__ feat,
                                                                 float* __restrict__ act, float* __restrict__ eaux) {
     __shared__ __attribute__((aligned(16))) float smain[TM * LDX];
@@ -53,7 +53,7 @@ __global__ __launch_bounds__(256, 1) void sdf_fwd_train_kernel(SdfPtrs P, const 
         embed_tile(pts, tile * TM, npts, saux, tid);
         __syncthreads();
         aux_lds_to_native(saux, eaux + tile * AUXT_F, wave, lane);
-        f32x16 acc[4][2];
+        f32x16 acc[MT][2];
         for (int l = 0; l < 8; ++l) {
             acc_zero(acc);
             if (l > 0) gemm_rows(acc, smain, LDX, l == 4 ? 28 : 32, P.fwd_main[l], wave, lane);
@@ -66,8 +66,8 @@ __global__ __launch_bounds__(256, 1) void sdf_fwd_train_kernel(SdfPtrs P, const 
             __syncthreads();
         }
         const float s = row_dot256(smain, P.w8row0, tid) + P.b8_0[0];
-        const int64_t gp = tile * TM + (tid >> 1);
-        if ((tid & 1) == 0 && gp < npts) sdf_out[gp] = s;
+        const int64_t gp = tile * TM + tid / TPP;
+        if (tid % TPP == 0 && gp < npts) sdf_out[gp] = s;
         acc_zero(acc);
         gemm_rows(acc, smain, LDX, 32, P.fwd_main[8], wave, lane);
         const float b0 = P.bias[8][acc_col(wave, 0, lane)], b1 = P.bias[8][acc_col(wave, 1, lane)];
@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256, 1) void sdf_fwd_train_kernel(SdfPtrs P, const 
 //   ge = a_0 W_0 + a_4 W_4[:,217:]/sqrt2 ;  n = J_e(x)^T ge.   Saves a_l (l=0..7) for the backward pass.
 //   asave : [8][ntiles][TILE_F]
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 1) void sdf_grad_kernel(SdfPtrs P, const float* __restrict__ pts, int64_t npts,
+__global__ __launch_bounds__(256, TM == 128 ? 1 : 2) void sdf_grad_kernel(SdfPtrs P, const float* __restrict__ pts, int64_t npts,
                                                            const float* __restrict__ act, float* __restrict__ asave,
                                                            float* __restrict__ normals) {
     __shared__ __attribute__((aligned(16))) float smain[TM * LDX];
@@ -91,9 +91,9 @@ __global__ __launch_bounds__(256, 1) void sdf_grad_kernel(SdfPtrs P, const float
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int64_t ntiles = (npts + TM - 1) / TM;
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        f32x16 acc[4][2];
-        f32x16 ge[2];
-        DH_UNROLL for (int t = 0; t < 2; ++t) DH_UNROLL for (int r = 0; r < 16; ++r) ge[t][r] = 0.f;
+        f32x16 acc[MT][2];
+        f32x16 ge[AUX_NTW];
+        aux_zero(ge);
         // a_7 = W8[0,:] * sigma'(z_7)
         {
             const float w0 = P.w8row0[acc_col(wave, 0, lane)], w1 = P.w8row0[acc_col(wave, 1, lane)];
@@ -108,8 +108,8 @@ __global__ __launch_bounds__(256, 1) void sdf_grad_kernel(SdfPtrs P, const float
             gemm_rows(acc, smain, LDX, 32, P.rev_main[l], wave, lane);              // u_l = a_l W_l
             if (l == 4) gemm_auxout(ge, smain, 32, P.rev_aux[4], wave, lane);       // skip path -> ge
             // a_{l-1} = u_l * sigma'(z_{l-1})   (sigma' from act[l-1] == input of layer l)
-            const f32x4* hp = reinterpret_cast<const f32x4*>(act + ((int64_t)(l - 1) * ntiles + tile) * TILE_F) + (size_t)wave * 32 * 64 + lane;
-            DH_UNROLL for (int m = 0; m < 4; ++m) {
+            const f32x4* hp = reinterpret_cast<const f32x4*>(act + ((int64_t)(l - 1) * ntiles + tile) * TILE_F) + (size_t)wave * MT * 8 * 64 + lane;
+            DH_UNROLL for (int m = 0; m < MT; ++m) {
                 DH_UNROLL for (int t = 0; t < 2; ++t)
                     DH_UNROLL for (int r4 = 0; r4 < 4; ++r4) {
                         const f32x4 h = hp[((m * 2 + t) * 4 + r4) * 64];
@@ -127,11 +127,10 @@ __global__ __launch_bounds__(256, 1) void sdf_grad_kernel(SdfPtrs P, const float
         }
         gemm_auxout(ge, smain, 32, P.rev_aux[0], wave, lane);                       // ge += a_0 W_0
         // ge -> LDS aux image
-        DH_UNROLL for (int t = 0; t < 2; ++t) {
-            const int col = 32 * t + (lane & 31);
+        DH_UNROLL for (int tt = 0; tt < AUX_NTW; ++tt) {
+            const int col = aux_col(wave, tt, lane);
             if (col < AUXW) {
-                DH_UNROLL for (int r = 0; r < 16; ++r)
-                    saux[(32 * wave + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * LDA + col] = ge[t][r];
+                DH_UNROLL for (int r = 0; r < 16; ++r) saux[aux_row(wave, r, lane) * LDA + col] = ge[tt][r];
             }
         }
         __syncthreads();
@@ -163,7 +162,7 @@ __global__ __launch_bounds__(256, 1) void sdf_grad_kernel(SdfPtrs P, const float
 // activations cact[l] (l=1..4 -> slot l-1) and writes colour = sigmoid(lin4).
 //   dirs: [nrays,3], point gp belongs to ray gp / n_per_ray.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 1) void color_fwd_kernel(ColPtrs C, const float* __restrict__ pts, const float* __restrict__ dirs,
+__global__ __launch_bounds__(256, TM == 128 ? 1 : 2) void color_fwd_kernel(ColPtrs C, const float* __restrict__ pts, const float* __restrict__ dirs,
                                                             int n_per_ray, const float* __restrict__ normals,
                                                             const float* __restrict__ feat, int64_t npts,
                                                             float* __restrict__ color, float* __restrict__ cact,
@@ -194,7 +193,7 @@ __global__ __launch_bounds__(256, 1) void color_fwd_kernel(ColPtrs C, const floa
             }
             DH_UNROLL for (int c = CAUX; c < LDA; ++c) row[c] = 0.f;
         }
-        f32x16 acc[4][2];
+        f32x16 acc[MT][2];
         acc_load_native(acc, feat + tile * TILE_F, wave, lane);
         acc_to_lds(acc, smain, wave, lane);
         __syncthreads();
@@ -210,10 +209,10 @@ __global__ __launch_bounds__(256, 1) void color_fwd_kernel(ColPtrs C, const floa
             acc_to_lds(acc, smain, wave, lane);
             __syncthreads();
         }
-        const int64_t gp = tile * TM + (tid >> 1);
+        const int64_t gp = tile * TM + tid / TPP;
         DH_UNROLL for (int j = 0; j < 3; ++j) {
             const float raw = row_dot256(smain, C.w4 + j * 256, tid) + C.b4[j];
-            if ((tid & 1) == 0 && gp < npts) color[gp * 3 + j] = 1.f / (1.f + __expf(-raw));
+            if (tid % TPP == 0 && gp < npts) color[gp * 3 + j] = 1.f / (1.f + __expf(-raw));
         }
         __syncthreads();
     }

@@ -21,7 +21,7 @@ enum : int { TP_SDF_B0 = 0, TP_SDF_B8 = 8, TP_W8ROW0_T = 9, TP_W8ROW0_S = 10, TP
 // ------------------------------------------------------------------------------------------------
 // K6: RenderingNetwork backward.  d_colors is wrt the post-sigmoid colour.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 1) void color_bwd_kernel(ColPtrs C, const float* __restrict__ colors,
+__global__ __launch_bounds__(256, TM == 128 ? 1 : 2) void color_bwd_kernel(ColPtrs C, const float* __restrict__ colors,
                                                             const float* __restrict__ d_colors, int64_t npts,
                                                             const float* __restrict__ cact, float* __restrict__ czbar,
                                                             float* __restrict__ featbar, float* __restrict__ d_normals,
@@ -50,12 +50,12 @@ __global__ __launch_bounds__(256, 1) void color_bwd_kernel(ColPtrs C, const floa
             for (int r = 0; r < TM; ++r) s += saux[r * 4 + tid];
             tp[TP_COL_B4 * 256 + tid] = s;
         }
-        f32x16 acc[4][2];
+        f32x16 acc[MT][2];
         // lin4: dW4 partials, zbar_3 = (craw W4) * [h4 > 0]
         acc_load_native(acc, cact + ((int64_t)3 * ntiles + tile) * TILE_F, wave, lane);
         {
             float dw[3][2] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
-            DH_UNROLL for (int m = 0; m < 4; ++m)
+            DH_UNROLL for (int m = 0; m < MT; ++m)
                 DH_UNROLL for (int r = 0; r < 16; ++r) {
                     const f32x4 cr = *reinterpret_cast<const f32x4*>(saux + acc_row(m, r, lane) * 4);
                     DH_UNROLL for (int t = 0; t < 2; ++t) {
@@ -79,8 +79,8 @@ __global__ __launch_bounds__(256, 1) void color_bwd_kernel(ColPtrs C, const floa
         for (int l = 3; l >= 1; --l) {
             acc_zero(acc);
             gemm_rows(acc, smain, LDX, 32, C.rev_main[l], wave, lane);                    // hbar_l = zbar_l W_l
-            const f32x4* hp = reinterpret_cast<const f32x4*>(cact + ((int64_t)(l - 1) * ntiles + tile) * TILE_F) + (size_t)wave * 32 * 64 + lane;
-            DH_UNROLL for (int m = 0; m < 4; ++m) {
+            const f32x4* hp = reinterpret_cast<const f32x4*>(cact + ((int64_t)(l - 1) * ntiles + tile) * TILE_F) + (size_t)wave * MT * 8 * 64 + lane;
+            DH_UNROLL for (int m = 0; m < MT; ++m) {
                 DH_UNROLL for (int t = 0; t < 2; ++t)
                     DH_UNROLL for (int r4 = 0; r4 < 4; ++r4) {
                         const f32x4 h = hp[((m * 2 + t) * 4 + r4) * 64];
@@ -99,15 +99,15 @@ __global__ __launch_bounds__(256, 1) void color_bwd_kernel(ColPtrs C, const floa
         acc_zero(acc);
         gemm_rows(acc, smain, LDX, 32, C.rev_main[0], wave, lane);
         acc_store_native(acc, featbar + tile * TILE_F, wave, lane);
-        f32x16 a2[2];
-        DH_UNROLL for (int t = 0; t < 2; ++t) DH_UNROLL for (int r = 0; r < 16; ++r) a2[t][r] = 0.f;
+        f32x16 a2[AUX_NTW];
+        aux_zero(a2);
         gemm_auxout(a2, smain, 32, C.rev_aux0, wave, lane);
-        DH_UNROLL for (int t = 0; t < 2; ++t) {
-            const int col = 32 * t + (lane & 31);
+        DH_UNROLL for (int tt = 0; tt < AUX_NTW; ++tt) {
+            const int col = aux_col(wave, tt, lane);
             if (col >= 30 && col < 33) {
                 DH_UNROLL for (int r = 0; r < 16; ++r) {
-                    const int64_t gp = tile * TM + 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                    if (gp < npts) d_normals[gp * 3 + (col - 30)] += a2[t][r];
+                    const int64_t gp = tile * TM + aux_row(wave, r, lane);
+                    if (gp < npts) d_normals[gp * 3 + (col - 30)] += a2[tt][r];
                 }
             }
         }
@@ -118,7 +118,7 @@ __global__ __launch_bounds__(256, 1) void color_bwd_kernel(ColPtrs C, const floa
 // ------------------------------------------------------------------------------------------------
 // K7a: tangent chain (forward direction) -> t_l, r_l ; colsum(t_8) feeds Wbar_8[0,:]
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 1) void sdf_tangent_kernel(SdfPtrs P, const float* __restrict__ pts,
+__global__ __launch_bounds__(256, TM == 128 ? 1 : 2) void sdf_tangent_kernel(SdfPtrs P, const float* __restrict__ pts,
                                                               const float* __restrict__ d_normals, int64_t npts,
                                                               const float* __restrict__ act, const float* __restrict__ asave,
                                                               float* __restrict__ t0aux, float* __restrict__ tsave,
@@ -130,17 +130,16 @@ __global__ __launch_bounds__(256, 1) void sdf_tangent_kernel(SdfPtrs P, const fl
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         float* tp = tpart + tile * N_TILE_PART * 256;
         {   // tt_0 = J_e(x) nbar
-            const int p = tid & 127, half = tid >> 7;
+            const int p = tid & (TM - 1), part = tid / TM;
             const int64_t gp = tile * TM + p;
             float x[3] = {0.f, 0.f, 0.f}, nb[3] = {0.f, 0.f, 0.f};
             if (gp < npts) {
                 DH_UNROLL for (int c = 0; c < 3; ++c) { x[c] = pts[gp * 3 + c]; nb[c] = d_normals[gp * 3 + c]; }
             }
             float* row = saux + p * LDA;
-            if (half == 0) { row[0] = nb[0]; row[1] = nb[1]; row[2] = nb[2]; }
-            else           { row[39] = 0.f; row[40] = 0.f; row[41] = 0.f; row[42] = 0.f; row[43] = 0.f; }
-            DH_UNROLL for (int kk = 0; kk < 3; ++kk) {
-                const int k = half * 3 + kk;
+            if (part == 0) { row[0] = nb[0]; row[1] = nb[1]; row[2] = nb[2]; }
+            if (part == 1) { row[39] = 0.f; row[40] = 0.f; row[41] = 0.f; row[42] = 0.f; row[43] = 0.f; }
+            for (int k = part; k < 6; k += TPP) {
                 const float f = (float)(1 << k);
                 DH_UNROLL for (int c = 0; c < 3; ++c) {
                     float s, co;
@@ -152,16 +151,16 @@ __global__ __launch_bounds__(256, 1) void sdf_tangent_kernel(SdfPtrs P, const fl
         }
         __syncthreads();
         aux_lds_to_native(saux, t0aux + tile * AUXT_F, wave, lane);
-        f32x16 acc[4][2];
+        f32x16 acc[MT][2];
         for (int l = 0; l < 8; ++l) {
             acc_zero(acc);
             if (l > 0) gemm_rows(acc, smain, LDX, l == 4 ? 28 : 32, P.fwd_main[l], wave, lane);
             if (l == 0 || l == 4) gemm_rows(acc, saux, LDA, 5, P.fwd_aux[l], wave, lane);     // abar_l
-            const size_t woff = (size_t)wave * 32 * 64 + lane;
+            const size_t woff = (size_t)wave * MT * 8 * 64 + lane;
             const f32x4* hp = reinterpret_cast<const f32x4*>(act + ((int64_t)l * ntiles + tile) * TILE_F) + woff;
             const f32x4* ap = reinterpret_cast<const f32x4*>(asave + ((int64_t)l * ntiles + tile) * TILE_F) + woff;
             f32x4* rp = reinterpret_cast<f32x4*>(rsave + ((int64_t)l * ntiles + tile) * TILE_F) + woff;
-            DH_UNROLL for (int m = 0; m < 4; ++m) {
+            DH_UNROLL for (int m = 0; m < MT; ++m) {
                 DH_UNROLL for (int t = 0; t < 2; ++t)
                     DH_UNROLL for (int r4 = 0; r4 < 4; ++r4) {
                         const int idx = ((m * 2 + t) * 4 + r4) * 64;
@@ -193,7 +192,7 @@ __global__ __launch_bounds__(256, 1) void sdf_tangent_kernel(SdfPtrs P, const fl
 // ------------------------------------------------------------------------------------------------
 // K7b: backward chain -> zbar_l (l = 7..0), bias-gradient partials, Wbar_8[0,:] partial
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 1) void sdf_bwd_kernel(SdfPtrs P, const float* __restrict__ d_sdf, int64_t npts,
+__global__ __launch_bounds__(256, TM == 128 ? 1 : 2) void sdf_bwd_kernel(SdfPtrs P, const float* __restrict__ d_sdf, int64_t npts,
                                                           const float* __restrict__ act, const float* __restrict__ rsave,
                                                           const float* __restrict__ featbar, float* __restrict__ zbar,
                                                           float* __restrict__ tpart) {
@@ -208,31 +207,32 @@ __global__ __launch_bounds__(256, 1) void sdf_bwd_kernel(SdfPtrs P, const float*
             const int64_t gp = tile * TM + tid;
             saux[tid] = gp < npts ? d_sdf[gp] : 0.f;
         }
-        f32x16 acc[4][2];
+        f32x16 acc[MT][2];
         acc_load_native(acc, featbar + tile * TILE_F, wave, lane);
         tile_colsum(acc, tp + TP_SDF_B8 * 256, wave, lane);
         acc_to_lds(acc, smain, wave, lane);
         __syncthreads();
         if (wave == 0) {                                       // sum of sdfbar -> bbar_8[0]
-            float s = saux[lane] + saux[lane + 64];
+            float s = 0.f;
+            for (int i = lane; i < TM; i += 64) s += saux[i];
             DH_UNROLL for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
             if (lane == 0) tp[TP_SCAL * 256] = s;
         }
         // hbar_8 = featbar W8[1:,:] + sdfbar (x) W8[0,:]
         acc_zero(acc);
         gemm_rows(acc, smain, LDX, 32, P.rev_main[8], wave, lane);
-        DH_UNROLL for (int m = 0; m < 4; ++m)
+        DH_UNROLL for (int m = 0; m < MT; ++m)
             DH_UNROLL for (int r = 0; r < 16; ++r) {
                 const float sb = saux[acc_row(m, r, lane)];
                 acc[m][0][r] = fmaf(sb, w0c0, acc[m][0][r]);
                 acc[m][1][r] = fmaf(sb, w0c1, acc[m][1][r]);
             }
         for (int l = 7; l >= 0; --l) {
-            const size_t woff = (size_t)wave * 32 * 64 + lane;
+            const size_t woff = (size_t)wave * MT * 8 * 64 + lane;
             const f32x4* hp = reinterpret_cast<const f32x4*>(act + ((int64_t)l * ntiles + tile) * TILE_F) + woff;
             const f32x4* rp = reinterpret_cast<const f32x4*>(rsave + ((int64_t)l * ntiles + tile) * TILE_F) + woff;
             float ws0 = 0.f, ws1 = 0.f;                         // sum_rows sdfbar * h_8 (l == 7 only)
-            DH_UNROLL for (int m = 0; m < 4; ++m) {
+            DH_UNROLL for (int m = 0; m < MT; ++m) {
                 DH_UNROLL for (int t = 0; t < 2; ++t)
                     DH_UNROLL for (int r4 = 0; r4 < 4; ++r4) {
                         const int idx = ((m * 2 + t) * 4 + r4) * 64;

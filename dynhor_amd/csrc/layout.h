@@ -9,7 +9,12 @@
 
 namespace dh {
 
-constexpr int TM = 128;        // points per tile (= rows of every tile GEMM)
+#ifndef DH_TM
+#define DH_TM 64
+#endif
+constexpr int TM = DH_TM;      // points per tile (= rows of every tile GEMM): 64 -> 2 workgroups/CU, 128 -> 1
+constexpr int MT = TM / 32;    // 32-row m-tiles per tile
+static_assert(TM == 64 || TM == 128, "tile height");
 constexpr int HID = 256;       // hidden width == main-tile width
 constexpr int AUXW = 40;       // aux tile logical width (39 embedding / 33 colour extras, zero padded)
 constexpr int LDX = 260;       // LDS row stride (floats) of the main tile: 260 % 64 == 4 -> b128 reads conflict free

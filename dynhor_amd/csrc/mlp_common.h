@@ -8,16 +8,16 @@ namespace dh {
 // positional embedding of 128 points into the LDS aux image: [x, sin(2^k x), cos(2^k x)]_{k<6}  (App. A.1)
 // 256 threads: thread handles point tid&127 and frequencies 3*(tid>>7) .. +2.
 // ------------------------------------------------------------------------------------------------
+constexpr int TPP = 256 / TM;      // threads per point in the per-point VALU phases (2 or 4)
 __device__ __forceinline__ void embed_tile(const float* __restrict__ pts, int64_t base, int64_t npts, float* aux, int tid) {
-    const int p = tid & 127, half = tid >> 7;
+    const int p = tid & (TM - 1), part = tid / TM;
     const int64_t gp = base + p;
     float x[3] = {0.f, 0.f, 0.f};
     if (gp < npts) { x[0] = pts[gp * 3 + 0]; x[1] = pts[gp * 3 + 1]; x[2] = pts[gp * 3 + 2]; }
     float* row = aux + p * LDA;
-    if (half == 0) { row[0] = x[0]; row[1] = x[1]; row[2] = x[2]; }
-    else           { row[39] = 0.f; row[40] = 0.f; row[41] = 0.f; row[42] = 0.f; row[43] = 0.f; }
-    DH_UNROLL for (int kk = 0; kk < 3; ++kk) {
-        const int k = half * 3 + kk;
+    if (part == 0) { row[0] = x[0]; row[1] = x[1]; row[2] = x[2]; }
+    if (part == 1) { row[39] = 0.f; row[40] = 0.f; row[41] = 0.f; row[42] = 0.f; row[43] = 0.f; }
+    for (int k = part; k < 6; k += TPP) {
         const float f = (float)(1 << k);
         DH_UNROLL for (int c = 0; c < 3; ++c) {
             float s, co;
@@ -29,23 +29,25 @@ __device__ __forceinline__ void embed_tile(const float* __restrict__ pts, int64_
 }
 
 template <class F>
-__device__ __forceinline__ void acc_map(f32x16 (&acc)[4][2], F f) {
-    DH_UNROLL for (int m = 0; m < 4; ++m)
+__device__ __forceinline__ void acc_map(f32x16 (&acc)[MT][2], F f) {
+    DH_UNROLL for (int m = 0; m < MT; ++m)
         DH_UNROLL for (int t = 0; t < 2; ++t)
             DH_UNROLL for (int r = 0; r < 16; ++r) acc[m][t][r] = f(m, t, r, acc[m][t][r]);
 }
 
-// per-point dot of the LDS main tile rows with a 256-vector: 2 threads per point, result valid on even threads
+// per-point dot of the LDS main tile rows with a 256-vector: TPP threads per point (point = tid / TPP), result
+// valid on every thread of the group
 __device__ __forceinline__ float row_dot256(const float* main, const float* __restrict__ w, int tid) {
-    const int p = tid >> 1, half = tid & 1;
-    const f32x4* xr = reinterpret_cast<const f32x4*>(main + p * LDX + half * 128);
-    const f32x4* wr = reinterpret_cast<const f32x4*>(w + half * 128);
+    constexpr int SEG = 256 / TPP;
+    const int p = tid / TPP, part = tid % TPP;
+    const f32x4* xr = reinterpret_cast<const f32x4*>(main + p * LDX + part * SEG);
+    const f32x4* wr = reinterpret_cast<const f32x4*>(w + part * SEG);
     float s = 0.f;
-    DH_UNROLL for (int i = 0; i < 32; ++i) {
+    DH_UNROLL for (int i = 0; i < SEG / 4; ++i) {
         const f32x4 a = xr[i], b = wr[i];
         s = fmaf(a[0], b[0], s); s = fmaf(a[1], b[1], s); s = fmaf(a[2], b[2], s); s = fmaf(a[3], b[3], s);
     }
-    s += __shfl_xor(s, 1);
+    DH_UNROLL for (int off = 1; off < TPP; off <<= 1) s += __shfl_xor(s, off);
     return s;
 }
 
@@ -97,11 +99,11 @@ static inline ColPtrs make_col_ptrs(const float* packed) {
 }
 
 
-// column sums of a [128 x 256] accumulator tile -> dst[256]
-__device__ __forceinline__ void tile_colsum(const f32x16 (&acc)[4][2], float* __restrict__ dst, int wave, int lane) {
+// column sums of a [TM x 256] accumulator tile -> dst[256]
+__device__ __forceinline__ void tile_colsum(const f32x16 (&acc)[MT][2], float* __restrict__ dst, int wave, int lane) {
     DH_UNROLL for (int t = 0; t < 2; ++t) {
         float s = 0.f;
-        DH_UNROLL for (int m = 0; m < 4; ++m)
+        DH_UNROLL for (int m = 0; m < MT; ++m)
             DH_UNROLL for (int r = 0; r < 16; ++r) s += acc[m][t][r];
         s += __shfl_xor(s, 32);
         if (lane < 32) dst[64 * wave + 32 * t + lane] = s;
