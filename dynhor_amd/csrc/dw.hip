@@ -15,49 +15,109 @@ namespace dh {
 struct DwJob {
     const float* A1; const float* B1;
     const float* A2; const float* B2;      // optional second (A,B) pair accumulated into the same output
-    float* out;                            // [G][8][nb][16][64]
+    int64_t off;                           // float offset of this job's [256 x nb*32] slab inside a split's slab block
     int nb;                                // 8: B is a main native tile; 2: B is an aux native tile
 };
 struct DwJobs { DwJob j[16]; int n; };
 
+// NB == 8: wave (wo = wave>>1, wn = wave&1) owns output rows [64wo, 64wo+64) x cols [128wn, 128wn+128): 2 x 4 tiles,
+//          6 operand float4 per 32 MFMAs.   NB == 2: wave owns rows [32wave, 32wave+32) x 64 cols: 1 x 2 tiles.
+template <int NB> struct DwShape;
+template <> struct DwShape<8> { static constexpr int NA = 2, NBW = 4; };
+template <> struct DwShape<2> { static constexpr int NA = 1, NBW = 2; };
+
 template <int NB>
-__device__ __forceinline__ void dw_body(const DwJob& J, int64_t t0, int64_t t1, int g, int wave, int lane) {
-    f32x16 acc[NB];
-    DH_UNROLL for (int j = 0; j < NB; ++j) DH_UNROLL for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-    const int abase = (((wave >> 1) * MT) * 2 + (wave & 1)) * 4 * 64 + lane;
+struct DwOperands { f32x4 a[DwShape<NB>::NA]; f32x4 b[DwShape<NB>::NBW]; };
+
+template <int NB>
+__device__ __forceinline__ void dw_load(DwOperands<NB>& o, const f32x4* ap, const f32x4* bp, int kq, int wave) {
+    const int m = kq >> 2, r4 = kq & 3;
+    DH_UNROLL for (int i = 0; i < DwShape<NB>::NA; ++i) {
+        const int ot = (NB == 8) ? ((wave >> 1) * 2 + i) : wave;                       // output 32-row tile 0..7
+        o.a[i] = ap[(((ot >> 1) * MT + m) * 2 + (ot & 1)) * 4 * 64 + r4 * 64];
+    }
+    DH_UNROLL for (int j = 0; j < DwShape<NB>::NBW; ++j) {
+        const int nt = (NB == 8) ? ((wave & 1) * 4 + j) : j;                           // B n-tile
+        const int bi = (NB == 8) ? ((((nt >> 1) * MT + m) * 2 + (nt & 1)) * 4 + r4) : ((m * 2 + nt) * 4 + r4);
+        o.b[j] = bp[bi * 64];
+    }
+}
+template <int NB>
+__device__ __forceinline__ void dw_mfma(f32x16 (&acc)[DwShape<NB>::NA][DwShape<NB>::NBW], const DwOperands<NB>& o) {
+    DH_UNROLL for (int rr = 0; rr < 4; ++rr)
+        DH_UNROLL for (int i = 0; i < DwShape<NB>::NA; ++i)
+            DH_UNROLL for (int j = 0; j < DwShape<NB>::NBW; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(o.a[i][rr], o.b[j][rr], acc[i][j], 0, 0, 0);
+}
+
+template <int NB>
+__device__ __forceinline__ void dw_body(const DwJob& J, int64_t t0, int64_t t1, float* __restrict__ out, int wave, int lane) {
+    constexpr int KQ = MT * 4;                 // k-quads (8 points each) per tile
+    constexpr int BT = (NB == 8) ? TILE_F : AUXT_F;
+    constexpr int NA = DwShape<NB>::NA, NBW = DwShape<NB>::NBW;
+    f32x16 acc[NA][NBW];
+    DH_UNROLL for (int i = 0; i < NA; ++i) DH_UNROLL for (int j = 0; j < NBW; ++j) DH_UNROLL for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     for (int pair = 0; pair < 2; ++pair) {
         const float* A = pair ? J.A2 : J.A1;
         const float* Bm = pair ? J.B2 : J.B1;
-        if (!A) continue;
+        if (!A || t0 >= t1) continue;
+        DwOperands<NB> s0, s1;
+        dw_load<NB>(s0, reinterpret_cast<const f32x4*>(A + t0 * TILE_F) + lane,
+                    reinterpret_cast<const f32x4*>(Bm + t0 * BT) + lane, 0, wave);
         for (int64_t tile = t0; tile < t1; ++tile) {
-            const f32x4* ap = reinterpret_cast<const f32x4*>(A + tile * TILE_F) + abase;
-            const f32x4* bp = reinterpret_cast<const f32x4*>(Bm + tile * (NB == 8 ? TILE_F : AUXT_F)) + lane;
-            _Pragma("unroll 2") for (int kq = 0; kq < MT * 4; ++kq) {
-                const int m = kq >> 2, r4 = kq & 3;
-                const f32x4 a = ap[(m * 8 + r4) * 64];
-                f32x4 b[NB];
-                DH_UNROLL for (int j = 0; j < NB; ++j) {
-                    const int bi = (NB == 8) ? ((j >> 1) * MT * 8 + m * 8 + (j & 1) * 4 + r4) : ((m * 2 + j) * 4 + r4);
-                    b[j] = bp[bi * 64];
-                }
-                DH_UNROLL for (int rr = 0; rr < 4; ++rr)
-                    DH_UNROLL for (int j = 0; j < NB; ++j)
-                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[rr], b[j][rr], acc[j], 0, 0, 0);
+            const f32x4* ap = reinterpret_cast<const f32x4*>(A + tile * TILE_F) + lane;
+            const f32x4* bp = reinterpret_cast<const f32x4*>(Bm + tile * BT) + lane;
+            const int64_t tn = (tile + 1 < t1) ? tile + 1 : tile;
+            const f32x4* apn = reinterpret_cast<const f32x4*>(A + tn * TILE_F) + lane;
+            const f32x4* bpn = reinterpret_cast<const f32x4*>(Bm + tn * BT) + lane;
+            // operands of k-quad q+1 are issued before the MFMAs of k-quad q (order pinned: see gemm_rows)
+            DH_UNROLL for (int kq = 0; kq < KQ; kq += 2) {
+                dw_load<NB>(s1, ap, bp, kq + 1, wave);
+                __builtin_amdgcn_sched_barrier(0);
+                dw_mfma<NB>(acc, s0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (kq + 2 < KQ) dw_load<NB>(s0, ap, bp, kq + 2, wave);
+                else dw_load<NB>(s0, apn, bpn, 0, wave);
+                __builtin_amdgcn_sched_barrier(0);
+                dw_mfma<NB>(acc, s1);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
     }
-    float* o = J.out + ((int64_t)(g * 8 + wave) * NB) * 1024 + lane;
-    DH_UNROLL for (int j = 0; j < NB; ++j)
-        DH_UNROLL for (int r = 0; r < 16; ++r) o[j * 1024 + r * 64] = acc[j][r];
+    // slab layout == accumulator layout: [ot 0..7][nt 0..nb)[16][64]
+    DH_UNROLL for (int i = 0; i < NA; ++i)
+        DH_UNROLL for (int j = 0; j < NBW; ++j) {
+            const int ot = (NB == 8) ? ((wave >> 1) * 2 + i) : wave;
+            const int nt = (NB == 8) ? ((wave & 1) * 4 + j) : j;
+            float* o = out + ((int64_t)ot * NB + nt) * 1024 + lane;
+            DH_UNROLL for (int r = 0; r < 16; ++r) o[r * 64] = acc[i][j][r];
+        }
 }
 
-__global__ __launch_bounds__(512, 2) void dw_kernel(DwJobs jobs, int64_t ntiles) {
-    const DwJob J = jobs.j[blockIdx.y];
+// One persistent workgroup per CU: split g owns tiles [nt*g/G, nt*(g+1)/G) and runs EVERY job over them, so all
+// workgroups do identical work (no tail) and write one slab block each.
+__global__ __launch_bounds__(512, 2) void dw_kernel(DwJobs jobs, int64_t ntiles, float* __restrict__ slabs, int64_t gstride) {
     const int G = gridDim.x, g = blockIdx.x;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int64_t t0 = ntiles * g / G, t1 = ntiles * (g + 1) / G;
-    if (J.nb == 8) dw_body<8>(J, t0, t1, g, wave, lane);
-    else dw_body<2>(J, t0, t1, g, wave, lane);
+    float* base = slabs + (int64_t)g * gstride;
+    for (int job = 0; job < jobs.n; ++job) {
+        const DwJob J = jobs.j[job];
+        if (J.nb == 8) dw_body<8>(J, t0, t1, base + J.off, wave, lane);
+        else dw_body<2>(J, t0, t1, base + J.off, wave, lane);
+    }
+}
+
+// red[e] = sum_g slabs[g*gstride + e]
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slabs, int64_t gstride, int G, float* __restrict__ red) {
+    const int64_t e = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (e >= gstride) return;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    for (int g = 0; g < G; ++g) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(slabs + (int64_t)g * gstride + e);
+        s[0] += v[0]; s[1] += v[1]; s[2] += v[2]; s[3] += v[3];
+    }
+    *reinterpret_cast<f32x4*>(red + e) = s;
 }
 
 // ---------------------------------------------------------------- per-tile partial sums -> [S][N_TILE_PART][256]
@@ -83,18 +143,14 @@ struct FoldLin {
 struct FoldTable { FoldLin lin[N_SDF + N_COL]; int total_rows; };
 struct SlabPtrs { const float* out[16]; int nb[16]; };
 
-__device__ __forceinline__ float slab_elem(const float* __restrict__ slab, int nb, int G, int o, int i) {
+__device__ __forceinline__ float slab_elem(const float* __restrict__ slab, int nb, int o, int i) {
     const int w = o >> 5, ro = o & 31, j = i >> 5;
     const int r = (ro & 3) + 4 * (ro >> 3);
     const int lane = (i & 31) + 32 * ((ro >> 2) & 1);
-    const int64_t stride = (int64_t)8 * nb * 1024;
-    const float* p = slab + ((int64_t)w * nb + j) * 1024 + r * 64 + lane;
-    float s = 0.f;
-    for (int g = 0; g < G; ++g) s += p[g * stride];
-    return s;
+    return slab[((int64_t)w * nb + j) * 1024 + r * 64 + lane];
 }
 
-__global__ __launch_bounds__(256) void fold_kernel(FoldTable T, SlabPtrs S, int G, const float* __restrict__ tred, int nS,
+__global__ __launch_bounds__(256) void fold_kernel(FoldTable T, SlabPtrs S, const float* __restrict__ tred, int nS,
                                                    const float* __restrict__ params, const float* __restrict__ packed,
                                                    float* __restrict__ grad) {
     __shared__ float s_red[4];
@@ -118,9 +174,9 @@ __global__ __launch_bounds__(256) void fold_kernel(FoldTable T, SlabPtrs S, int 
             else if (Ln.special == 1 && o == 0) d = tsum(9, i) + tsum(10, i);             // sdf lin8 row 0
             else {
                 const int so = o - Ln.row_shift;
-                if (i >= Ln.a_c0 && i < Ln.a_c1) d = Ln.a_scale * slab_elem(S.out[Ln.jobA], S.nb[Ln.jobA], G, so, i - Ln.a_c0);
+                if (i >= Ln.a_c0 && i < Ln.a_c1) d = Ln.a_scale * slab_elem(S.out[Ln.jobA], S.nb[Ln.jobA], so, i - Ln.a_c0);
                 else if (Ln.jobB >= 0 && i >= Ln.b_c0 && i < Ln.b_c1)
-                    d = Ln.b_scale * slab_elem(S.out[Ln.jobB], S.nb[Ln.jobB], G, so, i - Ln.b_c0);
+                    d = Ln.b_scale * slab_elem(S.out[Ln.jobB], S.nb[Ln.jobB], so, i - Ln.b_c0);
             }
             dw[q] = d;
             vv[q] = params[Ln.voff + (int64_t)o * Ln.in + i];
@@ -178,22 +234,24 @@ static FoldTable build_fold_table() {
     return T;
 }
 
-// dW slab workspace: 15 jobs x G x (256 x nb*32) floats
-int64_t dw_slab_floats(int G) {
+// dW slab workspace: G split blocks of (sum over 15 jobs of 256 x nb*32) floats, plus one reduced block
+static const int DW_NBS[15] = {2, 8, 8, 8, 8, 8, 8, 8, 2, 8, 8, 2, 8, 8, 8};
+static int64_t dw_gstride() {
     int64_t n = 0;
-    const int nbs[15] = {2, 8, 8, 8, 8, 8, 8, 8, 2, 8, 8, 2, 8, 8, 8};
-    for (int j = 0; j < 15; ++j) n += (int64_t)G * 8 * nbs[j] * 1024;
+    for (int j = 0; j < 15; ++j) n += (int64_t)8 * DW_NBS[j] * 1024;
     return n;
 }
+int64_t dw_slab_floats(int G) { return (int64_t)(G + 1) * dw_gstride(); }
 
 int launch_weight_grads(const Workspace& w, float* slabs, float* tred, int G, int nS, const float* params,
                         const float* packed, float* grad, hipStream_t st) {
     const int64_t nt = w.ntiles;
+    const int64_t gstride = dw_gstride();
+    float* red = slabs + (int64_t)G * gstride;
     DwJobs J{};
     SlabPtrs S{};
-    const int nbs[15] = {2, 8, 8, 8, 8, 8, 8, 8, 2, 8, 8, 2, 8, 8, 8};
-    float* so = slabs;
-    for (int j = 0; j < 15; ++j) { J.j[j].nb = nbs[j]; J.j[j].out = so; S.out[j] = so; S.nb[j] = nbs[j]; so += (int64_t)G * 8 * nbs[j] * 1024; }
+    int64_t off = 0;
+    for (int j = 0; j < 15; ++j) { J.j[j].nb = DW_NBS[j]; J.j[j].off = off; S.out[j] = red + off; S.nb[j] = DW_NBS[j]; off += (int64_t)8 * DW_NBS[j] * 1024; }
     J.n = 15;
     auto T_ = [&](float* base, int idx) { return base + (int64_t)idx * nt * TILE_F; };
     J.j[0].A1 = T_(w.zbar, 0); J.j[0].B1 = w.eaux; J.j[0].A2 = T_(w.asave, 0); J.j[0].B2 = w.t0aux;
@@ -208,10 +266,11 @@ int launch_weight_grads(const Workspace& w, float* slabs, float* tred, int G, in
     for (int l = 1; l <= 3; ++l) {
         J.j[11 + l].A1 = T_(w.czbar, l); J.j[11 + l].B1 = T_(w.cact, l - 1); J.j[11 + l].A2 = nullptr; J.j[11 + l].B2 = nullptr;
     }
-    hipLaunchKernelGGL(dw_kernel, dim3(G, 15), dim3(512), 0, st, J, nt);
+    hipLaunchKernelGGL(dw_kernel, dim3(G), dim3(512), 0, st, J, nt, slabs, gstride);
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((gstride / 4 + 255) / 256)), dim3(256), 0, st, slabs, gstride, G, red);
     hipLaunchKernelGGL(tpart_reduce_kernel, dim3(N_TILE_PART, nS), dim3(256), 0, st, w.tpart, nt, tred);
     static const FoldTable T = build_fold_table();
-    hipLaunchKernelGGL(fold_kernel, dim3(T.total_rows), dim3(256), 0, st, T, S, G, tred, nS, params, packed, grad);
+    hipLaunchKernelGGL(fold_kernel, dim3(T.total_rows), dim3(256), 0, st, T, S, tred, nS, params, packed, grad);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 

@@ -47,16 +47,22 @@ __device__ __forceinline__ void gemm_rows(f32x16 (&acc)[MT][2], const float* xs,
     f32x4 a0[MT], b0[2], a1[MT], b1[2];
     DH_UNROLL for (int t = 0; t < 2; ++t) b0[t] = wl[t * 64];
     DH_UNROLL for (int m = 0; m < MT; ++m) a0[m] = *reinterpret_cast<const f32x4*>(xrow + m * 32 * ldx);
+    // sched_barrier(0) pins "issue next operands, THEN the 8*MT MFMAs of the current ones": left alone, hipcc sinks
+    // the loads to just ahead of their first use and every k-group eats the L2 latency.
     _Pragma("unroll 1") for (int kg = 0; kg < nkg; kg += 2) {
         const int k1 = (kg + 1 < nkg) ? kg + 1 : kg;
         DH_UNROLL for (int t = 0; t < 2; ++t) b1[t] = wl[(k1 * 8 + t) * 64];
         DH_UNROLL for (int m = 0; m < MT; ++m) a1[m] = *reinterpret_cast<const f32x4*>(xrow + m * 32 * ldx + k1 * 8);
+        __builtin_amdgcn_sched_barrier(0);
         mfma_block(acc, a0, b0);
+        __builtin_amdgcn_sched_barrier(0);
         if (kg + 1 < nkg) {
             const int k2 = (kg + 2 < nkg) ? kg + 2 : kg + 1;
             DH_UNROLL for (int t = 0; t < 2; ++t) b0[t] = wl[(k2 * 8 + t) * 64];
             DH_UNROLL for (int m = 0; m < MT; ++m) a0[m] = *reinterpret_cast<const f32x4*>(xrow + m * 32 * ldx + k2 * 8);
+            __builtin_amdgcn_sched_barrier(0);
             mfma_block(acc, a1, b1);
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
 }
@@ -80,9 +86,11 @@ __device__ __forceinline__ void gemm_auxout(f32x16 (&acc2)[AUX_NTW], const float
         f32x4 an = *reinterpret_cast<const f32x4*>(xrow + kn * 8);
         f32x4 bn[AUX_NTW];
         DH_UNROLL for (int t = 0; t < AUX_NTW; ++t) bn[t] = wl[(kn * 2 + t) * 64];
+        __builtin_amdgcn_sched_barrier(0);
         DH_UNROLL for (int s = 0; s < 4; ++s)
             DH_UNROLL for (int t = 0; t < AUX_NTW; ++t)
                 acc2[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b[t][s], acc2[t], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
         a = an;
         DH_UNROLL for (int t = 0; t < AUX_NTW; ++t) b[t] = bn[t];
     }
@@ -153,21 +161,20 @@ __device__ __forceinline__ void aux_lds_to_native(const float* aux, float* __res
 }
 
 // ---------------------------------------------------------------- activation math
-// softplus(beta=100, threshold=20) with a compensated log1p (matches torch's log1p(exp(bx))/b to ~1 ulp)
+// fp32 MFMA issues at the VALU rate and does not overlap VALU work of either wave on the SIMD (measured:
+// scripts/micro/gemm_micro.hip), so every epilogue instruction is paid in full -- keep these minimal.
+// softplus(beta=100) = max(z,0) + log1p(exp(-|beta z|))/beta : 1 mul, v_exp, 1 add, v_log, v_max, 1 fma.
+// Equals torch's softplus (incl. its threshold=20 branch: the log term is < 2.1e-11 there) to <= 1e-9 absolute.
 __device__ __forceinline__ float softplus100(float z) {
-    const float t = SOFTPLUS_BETA * z;
-    const float e = __expf(fminf(t, 20.f));
-    const float u = 1.f + e;
-    const float d = u - 1.f;
-    const float l = (d == 0.f) ? e : __logf(u) * (e / d);
-    return t > 20.f ? z : l * (1.f / SOFTPLUS_BETA);
+    const float e = __builtin_amdgcn_exp2f(-fabsf(z) * (SOFTPLUS_BETA * 1.44269504088896f));
+    const float l = __builtin_amdgcn_logf(1.f + e);
+    return fmaf(l, 0.69314718055995f / SOFTPLUS_BETA, fmaxf(z, 0.f));
 }
-// From the saved post-activation h = softplus(z): s = sigma'(z) = 1 - exp(-beta h); em = exp(-beta h) = 1 - s.
+// From the saved post-activation h = softplus(z): em = exp(-beta h) = 1 - sigma'(z), s = sigma'(z) = 1 - em
+// (absolute error <= 6e-8 on s in [0,1]).
 __device__ __forceinline__ void softplus_deriv_from_h(float h, float& s, float& em) {
-    const float x = SOFTPLUS_BETA * h;
-    em = __expf(-x);
-    const float series = x * (1.f - x * (0.5f - x * (0.16666667f - x * (0.041666668f - x * 0.0083333338f))));
-    s = (x < 0.0625f) ? series : 1.f - em;
+    em = __builtin_amdgcn_exp2f(h * (-SOFTPLUS_BETA * 1.44269504088896f));
+    s = 1.f - em;
 }
 
 }  // namespace dh
