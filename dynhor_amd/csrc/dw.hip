@@ -6,6 +6,7 @@
 // coalesced loads and no LDS.  8 waves per workgroup, wave w owns output rows [32w, 32w+32) x all NB n-tiles
 // (128 accumulator VGPRs at NB=8); split-K over tiles across gridDim.x workgroups, slabs reduced in fold_kernel
 // (deterministic: no float atomics).
+#include <cstdlib>
 #include "tile.h"
 #include "kernels.h"
 #include "workspace.h"
@@ -51,7 +52,8 @@ __device__ __forceinline__ void dw_mfma(f32x16 (&acc)[DwShape<NB>::NA][DwShape<N
 }
 
 template <int NB>
-__device__ __forceinline__ void dw_body(const DwJob& J, int64_t t0, int64_t t1, float* __restrict__ out, int wave, int lane) {
+__device__ __forceinline__ void dw_body(const DwJob& J, int64_t t0, int64_t t1, float* __restrict__ out, int wave, int lane,
+                                        int64_t tile_mask) {
     constexpr int KQ = MT * 4;                 // k-quads (8 points each) per tile
     constexpr int BT = (NB == 8) ? TILE_F : AUXT_F;
     constexpr int NA = DwShape<NB>::NA, NBW = DwShape<NB>::NBW;
@@ -62,12 +64,12 @@ __device__ __forceinline__ void dw_body(const DwJob& J, int64_t t0, int64_t t1, 
         const float* Bm = pair ? J.B2 : J.B1;
         if (!A || t0 >= t1) continue;
         DwOperands<NB> s0, s1;
-        dw_load<NB>(s0, reinterpret_cast<const f32x4*>(A + t0 * TILE_F) + lane,
-                    reinterpret_cast<const f32x4*>(Bm + t0 * BT) + lane, 0, wave);
+        dw_load<NB>(s0, reinterpret_cast<const f32x4*>(A + (t0 & tile_mask) * TILE_F) + lane,
+                    reinterpret_cast<const f32x4*>(Bm + (t0 & tile_mask) * BT) + lane, 0, wave);
         for (int64_t tile = t0; tile < t1; ++tile) {
-            const f32x4* ap = reinterpret_cast<const f32x4*>(A + tile * TILE_F) + lane;
-            const f32x4* bp = reinterpret_cast<const f32x4*>(Bm + tile * BT) + lane;
-            const int64_t tn = (tile + 1 < t1) ? tile + 1 : tile;
+            const f32x4* ap = reinterpret_cast<const f32x4*>(A + (tile & tile_mask) * TILE_F) + lane;
+            const f32x4* bp = reinterpret_cast<const f32x4*>(Bm + (tile & tile_mask) * BT) + lane;
+            const int64_t tn = ((tile + 1 < t1) ? tile + 1 : tile) & tile_mask;
             const f32x4* apn = reinterpret_cast<const f32x4*>(A + tn * TILE_F) + lane;
             const f32x4* bpn = reinterpret_cast<const f32x4*>(Bm + tn * BT) + lane;
             // operands of k-quad q+1 are issued before the MFMAs of k-quad q (order pinned: see gemm_rows)
@@ -96,15 +98,117 @@ __device__ __forceinline__ void dw_body(const DwJob& J, int64_t t0, int64_t t1, 
 
 // One persistent workgroup per CU: split g owns tiles [nt*g/G, nt*(g+1)/G) and runs EVERY job over them, so all
 // workgroups do identical work (no tail) and write one slab block each.
-__global__ __launch_bounds__(512, 2) void dw_kernel(DwJobs jobs, int64_t ntiles, float* __restrict__ slabs, int64_t gstride) {
+__global__ __launch_bounds__(512, 2) void dw_kernel(DwJobs jobs, int64_t ntiles, float* __restrict__ slabs, int64_t gstride,
+                                                    int64_t tile_mask) {
     const int G = gridDim.x, g = blockIdx.x;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int64_t t0 = ntiles * g / G, t1 = ntiles * (g + 1) / G;
     float* base = slabs + (int64_t)g * gstride;
     for (int job = 0; job < jobs.n; ++job) {
         const DwJob J = jobs.j[job];
-        if (J.nb == 8) dw_body<8>(J, t0, t1, base + J.off, wave, lane);
-        else dw_body<2>(J, t0, t1, base + J.off, wave, lane);
+        if (J.nb == 8) dw_body<8>(J, t0, t1, base + J.off, wave, lane, tile_mask);
+        else dw_body<2>(J, t0, t1, base + J.off, wave, lane, tile_mask);
+    }
+}
+
+// ---------------------------------------------------------------- LDS-DMA staged variant (default)
+// The register-streamed kernel above fetches every operand byte 2x (A) / 4x (B) per workgroup and is limited by the
+// CU's L1-miss throughput (scripts/micro/dw_micro2.hip: 63 % streamed vs 84 % cache-resident).  Here each k-quad's
+// 16 KiB (8 A pieces + 8 B pieces of 1 KiB = one wave-wide 16-B LDS-DMA each: the native tile layout is lane-linear,
+// exactly what global_load_lds needs) enters the CU once into a DW_STAGES-deep LDS ring; the 8 waves then read their
+// 2 A + 4 B fragments with conflict-free ds_read_b128.  Every wave issues exactly 2 DMAs per k-quad, so one counted
+// s_waitcnt vmcnt(2*(S-2)) + one raw s_barrier per k-quad orders RAW (all pieces landed) and WAR (stage i-1 fully
+// read before it is refilled).  ds_reads are inline asm: hipcc would otherwise drain vmcnt(0) before LDS reads
+// while a DMA is in flight.
+constexpr int DW_STAGES = 4;
+constexpr int DW_STAGE_BYTES = 16384;
+
+__device__ __forceinline__ f32x4 lds_read_b128(unsigned addr) {
+    f32x4 v;
+    asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr));
+    return v;
+}
+
+template <int NB>
+__device__ __forceinline__ void dw_body_lds(const DwJob& J, int64_t t0, int64_t t1, float* __restrict__ out, int wave, int lane,
+                                            char* lds) {
+    constexpr int KQ = MT * 4;
+    constexpr int BT = (NB == 8) ? TILE_F : AUXT_F;
+    constexpr int NA = DwShape<NB>::NA, NBW = DwShape<NB>::NBW;
+    constexpr int S = DW_STAGES;
+    f32x16 acc[NA][NBW];
+    DH_UNROLL for (int i = 0; i < NA; ++i) DH_UNROLL for (int j = 0; j < NBW; ++j) DH_UNROLL for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int T = (int)(t1 - t0);
+    const int npairs = J.A2 ? 2 : 1;
+    const int total = npairs * T * KQ;
+    const unsigned lds_base = (unsigned)(uintptr_t)lds;     // LDS byte address of the ring
+    // this wave's DMA pieces: A piece ot = wave ; B piece nt = wave (NB == 8) or wave & 1 (NB == 2; slots >= 2 are dummies)
+    const int a_ot = wave, b_nt = (NB == 8) ? wave : (wave & 1);
+
+    auto issue = [&](int u) {
+        const int pair = u / (T * KQ);
+        const int rem = u - pair * T * KQ;
+        const int64_t tile = t0 + rem / KQ;
+        const int kq = rem % KQ, m = kq >> 2, r4 = kq & 3;
+        const float* A = pair ? J.A2 : J.A1;
+        const float* Bm = pair ? J.B2 : J.B1;
+        const int stage = u % S;
+        const f32x4* ga = reinterpret_cast<const f32x4*>(A + tile * TILE_F) + ((((a_ot >> 1) * MT + m) * 2 + (a_ot & 1)) * 4 + r4) * 64 + lane;
+        const int bi = (NB == 8) ? ((((b_nt >> 1) * MT + m) * 2 + (b_nt & 1)) * 4 + r4) : ((m * 2 + b_nt) * 4 + r4);
+        const f32x4* gb = reinterpret_cast<const f32x4*>(Bm + tile * BT) + bi * 64 + lane;
+        char* la = lds + stage * DW_STAGE_BYTES + wave * 1024;
+        char* lb = lds + stage * DW_STAGE_BYTES + 8192 + wave * 1024;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)ga,
+                                         (__attribute__((address_space(3))) void*)la, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gb,
+                                         (__attribute__((address_space(3))) void*)lb, 16, 0, 0);
+    };
+
+    if (total > 0) {
+        for (int u = 0; u < S - 1 && u < total; ++u) issue(u);
+        for (int i = 0; i < total; ++i) {
+            const int after = total - 1 - i;                       // units issued after unit i (capped at S-2)
+            if (after >= S - 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (S - 2)) : "memory");
+            else if (after == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_barrier" ::: "memory");
+            if (i + S - 1 < total) issue(i + S - 1);
+            const unsigned sb = lds_base + (unsigned)(i % S) * DW_STAGE_BYTES + (unsigned)lane * 16;
+            DwOperands<NB> o;
+            DH_UNROLL for (int ii = 0; ii < NA; ++ii) {
+                const int ot = (NB == 8) ? ((wave >> 1) * 2 + ii) : wave;
+                o.a[ii] = lds_read_b128(sb + ot * 1024);
+            }
+            DH_UNROLL for (int j = 0; j < NBW; ++j) {
+                const int nt = (NB == 8) ? ((wave & 1) * 4 + j) : j;
+                o.b[j] = lds_read_b128(sb + 8192 + nt * 1024);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            dw_mfma<NB>(acc, o);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    asm volatile("s_barrier" ::: "memory");      // ring is reused by the next job
+    DH_UNROLL for (int i = 0; i < NA; ++i)
+        DH_UNROLL for (int j = 0; j < NBW; ++j) {
+            const int ot = (NB == 8) ? ((wave >> 1) * 2 + i) : wave;
+            const int nt = (NB == 8) ? ((wave & 1) * 4 + j) : j;
+            float* o = out + ((int64_t)ot * NB + nt) * 1024 + lane;
+            DH_UNROLL for (int r = 0; r < 16; ++r) o[r * 64] = acc[i][j][r];
+        }
+}
+
+__global__ __launch_bounds__(512, 2) void dw_lds_kernel(DwJobs jobs, int64_t ntiles, float* __restrict__ slabs, int64_t gstride) {
+    __shared__ __attribute__((aligned(16))) char ring[DW_STAGES * DW_STAGE_BYTES];
+    const int G = gridDim.x, g = blockIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int64_t t0 = ntiles * g / G, t1 = ntiles * (g + 1) / G;
+    float* base = slabs + (int64_t)g * gstride;
+    for (int job = 0; job < jobs.n; ++job) {
+        const DwJob J = jobs.j[job];
+        if (J.nb == 8) dw_body_lds<8>(J, t0, t1, base + J.off, wave, lane, ring);
+        else dw_body_lds<2>(J, t0, t1, base + J.off, wave, lane, ring);
     }
 }
 
@@ -266,7 +370,9 @@ int launch_weight_grads(const Workspace& w, float* slabs, float* tred, int G, in
     for (int l = 1; l <= 3; ++l) {
         J.j[11 + l].A1 = T_(w.czbar, l); J.j[11 + l].B1 = T_(w.cact, l - 1); J.j[11 + l].A2 = nullptr; J.j[11 + l].B2 = nullptr;
     }
-    hipLaunchKernelGGL(dw_kernel, dim3(G), dim3(512), 0, st, J, nt, slabs, gstride);
+    static const bool use_regs = getenv("DH_DW_REGS") != nullptr;     // A/B switch: register-streamed variant
+    if (use_regs) hipLaunchKernelGGL(dw_kernel, dim3(G), dim3(512), 0, st, J, nt, slabs, gstride, (int64_t)-1);
+    else hipLaunchKernelGGL(dw_lds_kernel, dim3(G), dim3(512), 0, st, J, nt, slabs, gstride);
     hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((gstride / 4 + 255) / 256)), dim3(256), 0, st, slabs, gstride, G, red);
     hipLaunchKernelGGL(tpart_reduce_kernel, dim3(N_TILE_PART, nS), dim3(256), 0, st, w.tpart, nt, tred);
     static const FoldTable T = build_fold_table();
