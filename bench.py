@@ -20,7 +20,7 @@ import torch.distributed as dist
 # algorithmic MACs per sample point of each MLP stage (DESIGN.md "Algorithmic work")
 MACS = {
     "sdf_forward": 524544, "sdf_gradient": 459008, "color_forward": 271360, "color_backward": 271360,
-    "sdf_tangent": 458752, "sdf_backward": 514560, "weight_grads": 1254656,
+    "sdf_tangent": 458752, "sdf_backward": 514560, "weight_grads_gemm": 1254656,
     "sdf_nograd_coarse": 459008, "sdf_nograd_fine": 459008,
 }
 FP32_MFMA_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md, Chip-level parameters
@@ -64,7 +64,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--frames", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-rays", type=int, default=64)
+    ap.add_argument("--cpu-rays", type=int, default=512)
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -118,16 +118,23 @@ def main():
                "sdf_nograd_fine": B * (runner.renderer.n_importance // max(runner.renderer.up_sample_steps, 1))}
         per_kernel = {}
         for k, (mean_ms, cnt) in kern.items():
+            if k not in MACS:
+                per_kernel[k] = {"ms": round(mean_ms, 4), "launches_per_step": cnt / args.steps}
+                continue
             npts = pts.get(k, P)
             tf = 2.0 * MACS[k] * npts / (mean_ms * 1e-3) / 1e12
             per_kernel[k] = {"ms": round(mean_ms, 4), "launches_per_step": cnt / args.steps, "tflops": round(tf, 2)}
-        dom = max((k for k in per_kernel if per_kernel[k]["launches_per_step"] <= 1.01),
+        dom = max((k for k in per_kernel if per_kernel[k]["launches_per_step"] <= 1.01 and "tflops" in per_kernel[k]),
                   key=lambda k: per_kernel[k]["ms"])
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tpath):
-            traffic = json.load(open(tpath)).get(dom)
-        roof = {"bound": "mfma", "kernel": dom, "achieved": per_kernel[dom]["tflops"], "peak": FP32_MFMA_PEAK_TFLOPS,
+            traffic = json.load(open(tpath)).get(dom, {}).get("hbm_bytes_per_launch")
+        hip_names = {"weight_grads_gemm": "dw_lds_kernel", "sdf_forward": "sdf_fwd_train_kernel",
+                     "sdf_gradient": "sdf_grad_kernel", "color_forward": "color_fwd_kernel",
+                     "color_backward": "color_bwd_kernel", "sdf_tangent": "sdf_tangent_kernel",
+                     "sdf_backward": "sdf_bwd_kernel", "sdf_nograd_coarse": "sdf_nograd_kernel"}
+        roof = {"bound": "mfma", "kernel": hip_names.get(dom, dom), "stage": dom, "achieved": per_kernel[dom]["tflops"], "peak": FP32_MFMA_PEAK_TFLOPS,
                 "unit": "TFLOP/s", "frac": round(per_kernel[dom]["tflops"] / FP32_MFMA_PEAK_TFLOPS, 4),
                 "traffic": traffic, "avg_launch_ms": per_kernel[dom]["ms"],
                 "whole_step_mfma_frac": round(value / world * FLOP_PER_RAY_TRAIN / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4)}

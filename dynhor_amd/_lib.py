@@ -28,7 +28,8 @@ SIGNATURES = {
     "dh_color_backward": (_i32, [_vp, _vp, _vp, _i64, _vp, _vp, _vp]),
     "dh_sdf_tangent": (_i32, [_vp, _vp, _vp, _i64, _vp, _vp]),
     "dh_sdf_backward": (_i32, [_vp, _vp, _i64, _vp, _vp]),
-    "dh_weight_grads": (_i32, [_vp, _vp, _i64, _vp, _vp, _vp]),
+    "dh_weight_grads_gemm": (_i32, [_i64, _vp, _vp]),
+    "dh_weight_grads_fold": (_i32, [_vp, _vp, _i64, _vp, _vp, _vp]),
     "dh_mlp_backward": (_i32, [_vp, _vp, _vp, _i64] + [_vp] * 7),
     "dh_adam_step": (_i32, [_vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _i64, _f32, _vp]),
     "dh_gen_rays": (_i32, [_vp] * 6 + [_i32, _i32, _i32, _i32, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),

@@ -124,11 +124,18 @@ int dh_sdf_backward(const float* packed, const float* d_sdf, int64_t npts, float
                           static_cast<hipStream_t>(stream));
 }
 
-int dh_weight_grads(const float* packed, const float* params, int64_t npts, float* ws, float* grad_flat, void* stream) {
+int dh_weight_grads_gemm(int64_t npts, float* ws, void* stream) {
+    if (npts <= 0) return DH_ERR_BAD_ARG;
+    if (!ws || misaligned16(ws)) return DH_ERR_BAD_ARG;
+    const Workspace w = carve_workspace(ws, npts);
+    return launch_weight_grads_gemm(w, w.slabs, DW_G, static_cast<hipStream_t>(stream));
+}
+
+int dh_weight_grads_fold(const float* packed, const float* params, int64_t npts, float* ws, float* grad_flat, void* stream) {
     if (npts <= 0) return DH_ERR_BAD_ARG;
     if (!packed || !params || !ws || !grad_flat || misaligned16(packed) || misaligned16(ws)) return DH_ERR_BAD_ARG;
     const Workspace w = carve_workspace(ws, npts);
-    return launch_weight_grads(w, w.slabs, w.tred, DW_G, DW_NS, params, packed, grad_flat, static_cast<hipStream_t>(stream));
+    return launch_weight_grads_fold(w, w.slabs, w.tred, DW_G, DW_NS, params, packed, grad_flat, static_cast<hipStream_t>(stream));
 }
 
 int dh_mlp_backward(const float* packed, const float* params, const float* pts, int64_t npts, float* ws,
@@ -140,7 +147,9 @@ int dh_mlp_backward(const float* packed, const float* params, const float* pts, 
     if (rc) return rc;
     rc = dh_sdf_backward(packed, d_sdf, npts, ws, stream);
     if (rc) return rc;
-    return dh_weight_grads(packed, params, npts, ws, grad_flat, stream);
+    rc = dh_weight_grads_gemm(npts, ws, stream);
+    if (rc) return rc;
+    return dh_weight_grads_fold(packed, params, npts, ws, grad_flat, stream);
 }
 
 int dh_gen_rays(const uint8_t* rgb, const int8_t* label, const uint8_t* normal, const float* R, const float* T,

@@ -347,13 +347,8 @@ static int64_t dw_gstride() {
 }
 int64_t dw_slab_floats(int G) { return (int64_t)(G + 1) * dw_gstride(); }
 
-int launch_weight_grads(const Workspace& w, float* slabs, float* tred, int G, int nS, const float* params,
-                        const float* packed, float* grad, hipStream_t st) {
+static void build_dw_jobs(const Workspace& w, float* red, DwJobs& J, SlabPtrs& S) {
     const int64_t nt = w.ntiles;
-    const int64_t gstride = dw_gstride();
-    float* red = slabs + (int64_t)G * gstride;
-    DwJobs J{};
-    SlabPtrs S{};
     int64_t off = 0;
     for (int j = 0; j < 15; ++j) { J.j[j].nb = DW_NBS[j]; J.j[j].off = off; S.out[j] = red + off; S.nb[j] = DW_NBS[j]; off += (int64_t)8 * DW_NBS[j] * 1024; }
     J.n = 15;
@@ -370,11 +365,30 @@ int launch_weight_grads(const Workspace& w, float* slabs, float* tred, int G, in
     for (int l = 1; l <= 3; ++l) {
         J.j[11 + l].A1 = T_(w.czbar, l); J.j[11 + l].B1 = T_(w.cact, l - 1); J.j[11 + l].A2 = nullptr; J.j[11 + l].B2 = nullptr;
     }
+}
+
+// stage 1: the split-K weight-gradient GEMMs (one kernel)
+int launch_weight_grads_gemm(const Workspace& w, float* slabs, int G, hipStream_t st) {
+    const int64_t gstride = dw_gstride();
+    DwJobs J{};
+    SlabPtrs S{};
+    build_dw_jobs(w, slabs + (int64_t)G * gstride, J, S);
     static const bool use_regs = getenv("DH_DW_REGS") != nullptr;     // A/B switch: register-streamed variant
-    if (use_regs) hipLaunchKernelGGL(dw_kernel, dim3(G), dim3(512), 0, st, J, nt, slabs, gstride, (int64_t)-1);
-    else hipLaunchKernelGGL(dw_lds_kernel, dim3(G), dim3(512), 0, st, J, nt, slabs, gstride);
+    if (use_regs) hipLaunchKernelGGL(dw_kernel, dim3(G), dim3(512), 0, st, J, w.ntiles, slabs, gstride, (int64_t)-1);
+    else hipLaunchKernelGGL(dw_lds_kernel, dim3(G), dim3(512), 0, st, J, w.ntiles, slabs, gstride);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+// stage 2: slab + tile-partial reductions, weight-norm fold into the flat gradient
+int launch_weight_grads_fold(const Workspace& w, float* slabs, float* tred, int G, int nS, const float* params,
+                             const float* packed, float* grad, hipStream_t st) {
+    const int64_t gstride = dw_gstride();
+    float* red = slabs + (int64_t)G * gstride;
+    DwJobs J{};
+    SlabPtrs S{};
+    build_dw_jobs(w, red, J, S);
     hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((gstride / 4 + 255) / 256)), dim3(256), 0, st, slabs, gstride, G, red);
-    hipLaunchKernelGGL(tpart_reduce_kernel, dim3(N_TILE_PART, nS), dim3(256), 0, st, w.tpart, nt, tred);
+    hipLaunchKernelGGL(tpart_reduce_kernel, dim3(N_TILE_PART, nS), dim3(256), 0, st, w.tpart, w.ntiles, tred);
     static const FoldTable T = build_fold_table();
     hipLaunchKernelGGL(fold_kernel, dim3(T.total_rows), dim3(256), 0, st, T, S, tred, nS, params, packed, grad);
     return hipGetLastError() == hipSuccess ? 0 : -3;

@@ -52,8 +52,9 @@ int launch_sdf_tangent(const float* packed, const float* pts, const float* d_nor
 int launch_sdf_bwd(const float* packed, const float* d_sdf, int64_t npts, const float* act, const float* rsave,
                    const float* featbar, float* zbar, float* tpart, int grid, hipStream_t st);
 struct Workspace;
-int launch_weight_grads(const Workspace& w, float* slabs, float* tred, int G, int nS, const float* params,
-                        const float* packed, float* grad, hipStream_t st);
+int launch_weight_grads_gemm(const Workspace& w, float* slabs, int G, hipStream_t st);
+int launch_weight_grads_fold(const Workspace& w, float* slabs, float* tred, int G, int nS, const float* params,
+                             const float* packed, float* grad, hipStream_t st);
 
 int launch_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2, float eps,
                 int64_t step, float grad_scale, hipStream_t st);

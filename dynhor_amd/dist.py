@@ -1,0 +1,30 @@
+"""Data-parallel plumbing: one process per GPU, one all-reduce of the flat fp32 gradient per iteration
+(torch.distributed backend "nccl" == RCCL over xGMI on ROCm; "gloo" in the CPU tests).  No other collective exists
+on this path: rays, frames and activations never leave their rank."""
+import torch
+import torch.distributed as dist
+
+
+def world_info():
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def allreduce_sum_(flat_grad: torch.Tensor) -> torch.Tensor:
+    """In-place SUM all-reduce of the 802,491-float gradient bucket; the 1/world mean is folded into the fused Adam
+    (dh_adam_step grad_scale) so no extra pass over the bucket is needed."""
+    _, world = world_info()
+    if world > 1:
+        dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM)
+    return flat_grad
+
+
+def mean_stats(stats: torch.Tensor) -> torch.Tensor:
+    """Average the 8 logged scalars over ranks (report iterations only)."""
+    _, world = world_info()
+    s = stats.clone()
+    if world > 1:
+        dist.all_reduce(s, op=dist.ReduceOp.SUM)
+        s /= world
+    return s

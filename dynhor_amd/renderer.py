@@ -239,7 +239,8 @@ class NeuSRenderer:
           _lib.stream())
         T("sdf_tangent", L.dh_sdf_tangent, _p(st.packed), _p(s.pts), _p(d_normals), P, _p(s.ws), _lib.stream())
         T("sdf_backward", L.dh_sdf_backward, _p(st.packed), _p(d_sdf), P, _p(s.ws), _lib.stream())
-        T("weight_grads", L.dh_weight_grads, _p(st.packed), _p(st.flat), P, _p(s.ws), _p(grad), _lib.stream())
+        T("weight_grads_gemm", L.dh_weight_grads_gemm, P, _p(s.ws), _lib.stream())
+        T("weight_grads_fold", L.dh_weight_grads_fold, _p(st.packed), _p(st.flat), P, _p(s.ws), _p(grad), _lib.stream())
         # variance: inv_s = clip(exp(10 v), 1e-6, 1e6)
         raw = torch.exp(st.flat[st.var_off] * 10.0)
         passthrough = ((raw >= 1e-6) & (raw <= 1e6)).float()

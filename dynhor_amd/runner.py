@@ -18,6 +18,8 @@ import torch
 import torch.distributed as dist
 import yaml
 
+from . import dist as dh_dist
+from . import schedules
 from .dataset import Dataset
 from .fields import ParamStore, RenderingNetwork, SDFNetwork, SingleVarianceNetwork
 from .renderer import NeuSRenderer
@@ -104,18 +106,11 @@ class Runner:
         return torch.randperm(self.dataset.n_images, generator=self.perm_gen)
 
     def get_cos_anneal_ratio(self):
-        if self.anneal_end == 0.0:
-            return 1.0
-        return float(np.min([1.0, self.iter_step / self.anneal_end]))
+        return schedules.cos_anneal_ratio(self.iter_step, self.anneal_end)
 
     def current_lr(self):
-        if self.iter_step < self.warm_up_end:
-            factor = self.iter_step / self.warm_up_end
-        else:
-            alpha = self.learning_rate_alpha
-            progress = (self.iter_step - self.warm_up_end) / (self.end_iter - self.warm_up_end)
-            factor = (math.cos(math.pi * progress) + 1.0) * 0.5 * (1 - alpha) + alpha
-        return self.learning_rate * factor
+        return self.learning_rate * schedules.lr_factor(self.iter_step, self.warm_up_end, self.end_iter,
+                                                        self.learning_rate_alpha)
 
     def update_learning_rate(self):
         self.lr = self.current_lr()
@@ -124,7 +119,7 @@ class Runner:
     # ------------------------------------------------------------------ one iteration (the hot loop)
     def train_iteration(self):
         n = self.dataset.n_images
-        slot = self.iter_step * self.world + self.rank
+        slot = schedules.frame_slot(self.iter_step, self.rank, self.world)
         if self.world == 1 and slot % n == 0 and slot > 0:
             self.image_perm = self.get_image_perm()
         frame = int(self.image_perm[slot % n])
@@ -134,8 +129,7 @@ class Runner:
         stats = self.renderer.train_step_core(rays, near, far, self.dataset.R[frame], self.get_cos_anneal_ratio(),
                                               self.igr_weight, self.mask_weight, self.normal_weight, background_rgb=bg)
         grad = self.store.grad_flat
-        if self.world > 1:
-            dist.all_reduce(grad, op=dist.ReduceOp.SUM)          # RCCL over xGMI: one 3.2 MB bucket
+        dh_dist.allreduce_sum_(grad)                             # RCCL over xGMI: one 3.2 MB bucket
         lr = self.current_lr() if self.iter_step > 0 else self.learning_rate / max(self.warm_up_end, 1)
         self.store.adam_step(lr, grad=grad, grad_scale=1.0 / self.world)
         self.iter_step += 1
@@ -154,11 +148,7 @@ class Runner:
         return self
 
     def report(self, stats):
-        s = stats.clone()
-        if self.world > 1:
-            dist.all_reduce(s, op=dist.ReduceOp.SUM)
-            s /= self.world
-        v = s.tolist()
+        v = dh_dist.mean_stats(stats).tolist()
         rec = {"iter": self.iter_step, "Loss/loss": v[0], "Loss/color_loss": v[1], "Loss/eikonal_loss": v[2],
                "Loss/mask_loss": v[3], "Loss/normal_loss": v[4], "Statistics/psnr": v[5],
                "Statistics/s_val": float(1.0 / self.store.inv_s().item()), "lr": self.current_lr()}

@@ -1,0 +1,24 @@
+"""Pure host-side schedules of the training loop (upstream Runner) and the data-parallel frame
+assignment.  No device code here."""
+import math
+
+
+def lr_factor(iter_step: int, warm_up_end: int, end_iter: int, alpha: float) -> float:
+    """Linear warm-up then cosine decay to alpha (upstream update_learning_rate)."""
+    if iter_step < warm_up_end:
+        return iter_step / warm_up_end
+    progress = (iter_step - warm_up_end) / (end_iter - warm_up_end)
+    return (math.cos(math.pi * progress) + 1.0) * 0.5 * (1 - alpha) + alpha
+
+
+def cos_anneal_ratio(iter_step: int, anneal_end: float) -> float:
+    """min(1, iter/anneal_end); 1 if anneal_end == 0 (upstream get_cos_anneal_ratio)."""
+    if anneal_end == 0.0:
+        return 1.0
+    return min(1.0, iter_step / anneal_end)
+
+
+def frame_slot(iter_step: int, rank: int, world: int) -> int:
+    """Index into the shared frame permutation used by `rank` at `iter_step`: ranks take consecutive slots, so one
+    iteration covers `world` distinct frames and the ranks never exchange rays (only the gradient)."""
+    return iter_step * world + rank

@@ -75,12 +75,13 @@ int dh_mlp_backward(const float* packed, const float* params, const float* pts, 
 
 /* The four stages of dh_mlp_backward as separate launches (same ws, in this order): colour-network backward
  * (adds its d/d normal into d_normals), the forward-mode tangent chain of the second-order path, the SDF backward
- * chain, and the weight-gradient GEMMs + reduction + weight-norm fold into grad_flat. */
+ * chain, the split-K weight-gradient GEMMs (one kernel), and their reduction + weight-norm fold into grad_flat. */
 int dh_color_backward(const float* packed, const float* colors, const float* d_colors, int64_t npts, float* ws,
                       float* d_normals, void* stream);
 int dh_sdf_tangent(const float* packed, const float* pts, const float* d_normals, int64_t npts, float* ws, void* stream);
 int dh_sdf_backward(const float* packed, const float* d_sdf, int64_t npts, float* ws, void* stream);
-int dh_weight_grads(const float* packed, const float* params, int64_t npts, float* ws, float* grad_flat, void* stream);
+int dh_weight_grads_gemm(int64_t npts, float* ws, void* stream);
+int dh_weight_grads_fold(const float* packed, const float* params, int64_t npts, float* ws, float* grad_flat, void* stream);
 
 /* ---- per-ray stages ---------------------------------------------------------------------------------------
  * Mask-conditioned ray generation = upstream Dataset.gen_random_rays_at + near_far_from_sphere (App. A.8) under the

@@ -1,0 +1,77 @@
+"""CPU: the C-ABI library builds, loads and exports every symbol include/dynhor_hip.h declares (no compute calls:
+there is no GPU here); the host-only entry points behave; the product path has no CPU fallback."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    src = open(os.path.join(ROOT, "include", "dynhor_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(dh_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_every_declared_symbol_is_exported_and_bound(hiplib):
+    from dynhor_amd import _lib
+    syms = _declared_symbols()
+    assert len(syms) >= 25
+    raw = ctypes.CDLL(_lib.LIB_PATH)
+    for s in syms:
+        assert hasattr(raw, s), f"{s} declared in include/dynhor_hip.h but not exported"
+        assert s in _lib.SIGNATURES, f"{s} has no ctypes signature in dynhor_amd/_lib.py"
+    assert sorted(_lib.SIGNATURES) == syms, "ctypes table and header must list the same entry points"
+
+
+def test_host_only_entry_points(hiplib):
+    from dynhor_amd import _lib
+    assert hiplib.dh_version() >= 1
+    assert hiplib.dh_num_params() == 802491
+    assert hiplib.dh_packed_floats() > 1_000_000
+    assert b"bad argument" in hiplib.dh_strerror(-1) and hiplib.dh_strerror(0) == b"ok"
+    # flat layout is dense and in state_dict order: sdf lin0..8 (bias, g, v), variance, colour lin0..4
+    end = 0
+    for net, n in ((0, 9), (1, 1), (2, 5)):
+        for l in range(n):
+            b, g, v, o, i = _lib.param_layout(net, l)
+            if net == 1:
+                assert v == end
+                end += 1
+                continue
+            assert (b, g, v) == (end, end + o, end + 2 * o)
+            end = v + o * i
+    assert end == 802491
+    assert _lib.param_layout(0, 3)[3:] == (217, 256) and _lib.param_layout(0, 8)[3:] == (257, 256)
+    assert _lib.param_layout(2, 0)[3:] == (256, 289)
+    with pytest.raises(_lib.DynhorHipError):
+        _lib.param_layout(0, 9)
+    fwd, tot = _lib.workspace_floats(128 * 2048)
+    assert 0 < fwd < tot
+    assert _lib.workspace_floats(0) == (0, _lib.workspace_floats(0)[1])
+
+
+def test_argument_validation_without_gpu(hiplib):
+    null = ctypes.c_void_p(0)
+    assert hiplib.dh_sdf_nograd(null, null, 0, null, null) == 0          # empty input is a no-op
+    assert hiplib.dh_sdf_nograd(null, null, 5, null, null) == -1         # null pointers
+    assert hiplib.dh_sdf_nograd(null, null, -1, null, null) == -1
+    assert hiplib.dh_upsample_step(null, null, null, null, 4, 200, 16, 64.0, null, null, null) == -2   # unsupported n
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from dynhor_amd import _lib
+    monkeypatch.setattr(_lib, "_LIB", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(_lib.DynhorHipError):
+        _lib.lib()
+
+
+def test_product_package_never_imports_the_oracle():
+    for dp, _, files in os.walk(os.path.join(ROOT, "dynhor_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dp, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f"{f} imports the oracle"
