@@ -120,7 +120,7 @@ __global__ __launch_bounds__(512, 2) void dw_kernel(DwJobs jobs, int64_t ntiles,
 // s_waitcnt vmcnt(2*(S-2)) + one raw s_barrier per k-quad orders RAW (all pieces landed) and WAR (stage i-1 fully
 // read before it is refilled).  ds_reads are inline asm: hipcc would otherwise drain vmcnt(0) before LDS reads
 // while a DMA is in flight.
-constexpr int DW_STAGES = 4;
+constexpr int DW_STAGES = 6;
 constexpr int DW_STAGE_BYTES = 16384;
 
 __device__ __forceinline__ f32x4 lds_read_b128(unsigned addr) {
@@ -164,28 +164,55 @@ __device__ __forceinline__ void dw_body_lds(const DwJob& J, int64_t t0, int64_t 
                                          (__attribute__((address_space(3))) void*)lb, 16, 0, 0);
     };
 
+    // Operand registers are double-buffered: unit i+1 is read from LDS (latency hidden) while unit i's MFMAs issue.
+    // total is a multiple of KQ (even), so the two register sets alternate statically.
+    auto read_ops = [&](DwOperands<NB>& o, int u) {
+        const unsigned sb = lds_base + (unsigned)(u % S) * DW_STAGE_BYTES + (unsigned)lane * 16;
+        DH_UNROLL for (int ii = 0; ii < NA; ++ii) {
+            const int ot = (NB == 8) ? ((wave >> 1) * 2 + ii) : wave;
+            o.a[ii] = lds_read_b128(sb + ot * 1024);
+        }
+        DH_UNROLL for (int j = 0; j < NBW; ++j) {
+            const int nt = (NB == 8) ? ((wave & 1) * 4 + j) : j;
+            o.b[j] = lds_read_b128(sb + 8192 + nt * 1024);
+        }
+    };
+    // wait until unit u's two DMAs (this wave's) have landed: later-issued units may stay in flight
+    auto wait_unit = [&](int u, int issued_upto) {          // issued_upto = index of the youngest issued unit
+        const int later = issued_upto - u;
+        if (later >= S - 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (S - 2)) : "memory");
+        else if (later == 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else if (later == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else if (later == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
     if (total > 0) {
-        for (int u = 0; u < S - 1 && u < total; ++u) issue(u);
-        for (int i = 0; i < total; ++i) {
-            const int after = total - 1 - i;                       // units issued after unit i (capped at S-2)
-            if (after >= S - 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (S - 2)) : "memory");
-            else if (after == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        int issued = -1;
+        for (int u = 0; u < S - 1 && u < total; ++u) { issue(u); issued = u; }
+        DwOperands<NB> o0, o1;
+        wait_unit(0, issued);
+        asm volatile("s_barrier" ::: "memory");
+        read_ops(o0, 0);
+        for (int i = 0; i < total; i += 2) {
+            // ---- even unit i (operands o0); look-ahead read of unit i+1 into o1
+            wait_unit(i + 1, issued);
             asm volatile("s_barrier" ::: "memory");
-            if (i + S - 1 < total) issue(i + S - 1);
-            const unsigned sb = lds_base + (unsigned)(i % S) * DW_STAGE_BYTES + (unsigned)lane * 16;
-            DwOperands<NB> o;
-            DH_UNROLL for (int ii = 0; ii < NA; ++ii) {
-                const int ot = (NB == 8) ? ((wave >> 1) * 2 + ii) : wave;
-                o.a[ii] = lds_read_b128(sb + ot * 1024);
-            }
-            DH_UNROLL for (int j = 0; j < NBW; ++j) {
-                const int nt = (NB == 8) ? ((wave & 1) * 4 + j) : j;
-                o.b[j] = lds_read_b128(sb + 8192 + nt * 1024);
-            }
+            if (issued + 1 < total) { issue(issued + 1); ++issued; }
+            read_ops(o1, i + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            dw_mfma<NB>(acc, o0);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
-            dw_mfma<NB>(acc, o);
+            // ---- odd unit i+1 (operands o1); look-ahead read of unit i+2 into o0
+            if (i + 2 < total) {
+                wait_unit(i + 2, issued);
+                asm volatile("s_barrier" ::: "memory");
+                if (issued + 1 < total) { issue(issued + 1); ++issued; }
+                read_ops(o0, i + 2);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            dw_mfma<NB>(acc, o1);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
         }
     }
