@@ -65,15 +65,23 @@ def main():
     ap.add_argument("--frames", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-rays", type=int, default=512)
+    ap.add_argument("--backend", type=str, default="nccl", help="torch.distributed backend (nccl == RCCL; gloo for tests)")
+    ap.add_argument("--share-gpu", action="store_true", help="TEST ONLY: every rank uses cuda:0 (with --backend gloo)")
+    ap.add_argument("--check-sync", action="store_true", help="verify all ranks hold identical parameters at the end")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.share_gpu:
+        local_rank = 0
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        else:
+            dist.init_process_group(args.backend)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
     device = torch.device(f"cuda:{local_rank}")
     torch.cuda.set_device(device)
@@ -109,6 +117,18 @@ def main():
         dt = float(t.item())
     runner.renderer.timer.enabled = False
     kern = runner.renderer.timer.summary()
+    if args.check_sync and world > 1:
+        ref = runner.store.flat.clone()
+        dist.broadcast(ref, src=0)
+        assert torch.equal(ref, runner.store.flat), f"rank {rank}: parameters diverged from rank 0"
+        frames = torch.tensor([float(runner.image_perm[(i * world + rank) % runner.dataset.n_images]) for i in range(4)],
+                              device=device)
+        allf = [torch.empty_like(frames) for _ in range(world)]
+        dist.all_gather(allf, frames)
+        flat = torch.stack(allf).reshape(-1).tolist()
+        assert len(set(flat)) == len(flat), "ranks must draw disjoint frames"
+        if rank == 0:
+            print("check-sync ok: identical parameters on all ranks, disjoint frames", flush=True)
 
     if rank == 0:
         ms = dt / args.steps * 1e3

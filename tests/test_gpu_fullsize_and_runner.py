@@ -73,3 +73,21 @@ def test_training_reduces_loss_and_checkpoint_roundtrip(runner):
     assert psnr == psnr and psnr > 0          # finite
     u, crossings = runner.validate_mesh(resolution=32)
     assert u.shape == (32, 32, 32) and crossings > 0, "the geometric-init sphere must cross the grid"
+
+
+def test_two_rank_data_parallel_on_one_gpu():
+    """Whole DP flow (frame sharding, flat-gradient all-reduce, identical Adam step) with 2 processes sharing cuda:0 over
+    gloo -- the same code path the 8-GPU RCCL run takes, minus the transport."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29533", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--frames", "8", "--backend", "gloo", "--share-gpu", "--check-sync", "--no-cpu-baseline"]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    assert "check-sync ok" in p.stdout
+    import json
+    line = [l for l in p.stdout.splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["config"]["parallelism"] == "dp2" and out["value"] > 0
