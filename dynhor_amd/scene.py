@@ -116,3 +116,28 @@ def make_sequence(n_frames=64, H=512, W=512, seed=4321, device="cpu", hand=True,
         label[fi] = lab.reshape(H, W)
         normal[fi] = nu8.to(torch.uint8).reshape(H, W, 3)
     return {"rgb": rgb, "label": label, "normal": normal, "R": R.to(dev), "T": T.to(dev), "K": K.to(dev)}
+
+
+def write_sequence_to_disk(frames: dict, dataroot: str, pose_dir: str | None = None, ext: str = "png"):
+    """Write a sequence in the reference's data convention (README.md:27-45; ObjTracker/run.py:74-88,165-179):
+    <dataroot>/rgb/%04d.<ext>, sam_seg/%04d.png (channel 1 == 255 object, last channel == 255 hand),
+    monocular_normal/%04d.png, and <pose_dir>/%04d.npz with R[3,3], T[1,3], K[3,3]."""
+    import os
+    import numpy as np
+    from PIL import Image
+    pose_dir = pose_dir or os.path.join(dataroot, "obj_infos")
+    for sub in ("rgb", "sam_seg", "monocular_normal"):
+        os.makedirs(os.path.join(dataroot, sub), exist_ok=True)
+    os.makedirs(pose_dir, exist_ok=True)
+    rgb = frames["rgb"].cpu().numpy(); lab = frames["label"].cpu().numpy(); nrm = frames["normal"].cpu().numpy()
+    R = frames["R"].cpu().numpy(); T = frames["T"].cpu().numpy(); K = frames["K"].cpu().numpy()
+    for i in range(rgb.shape[0]):
+        stem = "%04d" % i
+        Image.fromarray(rgb[i]).save(os.path.join(dataroot, "rgb", stem + "." + ext))
+        m = np.zeros(rgb[i].shape, np.uint8)
+        m[..., 1][lab[i] == 1] = 255
+        m[..., 2][lab[i] == -1] = 255
+        Image.fromarray(m).save(os.path.join(dataroot, "sam_seg", stem + ".png"))
+        Image.fromarray(nrm[i]).save(os.path.join(dataroot, "monocular_normal", stem + ".png"))
+        np.savez(os.path.join(pose_dir, stem + ".npz"), R=R[i].astype(np.float32), T=T[i].reshape(1, 3).astype(np.float32),
+                 K=K.astype(np.float32))

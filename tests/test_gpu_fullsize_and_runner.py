@@ -71,8 +71,10 @@ def test_training_reduces_loss_and_checkpoint_roundtrip(runner):
     assert runner.iter_step == ck["iter_step"]
     psnr = runner.validate_image(idx=0, resolution_level=4)
     assert psnr == psnr and psnr > 0          # finite
-    u, crossings = runner.validate_mesh(resolution=32)
-    assert u.shape == (32, 32, 32) and crossings > 0, "the geometric-init sphere must cross the grid"
+    verts, faces = runner.validate_mesh(resolution=48)
+    assert verts.shape[0] > 100 and faces.shape[0] > 200 and faces.max().item() < verts.shape[0]
+    assert os.path.exists(os.path.join(runner.base_exp_dir, "meshes", "{:0>8d}.ply".format(runner.iter_step)))
+    assert verts.abs().max().item() <= 1.011, "surface must lie inside the object bounding box"
 
 
 def test_two_rank_data_parallel_on_one_gpu():
@@ -91,3 +93,22 @@ def test_two_rank_data_parallel_on_one_gpu():
     line = [l for l in p.stdout.splitlines() if l.startswith("{")][-1]
     out = json.loads(line)
     assert out["n_gpus"] == 2 and out["config"]["parallelism"] == "dp2" and out["value"] > 0
+
+
+def test_on_disk_dataset_in_reference_layout_roundtrips(tmp_path):
+    """Stage-1 -> stage-2 hand-off: frames written in the reference's directory/mask/pose convention
+    load back bit-identically and generate the same rays."""
+    from dynhor_amd.dataset import Dataset
+    from dynhor_amd.scene import make_sequence, write_sequence_to_disk
+    frames = make_sequence(n_frames=3, H=48, W=64, seed=3, device="cpu")
+    root = str(tmp_path / "custom_seq")
+    pose_dir = str(tmp_path / "exps" / "custom_seq" / "pred" / "obj_infos")
+    write_sequence_to_disk(frames, root, pose_dir)
+    ds_disk = Dataset({"dataroot": root, "obj_infos": pose_dir}, device="cuda:0")
+    ds_mem = Dataset(frames=frames, device="cuda:0")
+    assert ds_disk.n_images == 3 and (ds_disk.H, ds_disk.W) == (48, 64)
+    assert torch.equal(ds_disk.rgb, ds_mem.rgb) and torch.equal(ds_disk.label, ds_mem.label)
+    assert torch.equal(ds_disk.normal, ds_mem.normal)
+    assert torch.allclose(ds_disk.R, ds_mem.R) and torch.allclose(ds_disk.T, ds_mem.T) and torch.allclose(ds_disk.K, ds_mem.K)
+    px = torch.tensor([0, 5, 63, 17], device="cuda:0"); py = torch.tensor([0, 47, 20, 9], device="cuda:0")
+    assert torch.equal(ds_disk.gen_rays_at_pixels(1, px, py), ds_mem.gen_rays_at_pixels(1, px, py))
