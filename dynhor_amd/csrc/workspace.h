@@ -7,7 +7,7 @@ namespace dh {
 
 constexpr int N_TILE_PART = 20;
 constexpr int DW_G = 256;         // split-K factor of the weight-gradient GEMMs = one persistent workgroup per CU
-constexpr int DW_NS = 16;         // split factor of the tile-partial reduction
+constexpr int DW_NS = 64;         // split factor of the tile-partial reduction
 int64_t dw_slab_floats(int G);   // per-tile partial-sum slots of 256 floats (bias grads, lin8 row 0, colour lin4)
 
 struct Workspace {
