@@ -1,0 +1,90 @@
+"""GPU: edge cases of the per-ray / MLP entry points -- empty and ragged batches, rays that miss the object, extreme
+sample counts, degenerate masks.  Checked against the oracle where it is defined, else against invariants."""
+import pytest
+import torch
+
+from oracle import neus_oracle as O
+from tests.test_gpu_render_forward import make_pair, make_rays
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("B", [1, 2, 3, 63, 65])
+def test_ragged_batches_match_oracle(B):
+    o_r, p_r = make_pair(seed=9, n_samples=64, n_importance=64)
+    o, d, near, far, t_rand = make_rays(B, seed=700 + B)
+    z = o_r.sample_z(o, d, near, far, t_rand=t_rand)
+    ref = o_r.render(o, d, near, far, cos_anneal_ratio=0.6, z_vals=z)
+    with torch.no_grad():
+        got = p_r.render(o, d, near, far, cos_anneal_ratio=0.6, z_vals=z)
+    for k in ("color_fine", "weight_sum", "weights", "gradient_error"):
+        assert (got[k] - ref[k].detach()).abs().max().item() < 3e-5, k
+    zs = p_r.sample_z(o, d, near, far, t_rand=t_rand)
+    assert zs.shape == (B, 128) and (zs[:, 1:] >= zs[:, :-1]).all()
+
+
+def test_rays_missing_the_object_and_background():
+    """Rays through empty space: weights ~ 0, colour = background, finite gradients."""
+    o_r, p_r = make_pair(seed=9, n_samples=64, n_importance=64)
+    B = 32
+    o = torch.tensor([[0.0, 0.0, -2.5]], device="cuda:0").repeat(B, 1)
+    d = torch.nn.functional.normalize(torch.tensor([[0.35, 0.0, 1.0]], device="cuda:0"), dim=-1).repeat(B, 1)   # misses r~0.5
+    near, far = O.near_far_from_sphere(o, d)
+    bg = torch.ones(1, 3, device="cuda:0")
+    out = p_r.render(o, d, near, far, background_rgb=bg, cos_anneal_ratio=1.0)
+    ref = o_r.render(o, d, near, far, background_rgb=bg, cos_anneal_ratio=1.0, z_vals=out["z_vals"])
+    assert (out["color_fine"] - ref["color_fine"].detach()).abs().max().item() < 3e-5
+    assert out["weight_sum"].max().item() < 0.2
+    (out["color_fine"].sum() + out["gradient_error"]).backward()
+    for p in p_r.store.params():
+        assert torch.isfinite(p.grad).all()
+
+
+@pytest.mark.parametrize("ns,ni", [(2, 0), (8, 8), (64, 0), (96, 32), (64, 64)])
+def test_sample_count_extremes(ns, ni):
+    o_r, p_r = make_pair(seed=9, n_samples=ns, n_importance=ni)
+    o, d, near, far, t_rand = make_rays(17, seed=ns * 100 + ni)
+    z_ref = o_r.sample_z(o, d, near, far, t_rand=t_rand)
+    z = p_r.sample_z(o, d, near, far, t_rand=t_rand)
+    assert z.shape == z_ref.shape == (17, ns + ni)
+    assert (z - z_ref).abs().median().item() < 1e-5
+    ref = o_r.render(o, d, near, far, cos_anneal_ratio=0.0, z_vals=z_ref)
+    with torch.no_grad():
+        got = p_r.render(o, d, near, far, cos_anneal_ratio=0.0, z_vals=z_ref)
+    assert (got["color_fine"] - ref["color_fine"].detach()).abs().max().item() < 3e-5
+
+
+def test_unsupported_configurations_fail_loudly():
+    from dynhor_amd.fields import RenderingNetwork, SDFNetwork, SingleVarianceNetwork
+    from dynhor_amd.renderer import NeuSRenderer
+    with pytest.raises(ValueError):
+        SDFNetwork(d_hidden=128)
+    with pytest.raises(ValueError):
+        RenderingNetwork(mode="no_view_dir")
+    s, c, v = SDFNetwork(), RenderingNetwork(), SingleVarianceNetwork(0.3)
+    with pytest.raises(ValueError):
+        NeuSRenderer(None, s, v, c, 64, 64, 32, 4, 1.0)          # n_outside > 0
+    with pytest.raises(ValueError):
+        NeuSRenderer(None, s, v, c, 128, 64, 0, 4, 1.0)          # > 128 samples per ray
+    r = NeuSRenderer(None, s, v, c, 16, 16, 0, 4, 1.0, device="cuda:0")
+    with pytest.raises(TypeError):
+        r.render(torch.zeros(4, 3), torch.zeros(4, 3), torch.zeros(4, 1), torch.ones(4, 1))   # CPU tensors
+    with pytest.raises(ValueError):
+        r.render(torch.zeros(4, 2, device="cuda:0"), torch.zeros(4, 2, device="cuda:0"), None, None)
+
+
+def test_all_hand_or_all_background_masks_do_not_produce_nans(tmp_path):
+    """keep-mask gating (reference utils/losses.py:69-71): a batch made only of hand pixels contributes nothing but must
+    stay finite (the 1e-5 denominators)."""
+    o_r, p_r = make_pair(seed=9, n_samples=32, n_importance=32)
+    o, d, near, far, t_rand = make_rays(64, seed=5)
+    rays = torch.cat([o, d, torch.rand(64, 3, device="cuda:0"), torch.zeros(64, 1, device="cuda:0"),
+                      torch.zeros(64, 1, device="cuda:0"),                                     # keep = 0 everywhere (all hand)
+                      torch.nn.functional.normalize(torch.randn(64, 3, device="cuda:0"), dim=-1)], dim=-1).contiguous()
+    stats = p_r.train_step_core(rays, near, far, torch.eye(3, device="cuda:0"), 0.5, 0.1, 0.1, 0.05, t_rand=t_rand)
+    finite = torch.isfinite(stats)
+    assert finite[[0, 1, 2, 3, 4, 6, 7]].all() and torch.isfinite(p_r.store.grad_flat).all()
+    assert stats[5].item() == float("inf"), "psnr statistic of an empty mask is +inf, exactly as upstream's formula gives"
+    assert stats[1].item() == 0.0 and stats[3].item() == 0.0, "colour and mask losses are fully gated by keep = 0"
+    # eikonal is not mask-gated (App. A.8): it alone drives the gradient
+    assert p_r.store.grad_flat.abs().sum().item() > 0
