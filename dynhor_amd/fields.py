@@ -9,7 +9,6 @@ touch a single contiguous buffer.
 """
 from __future__ import annotations
 
-import math
 
 import numpy as np
 import torch

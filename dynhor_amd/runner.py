@@ -9,7 +9,6 @@ iteration, then every rank applies the same fused Adam step.
 from __future__ import annotations
 
 import json
-import math
 import os
 import shutil
 

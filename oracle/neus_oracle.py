@@ -9,9 +9,8 @@ Device-agnostic, dtype-agnostic (fp32 for the CPU baseline, fp64 for tight check
 from __future__ import annotations
 
 import math
-from typing import Dict, Optional
+from typing import Dict
 
-import numpy as np
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
