@@ -115,3 +115,33 @@ def test_on_disk_dataset_in_reference_layout_roundtrips(tmp_path):
     assert torch.allclose(ds_disk.R, ds_mem.R) and torch.allclose(ds_disk.T, ds_mem.T) and torch.allclose(ds_disk.K, ds_mem.K)
     px = torch.tensor([0, 5, 63, 17], device="cuda:0"); py = torch.tensor([0, 47, 20, 9], device="cuda:0")
     assert torch.equal(ds_disk.gen_rays_at_pixels(1, px, py), ds_mem.gen_rays_at_pixels(1, px, py))
+
+
+def test_fullsize_parity_against_gpu_eager_oracle():
+    """BASELINE cfg2 size (2048 rays x 64+64 samples = 262,144 fine points): loss terms and the whole flat gradient
+    against the oracle run in GPU-eager fp32 on the same rays and the same z (the fp64 oracle needs ~50 GB here)."""
+    from oracle import neus_oracle as O
+    from tests.test_gpu_render_forward import make_pair, make_rays
+    o_r, p_r = make_pair(seed=77, jitter=0.05, n_samples=64, n_importance=64)
+    B = 2048
+    o, d, near, far, t_rand = make_rays(B, seed=2048)
+    g = torch.Generator(device="cpu").manual_seed(1)
+    rays = torch.cat([o, d, torch.rand(B, 3, generator=g).cuda(), (torch.rand(B, 1, generator=g) > 0.4).float().cuda(),
+                      (torch.rand(B, 1, generator=g) > 0.2).float().cuda(),
+                      torch.nn.functional.normalize(torch.randn(B, 3, generator=g), dim=-1).cuda()], dim=-1).contiguous()
+    R = torch.linalg.qr(torch.randn(3, 3, generator=g))[0].cuda()
+    z = p_r.sample_z(o, d, near, far, t_rand=t_rand)
+    p_r.sample_z = lambda *a, **k: z
+    stats = p_r.train_step_core(rays, near, far, R, 0.4, 0.1, 0.1, 0.05)
+    got = p_r.store.grad_flat.double()
+    mods = (o_r.sdf_network, o_r.deviation_network, o_r.color_network)
+    out = o_r.render(o, d, near, far, cos_anneal_ratio=0.4, z_vals=z)
+    ref = O.neus_losses(out, rays[:, 6:9], rays[:, 9:10], rays[:, 10:11], 0.1, 0.1, 0.05, rays[:, 11:14], R)
+    ref["loss"].backward()
+    gref = torch.cat([p.grad.reshape(-1) for m in mods for p in m.parameters()]).double()
+    for i, k in enumerate(["loss", "color_loss", "eikonal_loss", "mask_loss", "normal_loss"]):
+        assert abs(stats[i].item() - ref[k].item()) < 5e-5 * max(1.0, abs(ref[k].item())), k
+    rel = (got - gref).norm().item() / gref.norm().item()
+    print("full-size flat gradient rel err vs GPU-eager fp32 oracle:", rel)
+    # both sides are fp32 here (sums over 262,144 points): stated tolerance 1e-3 relative L2
+    assert rel < 1e-3
