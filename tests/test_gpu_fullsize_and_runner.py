@@ -145,3 +145,38 @@ def test_fullsize_parity_against_gpu_eager_oracle():
     print("full-size flat gradient rel err vs GPU-eager fp32 oracle:", rel)
     # both sides are fp32 here (sums over 262,144 points): stated tolerance 1e-3 relative L2
     assert rel < 1e-3
+
+
+def test_parity_holds_after_training(runner):
+    """Parity on TRAINED weights (sharper inv_s, saturated softplus units), not only near the geometric init: train the
+    HIP path a few hundred iterations, copy the weights into the oracle, compare a batch in fp64."""
+    from oracle import neus_oracle as O
+    for _ in range(300):
+        runner.train_iteration()
+    ds, p_r = runner.dataset, runner.renderer
+    o_sdf, o_col, o_var = O.build_models(seed=1, device="cuda:0")
+    o_sdf.load_state_dict(runner.sdf_network.state_dict()); o_col.load_state_dict(runner.color_network.state_dict())
+    o_var.load_state_dict(runner.deviation_network.state_dict())
+    o_r = O.NeuSRenderer(None, o_sdf.double(), o_var.double(), o_col.double(), 64, 64, 0, 4, 1.0)
+    g = torch.Generator(device="cuda:0"); g.manual_seed(99)
+    rays = ds.gen_random_rays_at(2, 192, generator=g)
+    near, far = ds._last_near_far
+    t_rand = torch.rand(192, 1, device="cuda:0", generator=g)
+    z = p_r.sample_z(rays[:, :3].contiguous(), rays[:, 3:6].contiguous(), near, far, t_rand=t_rand)
+    p_r.sample_z = lambda *a, **k: z
+    car = runner.get_cos_anneal_ratio()
+    try:
+        stats = p_r.train_step_core(rays, near, far, ds.R[2], car, 0.1, 0.1, 0.05)
+    finally:
+        del p_r.sample_z
+    got = p_r.store.grad_flat.double()
+    r64 = rays.double()
+    out = o_r.render(r64[:, :3], r64[:, 3:6], near.double(), far.double(), cos_anneal_ratio=car, z_vals=z.double())
+    ref = O.neus_losses(out, r64[:, 6:9], r64[:, 9:10], r64[:, 10:11], 0.1, 0.1, 0.05, r64[:, 11:14], ds.R[2].double())
+    ref["loss"].backward()
+    gref = torch.cat([p.grad.reshape(-1) for m in (o_sdf, o_var, o_col) for p in m.parameters()])
+    inv_s = float(torch.exp(runner.deviation_network.variance * 10))
+    rel = (got - gref).norm().item() / gref.norm().item()
+    print(f"after 340 iters: inv_s={inv_s:.1f} loss hip={stats[0].item():.6f} ref={ref['loss'].item():.6f} grad rel err={rel:.2e}")
+    assert abs(stats[0].item() - ref["loss"].item()) < 2e-5
+    assert rel < 2e-4
