@@ -124,6 +124,7 @@ class Runner:
         frame = int(self.image_perm[slot % n])
         rays = self.dataset.gen_random_rays_at(frame, self.batch_size, keep_only=self.keep_only, generator=self.ray_gen)
         near, far = self.dataset._last_near_far
+        self._last_rays = rays
         bg = torch.ones(3, device=self.device) if self.use_white_bkgd else None
         stats = self.renderer.train_step_core(rays, near, far, self.dataset.R[frame], self.get_cos_anneal_ratio(),
                                               self.igr_weight, self.mask_weight, self.normal_weight, background_rgb=bg)
@@ -151,6 +152,13 @@ class Runner:
         rec = {"iter": self.iter_step, "Loss/loss": v[0], "Loss/color_loss": v[1], "Loss/eikonal_loss": v[2],
                "Loss/mask_loss": v[3], "Loss/normal_loss": v[4], "Statistics/psnr": v[5],
                "Statistics/s_val": float(1.0 / self.store.inv_s().item()), "lr": self.current_lr()}
+        st = getattr(self.renderer, "last_state", None)
+        if st is not None and getattr(self, "_last_rays", None) is not None:
+            # upstream Statistics/cdf and Statistics/weight_max (App. A.8), masked by obj*keep like the colour loss
+            m = (self._last_rays[:, 9:10] * self._last_rays[:, 10:11])
+            msum = float(m.sum()) + 1e-5
+            rec["Statistics/cdf"] = float((st.cdf[:, :1] * m).sum()) / msum
+            rec["Statistics/weight_max"] = float((st.wmax * m).sum()) / msum
         if self.rank == 0:
             self.scalars.append(rec)
             with open(os.path.join(self.base_exp_dir, "scalars.jsonl"), "a") as f:
