@@ -141,33 +141,41 @@ __device__ __forceinline__ void dw_body_lds(const DwJob& J, int64_t t0, int64_t 
     const int T = (int)(t1 - t0);
     const int npairs = J.A2 ? 2 : 1;
     const int total = npairs * T * KQ;
+    (void)total;
     const unsigned lds_base = (unsigned)(uintptr_t)lds;     // LDS byte address of the ring
     // this wave's DMA pieces: A piece ot = wave ; B piece nt = wave (NB == 8) or wave & 1 (NB == 2; slots >= 2 are dummies)
     const int a_ot = wave, b_nt = (NB == 8) ? wave : (wave & 1);
 
-    auto issue = [&](int u) {
-        const int pair = u / (T * KQ);
-        const int rem = u - pair * T * KQ;
-        const int64_t tile = t0 + rem / KQ;
-        const int kq = rem % KQ, m = kq >> 2, r4 = kq & 3;
-        const float* A = pair ? J.A2 : J.A1;
-        const float* Bm = pair ? J.B2 : J.B1;
-        const int stage = u % S;
-        const f32x4* ga = reinterpret_cast<const f32x4*>(A + tile * TILE_F) + ((((a_ot >> 1) * MT + m) * 2 + (a_ot & 1)) * 4 + r4) * 64 + lane;
+    // issue-side cursor (pair, tile, kq) advanced incrementally: no division / modulo in the loop (the recomputing
+    // form cost ~100 SALU instructions per k-quad, 3 per MFMA)
+    int is_pair = 0, is_kq = 0, is_stage = 0;
+    int64_t is_tile = t0;
+    auto issue = [&](int /*u*/) {
+        const int m = is_kq >> 2, r4 = is_kq & 3;
+        const float* A = is_pair ? J.A2 : J.A1;
+        const float* Bm = is_pair ? J.B2 : J.B1;
+        const f32x4* ga = reinterpret_cast<const f32x4*>(A + is_tile * TILE_F) + ((((a_ot >> 1) * MT + m) * 2 + (a_ot & 1)) * 4 + r4) * 64 + lane;
         const int bi = (NB == 8) ? ((((b_nt >> 1) * MT + m) * 2 + (b_nt & 1)) * 4 + r4) : ((m * 2 + b_nt) * 4 + r4);
-        const f32x4* gb = reinterpret_cast<const f32x4*>(Bm + tile * BT) + bi * 64 + lane;
-        char* la = lds + stage * DW_STAGE_BYTES + wave * 1024;
-        char* lb = lds + stage * DW_STAGE_BYTES + 8192 + wave * 1024;
+        const f32x4* gb = reinterpret_cast<const f32x4*>(Bm + is_tile * BT) + bi * 64 + lane;
+        char* la = lds + is_stage * DW_STAGE_BYTES + wave * 1024;
+        char* lb = lds + is_stage * DW_STAGE_BYTES + 8192 + wave * 1024;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)ga,
                                          (__attribute__((address_space(3))) void*)la, 16, 0, 0);
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gb,
                                          (__attribute__((address_space(3))) void*)lb, 16, 0, 0);
+        if (++is_stage == S) is_stage = 0;
+        if (++is_kq == KQ) {
+            is_kq = 0;
+            if (++is_tile == t1) { is_tile = t0; ++is_pair; }
+        }
     };
 
     // Operand registers are double-buffered: unit i+1 is read from LDS (latency hidden) while unit i's MFMAs issue.
     // total is a multiple of KQ (even), so the two register sets alternate statically.
-    auto read_ops = [&](DwOperands<NB>& o, int u) {
-        const unsigned sb = lds_base + (unsigned)(u % S) * DW_STAGE_BYTES + (unsigned)lane * 16;
+    int rd_stage = 0;
+    auto read_ops = [&](DwOperands<NB>& o, int /*u*/) {
+        const unsigned sb = lds_base + (unsigned)rd_stage * DW_STAGE_BYTES + (unsigned)lane * 16;
+        if (++rd_stage == S) rd_stage = 0;
         DH_UNROLL for (int ii = 0; ii < NA; ++ii) {
             const int ot = (NB == 8) ? ((wave >> 1) * 2 + ii) : wave;
             o.a[ii] = lds_read_b128(sb + ot * 1024);

@@ -20,10 +20,12 @@ __global__ __launch_bounds__(256, TM == 128 ? 1 : 2) void sdf_nograd_kernel(SdfP
         embed_tile(pts, tile * TM, npts, saux, tid);
         __syncthreads();
         f32x16 acc[MT][2];
+        BFrag pre = gemm_b_prefetch(P.fwd_main[1], wave, lane);
         for (int l = 0; l < 8; ++l) {
             acc_zero(acc);
-            if (l > 0) gemm_rows(acc, smain, LDX, l == 4 ? 28 : 32, P.fwd_main[l], wave, lane);
+            if (l > 0) gemm_rows(acc, smain, LDX, l == 4 ? 28 : 32, P.fwd_main[l], wave, lane, pre);
             if (l == 0 || l == 4) gemm_rows(acc, saux, LDA, 5, P.fwd_aux[l], wave, lane);
+            pre = gemm_b_prefetch(P.fwd_main[l + 1], wave, lane);      // next layer's first weights, ahead of the epilogue
             const float b0 = P.bias[l][acc_col(wave, 0, lane)], b1 = P.bias[l][acc_col(wave, 1, lane)];
             acc_map(acc, [&](int, int t, int, float v) { return softplus100(v + (t ? b1 : b0)); });
             __syncthreads();                 // every wave finished reading smain as the A operand
@@ -54,10 +56,12 @@ __global__ __launch_bounds__(256, TM == 128 ? 1 : 2) void sdf_fwd_train_kernel(S
         __syncthreads();
         aux_lds_to_native(saux, eaux + tile * AUXT_F, wave, lane);
         f32x16 acc[MT][2];
+        BFrag pre = gemm_b_prefetch(P.fwd_main[1], wave, lane);
         for (int l = 0; l < 8; ++l) {
             acc_zero(acc);
-            if (l > 0) gemm_rows(acc, smain, LDX, l == 4 ? 28 : 32, P.fwd_main[l], wave, lane);
+            if (l > 0) gemm_rows(acc, smain, LDX, l == 4 ? 28 : 32, P.fwd_main[l], wave, lane, pre);
             if (l == 0 || l == 4) gemm_rows(acc, saux, LDA, 5, P.fwd_aux[l], wave, lane);
+            pre = gemm_b_prefetch(P.fwd_main[l + 1], wave, lane);      // next layer's first weights, ahead of the epilogue
             const float b0 = P.bias[l][acc_col(wave, 0, lane)], b1 = P.bias[l][acc_col(wave, 1, lane)];
             acc_map(acc, [&](int, int t, int, float v) { return softplus100(v + (t ? b1 : b0)); });
             acc_store_native(acc, act + ((int64_t)l * ntiles + tile) * TILE_F, wave, lane);
@@ -69,7 +73,7 @@ __global__ __launch_bounds__(256, TM == 128 ? 1 : 2) void sdf_fwd_train_kernel(S
         const int64_t gp = tile * TM + tid / TPP;
         if (tid % TPP == 0 && gp < npts) sdf_out[gp] = s;
         acc_zero(acc);
-        gemm_rows(acc, smain, LDX, 32, P.fwd_main[8], wave, lane);
+        gemm_rows(acc, smain, LDX, 32, P.fwd_main[8], wave, lane, pre);
         const float b0 = P.bias[8][acc_col(wave, 0, lane)], b1 = P.bias[8][acc_col(wave, 1, lane)];
         acc_map(acc, [&](int, int t, int, float v) { return v + (t ? b1 : b0); });
         acc_store_native(acc, feat + tile * TILE_F, wave, lane);
@@ -103,9 +107,11 @@ __global__ __launch_bounds__(256, TM == 128 ? 1 : 2) void sdf_grad_kernel(SdfPtr
             acc_to_lds(acc, smain, wave, lane);
             __syncthreads();
         }
+        BFrag pre = gemm_b_prefetch(P.rev_main[7], wave, lane);
         for (int l = 7; l >= 1; --l) {
             acc_zero(acc);
-            gemm_rows(acc, smain, LDX, 32, P.rev_main[l], wave, lane);              // u_l = a_l W_l
+            gemm_rows(acc, smain, LDX, 32, P.rev_main[l], wave, lane, pre);         // u_l = a_l W_l
+            if (l > 1) pre = gemm_b_prefetch(P.rev_main[l - 1], wave, lane);
             if (l == 4) gemm_auxout(ge, smain, 32, P.rev_aux[4], wave, lane);       // skip path -> ge
             // a_{l-1} = u_l * sigma'(z_{l-1})   (sigma' from act[l-1] == input of layer l)
             const f32x4* hp = reinterpret_cast<const f32x4*>(act + ((int64_t)(l - 1) * ntiles + tile) * TILE_F) + (size_t)wave * MT * 8 * 64 + lane;
@@ -198,10 +204,12 @@ __global__ __launch_bounds__(256, TM == 128 ? 1 : 2) void color_fwd_kernel(ColPt
         acc_to_lds(acc, smain, wave, lane);
         __syncthreads();
         if (save) aux_lds_to_native(saux, caux + tile * AUXT_F, wave, lane);
+        BFrag pre = gemm_b_prefetch(C.fwd_main[0], wave, lane);
         for (int l = 0; l < 4; ++l) {
             acc_zero(acc);
-            gemm_rows(acc, smain, LDX, 32, C.fwd_main[l], wave, lane);
+            gemm_rows(acc, smain, LDX, 32, C.fwd_main[l], wave, lane, pre);
             if (l == 0) gemm_rows(acc, saux, LDA, 5, C.fwd_aux0, wave, lane);
+            if (l < 3) pre = gemm_b_prefetch(C.fwd_main[l + 1], wave, lane);
             const float b0 = C.bias[l][acc_col(wave, 0, lane)], b1 = C.bias[l][acc_col(wave, 1, lane)];
             acc_map(acc, [&](int, int t, int, float v) { return fmaxf(v + (t ? b1 : b0), 0.f); });
             if (save) acc_store_native(acc, cact + ((int64_t)l * ntiles + tile) * TILE_F, wave, lane);

@@ -76,9 +76,11 @@ __global__ __launch_bounds__(256, TM == 128 ? 1 : 2) void color_bwd_kernel(ColPt
         tile_colsum(acc, tp + (TP_COL_B0 + 3) * 256, wave, lane);
         acc_to_lds(acc, smain, wave, lane);
         __syncthreads();
+        BFrag pre = gemm_b_prefetch(C.rev_main[3], wave, lane);
         for (int l = 3; l >= 1; --l) {
             acc_zero(acc);
-            gemm_rows(acc, smain, LDX, 32, C.rev_main[l], wave, lane);                    // hbar_l = zbar_l W_l
+            gemm_rows(acc, smain, LDX, 32, C.rev_main[l], wave, lane, pre);               // hbar_l = zbar_l W_l
+            pre = gemm_b_prefetch(C.rev_main[l - 1], wave, lane);
             const f32x4* hp = reinterpret_cast<const f32x4*>(cact + ((int64_t)(l - 1) * ntiles + tile) * TILE_F) + (size_t)wave * MT * 8 * 64 + lane;
             DH_UNROLL for (int m = 0; m < MT; ++m) {
                 DH_UNROLL for (int t = 0; t < 2; ++t)
@@ -97,7 +99,7 @@ __global__ __launch_bounds__(256, TM == 128 ? 1 : 2) void color_bwd_kernel(ColPt
         }
         // lin0: featbar = zbar_0 W0[:,33:] ; extras adjoint = zbar_0 W0[:,:33] (only the normal columns 30..32 matter)
         acc_zero(acc);
-        gemm_rows(acc, smain, LDX, 32, C.rev_main[0], wave, lane);
+        gemm_rows(acc, smain, LDX, 32, C.rev_main[0], wave, lane, pre);
         acc_store_native(acc, featbar + tile * TILE_F, wave, lane);
         f32x16 a2[AUX_NTW];
         aux_zero(a2);
@@ -152,10 +154,12 @@ __global__ __launch_bounds__(256, TM == 128 ? 1 : 2) void sdf_tangent_kernel(Sdf
         __syncthreads();
         aux_lds_to_native(saux, t0aux + tile * AUXT_F, wave, lane);
         f32x16 acc[MT][2];
+        BFrag pre = gemm_b_prefetch(P.fwd_main[1], wave, lane);
         for (int l = 0; l < 8; ++l) {
             acc_zero(acc);
-            if (l > 0) gemm_rows(acc, smain, LDX, l == 4 ? 28 : 32, P.fwd_main[l], wave, lane);
+            if (l > 0) gemm_rows(acc, smain, LDX, l == 4 ? 28 : 32, P.fwd_main[l], wave, lane, pre);
             if (l == 0 || l == 4) gemm_rows(acc, saux, LDA, 5, P.fwd_aux[l], wave, lane);     // abar_l
+            if (l < 7) pre = gemm_b_prefetch(P.fwd_main[l + 1], wave, lane);
             const size_t woff = (size_t)wave * MT * 8 * 64 + lane;
             const f32x4* hp = reinterpret_cast<const f32x4*>(act + ((int64_t)l * ntiles + tile) * TILE_F) + woff;
             const f32x4* ap = reinterpret_cast<const f32x4*>(asave + ((int64_t)l * ntiles + tile) * TILE_F) + woff;
@@ -221,6 +225,7 @@ __global__ __launch_bounds__(256, TM == 128 ? 1 : 2) void sdf_bwd_kernel(SdfPtrs
         // hbar_8 = featbar W8[1:,:] + sdfbar (x) W8[0,:]
         acc_zero(acc);
         gemm_rows(acc, smain, LDX, 32, P.rev_main[8], wave, lane);
+        BFrag pre = gemm_b_prefetch(P.rev_main[7], wave, lane);
         DH_UNROLL for (int m = 0; m < MT; ++m)
             DH_UNROLL for (int r = 0; r < 16; ++r) {
                 const float sb = saux[acc_row(m, r, lane)];
@@ -262,7 +267,8 @@ __global__ __launch_bounds__(256, TM == 128 ? 1 : 2) void sdf_bwd_kernel(SdfPtrs
                 acc_to_lds(acc, smain, wave, lane);
                 __syncthreads();
                 acc_zero(acc);
-                gemm_rows(acc, smain, LDX, 32, P.rev_main[l], wave, lane);          // hbar_l = zbar_l W_l
+                gemm_rows(acc, smain, LDX, 32, P.rev_main[l], wave, lane, pre);     // hbar_l = zbar_l W_l
+                if (l > 1) pre = gemm_b_prefetch(P.rev_main[l - 1], wave, lane);
             }
         }
         __syncthreads();

@@ -40,12 +40,21 @@ __device__ __forceinline__ void mfma_block(f32x16 (&acc)[MT][2], const f32x4 (&a
             DH_UNROLL for (int t = 0; t < 2; ++t)
                 acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m][s], b[t][s], acc[m][t], 0, 0, 0);
 }
+// First B fragments (k-group 0) of a layer: they depend only on the weights, so a chain issues them BEFORE the previous
+// layer's epilogue + LDS hand-off barrier and their L2 latency is off the critical path of the next GEMM's first MFMAs.
+struct BFrag { f32x4 b[2]; };
+__device__ __forceinline__ BFrag gemm_b_prefetch(const f32x4* __restrict__ wp, const int wave, const int lane) {
+    BFrag f;
+    const f32x4* wl = wp + (2 * wave) * 64 + lane;
+    DH_UNROLL for (int t = 0; t < 2; ++t) f.b[t] = wl[t * 64];
+    return f;
+}
 __device__ __forceinline__ void gemm_rows(f32x16 (&acc)[MT][2], const float* xs, const int ldx, const int nkg,
-                                          const f32x4* __restrict__ wp, const int wave, const int lane) {
+                                          const f32x4* __restrict__ wp, const int wave, const int lane, const BFrag& pre) {
     const float* xrow = xs + (lane & 31) * ldx + 4 * (lane >> 5);
     const f32x4* wl = wp + (2 * wave) * 64 + lane;
     f32x4 a0[MT], b0[2], a1[MT], b1[2];
-    DH_UNROLL for (int t = 0; t < 2; ++t) b0[t] = wl[t * 64];
+    DH_UNROLL for (int t = 0; t < 2; ++t) b0[t] = pre.b[t];
     DH_UNROLL for (int m = 0; m < MT; ++m) a0[m] = *reinterpret_cast<const f32x4*>(xrow + m * 32 * ldx);
     // sched_barrier(0) pins "issue next operands, THEN the 8*MT MFMAs of the current ones": left alone, hipcc sinks
     // the loads to just ahead of their first use and every k-group eats the L2 latency.
@@ -65,6 +74,10 @@ __device__ __forceinline__ void gemm_rows(f32x16 (&acc)[MT][2], const float* xs,
             __builtin_amdgcn_sched_barrier(0);
         }
     }
+}
+__device__ __forceinline__ void gemm_rows(f32x16 (&acc)[MT][2], const float* xs, const int ldx, const int nkg,
+                                          const f32x4* __restrict__ wp, const int wave, const int lane) {
+    gemm_rows(acc, xs, ldx, nkg, wp, wave, lane, gemm_b_prefetch(wp, wave, lane));
 }
 
 // acc2[.] += X[rows of one m-tile][256] * Mpacked(NT=2)   (P2: 64-wide "aux" output).
