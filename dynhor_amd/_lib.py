@@ -20,11 +20,11 @@ SIGNATURES = {
                                ctypes.POINTER(_i32), ctypes.POINTER(_i32)]),
     "dh_pack_weights": (_i32, [_vp, _vp, _vp]),
     "dh_sdf_nograd": (_i32, [_vp, _vp, _i64, _vp, _vp]),
-    "dh_workspace_floats": (_i32, [_i64, ctypes.POINTER(_i64), ctypes.POINTER(_i64)]),
+    "dh_workspace_floats": (_i32, [_i64, ctypes.POINTER(_i64), ctypes.POINTER(_i64), ctypes.POINTER(_i64)]),
     "dh_mlp_forward": (_i32, [_vp, _vp, _vp, _i32, _i64, _vp, _vp, _vp, _vp, _vp]),
     "dh_sdf_forward": (_i32, [_vp, _vp, _i64, _vp, _vp, _vp]),
-    "dh_sdf_gradient": (_i32, [_vp, _vp, _i64, _vp, _vp, _vp]),
-    "dh_color_forward": (_i32, [_vp, _vp, _vp, _i32, _vp, _i64, _vp, _vp, _vp]),
+    "dh_sdf_gradient": (_i32, [_vp, _vp, _i64, _vp, _vp, _i32, _vp]),
+    "dh_color_forward": (_i32, [_vp, _vp, _vp, _i32, _vp, _i64, _vp, _vp, _i32, _vp]),
     "dh_color_backward": (_i32, [_vp, _vp, _vp, _i64, _vp, _vp, _vp]),
     "dh_sdf_tangent": (_i32, [_vp, _vp, _vp, _i64, _vp, _vp]),
     "dh_sdf_backward": (_i32, [_vp, _vp, _i64, _vp, _vp]),
@@ -86,6 +86,7 @@ def param_layout(net: int, layer: int):
 
 
 def workspace_floats(npts: int):
-    f, t = _i64(), _i64()
-    check(lib().dh_workspace_floats(npts, ctypes.byref(f), ctypes.byref(t)))
-    return f.value, t.value
+    """(forward-only, training-forward, total) workspace sizes in floats."""
+    i, f, t = _i64(), _i64(), _i64()
+    check(lib().dh_workspace_floats(npts, ctypes.byref(i), ctypes.byref(f), ctypes.byref(t)))
+    return i.value, f.value, t.value

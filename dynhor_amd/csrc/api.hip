@@ -58,9 +58,10 @@ int dh_sdf_nograd(const float* packed, const float* pts, int64_t npts, float* sd
     return launch_sdf_nograd(packed, pts, npts, sdf, DEFAULT_GRID, static_cast<hipStream_t>(stream));
 }
 
-int dh_workspace_floats(int64_t npts, int64_t* fwd_floats, int64_t* total_floats) {
-    if (npts < 0 || !fwd_floats || !total_floats) return DH_ERR_BAD_ARG;
+int dh_workspace_floats(int64_t npts, int64_t* infer_floats, int64_t* fwd_floats, int64_t* total_floats) {
+    if (npts < 0 || !infer_floats || !fwd_floats || !total_floats) return DH_ERR_BAD_ARG;
     const Workspace w = carve_workspace(nullptr, npts);
+    *infer_floats = w.infer_floats;
     *fwd_floats = w.fwd_floats;
     *total_floats = w.total_floats;
     return DH_OK;
@@ -73,20 +74,20 @@ int dh_sdf_forward(const float* packed, const float* pts, int64_t npts, float* w
     return launch_sdf_fwd_train(packed, pts, npts, sdf, w.feat, w.act, w.eaux, DEFAULT_GRID, static_cast<hipStream_t>(stream));
 }
 
-int dh_sdf_gradient(const float* packed, const float* pts, int64_t npts, float* ws, float* normals, void* stream) {
+int dh_sdf_gradient(const float* packed, const float* pts, int64_t npts, float* ws, float* normals, int save, void* stream) {
     if (npts <= 0) return npts == 0 ? DH_OK : DH_ERR_BAD_ARG;
     if (!packed || !pts || !ws || !normals || misaligned16(packed) || misaligned16(ws)) return DH_ERR_BAD_ARG;
     const Workspace w = carve_workspace(ws, npts);
-    return launch_sdf_grad(packed, pts, npts, w.act, w.asave, normals, DEFAULT_GRID, static_cast<hipStream_t>(stream));
+    return launch_sdf_grad(packed, pts, npts, w.act, w.asave, normals, save, DEFAULT_GRID, static_cast<hipStream_t>(stream));
 }
 
 int dh_color_forward(const float* packed, const float* pts, const float* dirs, int n_per_ray, const float* normals,
-                     int64_t npts, float* ws, float* color, void* stream) {
+                     int64_t npts, float* ws, float* color, int save, void* stream) {
     if (npts < 0 || n_per_ray <= 0) return DH_ERR_BAD_ARG;
     if (npts == 0) return DH_OK;
     if (!packed || !pts || !dirs || !normals || !ws || !color || misaligned16(packed) || misaligned16(ws)) return DH_ERR_BAD_ARG;
     const Workspace w = carve_workspace(ws, npts);
-    return launch_color_fwd(packed, pts, dirs, n_per_ray, normals, w.feat, npts, color, w.cact, w.caux, 1, DEFAULT_GRID,
+    return launch_color_fwd(packed, pts, dirs, n_per_ray, normals, w.feat, npts, color, w.cact, w.caux, save, DEFAULT_GRID,
                             static_cast<hipStream_t>(stream));
 }
 
@@ -94,9 +95,9 @@ int dh_mlp_forward(const float* packed, const float* pts, const float* dirs, int
                    float* sdf, float* normals, float* color, void* stream) {
     int rc = dh_sdf_forward(packed, pts, npts, ws, sdf, stream);
     if (rc) return rc;
-    rc = dh_sdf_gradient(packed, pts, npts, ws, normals, stream);
+    rc = dh_sdf_gradient(packed, pts, npts, ws, normals, 1, stream);
     if (rc) return rc;
-    return dh_color_forward(packed, pts, dirs, n_per_ray, normals, npts, ws, color, stream);
+    return dh_color_forward(packed, pts, dirs, n_per_ray, normals, npts, ws, color, 1, stream);
 }
 
 int dh_color_backward(const float* packed, const float* colors, const float* d_colors, int64_t npts, float* ws,

@@ -14,7 +14,7 @@ int launch_sdf_nograd(const float* packed, const float* pts, int64_t npts, float
 int launch_sdf_fwd_train(const float* packed, const float* pts, int64_t npts, float* sdf, float* feat, float* act,
                          float* eaux, int grid, hipStream_t stream);
 int launch_sdf_grad(const float* packed, const float* pts, int64_t npts, const float* act, float* asave, float* normals,
-                    int grid, hipStream_t stream);
+                    int save, int grid, hipStream_t stream);
 int launch_color_fwd(const float* packed, const float* pts, const float* dirs, int n_per_ray, const float* normals,
                      const float* feat, int64_t npts, float* color, float* cact, float* caux, int save, int grid,
                      hipStream_t stream);

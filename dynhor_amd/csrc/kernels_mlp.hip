@@ -89,7 +89,7 @@ __global__ __launch_bounds__(256, TM == 128 ? 1 : 2) void sdf_fwd_train_kernel(S
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256, TM == 128 ? 1 : 2) void sdf_grad_kernel(SdfPtrs P, const float* __restrict__ pts, int64_t npts,
                                                            const float* __restrict__ act, float* __restrict__ asave,
-                                                           float* __restrict__ normals) {
+                                                           float* __restrict__ normals, int save) {
     __shared__ __attribute__((aligned(16))) float smain[TM * LDX];
     __shared__ __attribute__((aligned(16))) float saux[TM * LDA];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -103,7 +103,7 @@ __global__ __launch_bounds__(256, TM == 128 ? 1 : 2) void sdf_grad_kernel(SdfPtr
             const float w0 = P.w8row0[acc_col(wave, 0, lane)], w1 = P.w8row0[acc_col(wave, 1, lane)];
             acc_load_native(acc, act + ((int64_t)7 * ntiles + tile) * TILE_F, wave, lane);
             acc_map(acc, [&](int, int t, int, float h) { float s, em; softplus_deriv_from_h(h, s, em); return (t ? w1 : w0) * s; });
-            acc_store_native(acc, asave + ((int64_t)7 * ntiles + tile) * TILE_F, wave, lane);
+            if (save) acc_store_native(acc, asave + ((int64_t)7 * ntiles + tile) * TILE_F, wave, lane);
             acc_to_lds(acc, smain, wave, lane);
             __syncthreads();
         }
@@ -126,7 +126,7 @@ __global__ __launch_bounds__(256, TM == 128 ? 1 : 2) void sdf_grad_kernel(SdfPtr
                     }
                 __builtin_amdgcn_sched_barrier(0);     // bound live registers: one m-slab (8 float4) in flight
             }
-            acc_store_native(acc, asave + ((int64_t)(l - 1) * ntiles + tile) * TILE_F, wave, lane);
+            if (save) acc_store_native(acc, asave + ((int64_t)(l - 1) * ntiles + tile) * TILE_F, wave, lane);
             __syncthreads();
             acc_to_lds(acc, smain, wave, lane);
             __syncthreads();
@@ -234,10 +234,10 @@ int launch_sdf_fwd_train(const float* packed, const float* pts, int64_t npts, fl
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 int launch_sdf_grad(const float* packed, const float* pts, int64_t npts, const float* act, float* asave, float* normals,
-                    int grid, hipStream_t stream) {
+                    int save, int grid, hipStream_t stream) {
     const int64_t ntiles = (npts + TM - 1) / TM;
     const int g = (int)(ntiles < grid ? ntiles : grid);
-    hipLaunchKernelGGL(sdf_grad_kernel, dim3(g), dim3(256), 0, stream, make_sdf_ptrs(packed), pts, npts, act, asave, normals);
+    hipLaunchKernelGGL(sdf_grad_kernel, dim3(g), dim3(256), 0, stream, make_sdf_ptrs(packed), pts, npts, act, asave, normals, save);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 int launch_color_fwd(const float* packed, const float* pts, const float* dirs, int n_per_ray, const float* normals,

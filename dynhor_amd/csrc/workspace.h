@@ -30,7 +30,7 @@ struct Workspace {
     float* tpart;   // [nt][N_TILE_PART][256]
     float* tred;    // [DW_NS][N_TILE_PART][256]
     float* slabs;   // dW split-K slabs (dw.hip)
-    int64_t fwd_floats, total_floats;
+    int64_t infer_floats, fwd_floats, total_floats;   // forward-only (no saves for backward) / forward / everything
 };
 
 inline Workspace carve_workspace(float* base, int64_t npts) {
@@ -43,6 +43,7 @@ inline Workspace carve_workspace(float* base, int64_t npts) {
     w.act = take(8 * nt * TILE_F);
     w.eaux = take(nt * AUXT_F);
     w.feat = take(nt * TILE_F);
+    w.infer_floats = o;
     w.asave = take(8 * nt * TILE_F);
     w.cact = take(4 * nt * TILE_F);
     w.caux = take(nt * AUXT_F);

@@ -20,13 +20,20 @@ def marching_tetrahedra(u: torch.Tensor, threshold: float, bound_min, bound_max)
     N = u.shape[0]
     bmin = torch.as_tensor(bound_min, dtype=torch.float32, device=dev)
     bmax = torch.as_tensor(bound_max, dtype=torch.float32, device=dev)
-    idx = torch.arange(N - 1, device=dev)
-    cx, cy, cz = torch.meshgrid(idx, idx, idx, indexing="ij")
-    base = torch.stack([cx, cy, cz], -1).reshape(-1, 1, 3)                    # [C,1,3]
+    # active cells first (8 shifted views of the grid: no per-cell index tensors for the empty 99 % of the volume)
+    f = u - threshold
+    sl = (slice(0, N - 1), slice(1, N))
+    vmax = torch.full((N - 1, N - 1, N - 1), -float("inf"), device=dev)
+    vmin = torch.full((N - 1, N - 1, N - 1), float("inf"), device=dev)
+    for dx in (0, 1):
+        for dy in (0, 1):
+            for dz in (0, 1):
+                c = f[sl[dx], sl[dy], sl[dz]]
+                vmax = torch.maximum(vmax, c)
+                vmin = torch.minimum(vmin, c)
+    base = ((vmax > 0) & (vmin <= 0)).nonzero().reshape(-1, 1, 3)              # [C,1,3] active cells only
     corners = base + _CORNERS.to(dev).reshape(1, 8, 3)                          # [C,8,3]
-    vals = u[corners[..., 0], corners[..., 1], corners[..., 2]] - threshold   # [C,8]
-    active = (vals.max(dim=1).values > 0) & (vals.min(dim=1).values <= 0)
-    corners, vals = corners[active], vals[active]
+    vals = f[corners[..., 0], corners[..., 1], corners[..., 2]]               # [C,8]
     tets = _TETS.to(dev)
     tv = vals[:, tets]                                                         # [C,6,4]
     tp = corners[:, tets].float()                                              # [C,6,4,3]

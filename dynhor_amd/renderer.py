@@ -106,11 +106,12 @@ class NeuSRenderer:
         self.timer = StageTimer()
 
     # ------------------------------------------------------------------ workspace (caller-owned, reused)
-    def _workspace(self, npts: int) -> torch.Tensor:
-        _, total = _lib.workspace_floats(npts)
-        if self._ws is None or self._ws.numel() < total:
+    def _workspace(self, npts: int, infer_only: bool = False) -> torch.Tensor:
+        infer, _, total = _lib.workspace_floats(npts)
+        need = infer if infer_only else total
+        if self._ws is None or self._ws.numel() < need:
             self._ws = None
-            self._ws = torch.empty(total, device=self.store.device, dtype=torch.float32)
+            self._ws = torch.empty(need, device=self.store.device, dtype=torch.float32)
         return self._ws
 
     # ------------------------------------------------------------------ no-grad SDF queries
@@ -170,7 +171,7 @@ class NeuSRenderer:
 
     # ------------------------------------------------------------------ render_core forward / backward (no autograd)
     @torch.no_grad()
-    def _forward_core(self, rays_o, rays_d, z_vals, cos_anneal_ratio, background_rgb, want_nmap):
+    def _forward_core(self, rays_o, rays_d, z_vals, cos_anneal_ratio, background_rgb, want_nmap, infer_only=False):
         L = _lib.lib()
         st = self.store
         packed = st.ensure_packed()
@@ -180,7 +181,8 @@ class NeuSRenderer:
         s = SimpleNamespace()
         s.B, s.n, s.car, s.sample_dist = B, n, float(cos_anneal_ratio), 2.0 / self.n_samples
         s.rays_o, s.rays_d, s.z_vals, s.bg = rays_o, rays_d, z_vals, background_rgb
-        s.ws = self._workspace(P)
+        s.ws = self._workspace(P, infer_only)
+        s.infer_only = infer_only
         self._ws_token += 1
         s.ws_token = self._ws_token
         s.pts = torch.empty(P, 3, device=dev)
@@ -190,9 +192,10 @@ class NeuSRenderer:
         _lib.check(L.dh_midpoints(_p(rays_o), _p(rays_d), _p(z_vals), B, n, s.sample_dist, _p(s.pts), _lib.stream()))
         T = self.timer
         T("sdf_forward", L.dh_sdf_forward, _p(packed), _p(s.pts), P, _p(s.ws), _p(s.sdf), _lib.stream())
-        T("sdf_gradient", L.dh_sdf_gradient, _p(packed), _p(s.pts), P, _p(s.ws), _p(s.normals), _lib.stream())
+        save = 0 if infer_only else 1
+        T("sdf_gradient", L.dh_sdf_gradient, _p(packed), _p(s.pts), P, _p(s.ws), _p(s.normals), save, _lib.stream())
         T("color_forward", L.dh_color_forward, _p(packed), _p(s.pts), _p(rays_d), n, _p(s.normals), P, _p(s.ws),
-          _p(s.colors), _lib.stream())
+          _p(s.colors), save, _lib.stream())
         s.inv_s = st.inv_s()
         s.weights = torch.empty(B, n, device=dev)
         s.color = torch.empty(B, 3, device=dev)
@@ -215,6 +218,8 @@ class NeuSRenderer:
         """Adjoint of _forward_core: returns the flat parameter gradient (also kept as store.grad_flat)."""
         L = _lib.lib()
         st = self.store
+        if s.infer_only:
+            raise RuntimeError("this forward pass was run with infer_only=True: nothing was saved for backward")
         if s.ws_token != self._ws_token:
             raise RuntimeError("NeuSRenderer workspace was overwritten by a later render() call before backward(); "
                                "call backward() before rendering again (one live graph per renderer)")

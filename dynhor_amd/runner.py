@@ -205,7 +205,7 @@ class Runner:
             r = rays[s:s + chunk]
             o, d = r[:, :3].contiguous(), r[:, 3:6].contiguous()
             z = self.renderer.sample_z(o, d, near[s:s + chunk], far[s:s + chunk], perturb_overwrite=0)
-            st = self.renderer._forward_core(o, d, z, self.get_cos_anneal_ratio(), bg, want_nmap=True)
+            st = self.renderer._forward_core(o, d, z, self.get_cos_anneal_ratio(), bg, want_nmap=True, infer_only=True)
             cols.append(st.color); nrms.append(st.nmap)
         return torch.cat(cols).view(h, w, 3), torch.cat(nrms).view(h, w, 3), rays.view(h, w, 14)
 

@@ -47,9 +47,10 @@ int dh_pack_weights(const float* params, float* packed, void* stream);
  * pts [npts,3] -> sdf [npts]. */
 int dh_sdf_nograd(const float* packed, const float* pts, int64_t npts, float* sdf, void* stream);
 
-/* Workspace size (floats) for a render call over npts fine sample points: fwd_floats is what the forward pass
- * writes (saved activations), total_floats additionally covers the backward pass. */
-int dh_workspace_floats(int64_t npts, int64_t* fwd_floats, int64_t* total_floats);
+/* Workspace size (floats) for a render call over npts fine sample points: infer_floats suffices for a forward-only
+ * render (save = 0 below), fwd_floats is what a training forward writes (saved activations), total_floats additionally
+ * covers the backward pass. */
+int dh_workspace_floats(int64_t npts, int64_t* infer_floats, int64_t* fwd_floats, int64_t* total_floats);
 
 /* The MLP part of upstream NeuSRenderer.render_core (App. A.7) on npts points (point i belongs to ray
  * i / n_per_ray): sdf_network(pts) -> sdf [npts], feature (kept in ws); sdf_network.gradient(pts) -> normals
@@ -58,11 +59,12 @@ int dh_workspace_floats(int64_t npts, int64_t* fwd_floats, int64_t* total_floats
 int dh_mlp_forward(const float* packed, const float* pts, const float* dirs, int n_per_ray, int64_t npts, float* ws,
                    float* sdf, float* normals, float* color, void* stream);
 
-/* The three stages of dh_mlp_forward as separate single-kernel launches (same ws): */
+/* The three stages of dh_mlp_forward as separate single-kernel launches (same ws); save = 0 skips the stores that only
+ * the backward pass needs (forward-only rendering: validate_image). */
 int dh_sdf_forward(const float* packed, const float* pts, int64_t npts, float* ws, float* sdf, void* stream);
-int dh_sdf_gradient(const float* packed, const float* pts, int64_t npts, float* ws, float* normals, void* stream);
+int dh_sdf_gradient(const float* packed, const float* pts, int64_t npts, float* ws, float* normals, int save, void* stream);
 int dh_color_forward(const float* packed, const float* pts, const float* dirs, int n_per_ray, const float* normals,
-                     int64_t npts, float* ws, float* color, void* stream);
+                     int64_t npts, float* ws, float* color, int save, void* stream);
 
 /* Adjoint of dh_mlp_forward (autograd of upstream render_core's network calls, incl. the second-order path through
  * sdf_network.gradient's create_graph=True): given d_sdf [npts], d_normals [npts,3] (updated in place with the colour

@@ -48,9 +48,9 @@ def test_host_only_entry_points(hiplib):
     assert _lib.param_layout(2, 0)[3:] == (256, 289)
     with pytest.raises(_lib.DynhorHipError):
         _lib.param_layout(0, 9)
-    fwd, tot = _lib.workspace_floats(128 * 2048)
-    assert 0 < fwd < tot
-    assert _lib.workspace_floats(0) == (0, _lib.workspace_floats(0)[1])
+    inf, fwd, tot = _lib.workspace_floats(128 * 2048)
+    assert 0 < inf < fwd < tot
+    assert _lib.workspace_floats(0)[:2] == (0, 0)
 
 
 def test_argument_validation_without_gpu(hiplib):

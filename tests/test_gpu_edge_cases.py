@@ -88,3 +88,15 @@ def test_all_hand_or_all_background_masks_do_not_produce_nans(tmp_path):
     assert stats[1].item() == 0.0 and stats[3].item() == 0.0, "colour and mask losses are fully gated by keep = 0"
     # eikonal is not mask-gated (App. A.8): it alone drives the gradient
     assert p_r.store.grad_flat.abs().sum().item() > 0
+
+
+def test_forward_only_mode_equals_training_forward_and_refuses_backward():
+    o_r, p_r = make_pair(seed=9, n_samples=64, n_importance=64)
+    o, d, near, far, t_rand = make_rays(77, seed=3)
+    z = p_r.sample_z(o, d, near, far, t_rand=t_rand)
+    a = p_r._forward_core(o, d, z, 0.5, None, want_nmap=True)
+    ca, wa, na = a.color.clone(), a.weights.clone(), a.nmap.clone()
+    b = p_r._forward_core(o, d, z, 0.5, None, want_nmap=True, infer_only=True)
+    assert torch.equal(ca, b.color) and torch.equal(wa, b.weights) and torch.equal(na, b.nmap)
+    with pytest.raises(RuntimeError):
+        p_r._backward_core(b, torch.zeros(77, 3, device="cuda:0"), None, None, None, None, torch.zeros(1, device="cuda:0"))

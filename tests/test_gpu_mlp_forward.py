@@ -19,7 +19,7 @@ def test_mlp_forward_matches_oracle(hiplib, nrays, n_per_ray, jitter):
     npts = nrays * n_per_ray
     pts = ((torch.rand(npts, 3, generator=g) * 2 - 1) * 1.1).to(dev)
     dirs = torch.nn.functional.normalize(torch.randn(nrays, 3, generator=g), dim=-1).to(dev)
-    _, total = _lib.workspace_floats(npts)
+    _, _, total = _lib.workspace_floats(npts)
     ws = torch.empty(total, device=dev)
     o_sdf = torch.full((npts,), float("nan"), device=dev)
     o_n = torch.full((npts, 3), float("nan"), device=dev)
