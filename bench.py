@@ -63,6 +63,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--frames", type=int, default=64)
+    ap.add_argument("--rays-per-rank", type=int, default=2048,
+                    help="2048 = throughput mode (weak scaling, the headline); 2048/N = fixed global batch (PSNR-parity mode)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-rays", type=int, default=512)
     ap.add_argument("--backend", type=str, default="nccl", help="torch.distributed backend (nccl == RCCL; gloo for tests)")
@@ -89,7 +91,7 @@ def main():
     from dynhor_amd.runner import Runner
     conf = {"seq_name": "bench_synth", "exp_name": f"r{rank}",
             "data_info": {"synthetic": {"n_frames": args.frames, "H": 512, "W": 512, "seed": 4321}},
-            "train": {"batch_size": 2048, "normal_weight": 0.05, "report_freq": 10 ** 9, "save_freq": 10 ** 9,
+            "train": {"batch_size": args.rays_per_rank, "normal_weight": 0.05, "report_freq": 10 ** 9, "save_freq": 10 ** 9,
                       "val_freq": 0}}
     runner = Runner(conf=conf, device=device, exp_root=os.path.join("/tmp", "dynhor_bench_exps"))
     B = runner.batch_size
@@ -160,7 +162,7 @@ def main():
                 "whole_step_mfma_frac": round(value / world * FLOP_PER_RAY_TRAIN / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4)}
         out = {"metric": "training rays/sec", "value": round(value, 1), "unit": "rays/s", "n_gpus": world,
                "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
-               "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "scaling": "weak" if args.rays_per_rank == 2048 else "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": "custom_shoes-shaped synthetic seq, 512x512, 2048 rays x (64+64) samples per rank, "
                                       "NeuS SDF(8x256, skip 4, softplus100) + colour(4x256) MLP, full training iteration",
                           "frames": args.frames, "rays_per_rank": B, "samples_per_ray": n_samples,
