@@ -70,6 +70,7 @@ def main():
     ap.add_argument("--backend", type=str, default="nccl", help="torch.distributed backend (nccl == RCCL; gloo for tests)")
     ap.add_argument("--share-gpu", action="store_true", help="TEST ONLY: every rank uses cuda:0 (with --backend gloo)")
     ap.add_argument("--check-sync", action="store_true", help="verify all ranks hold identical parameters at the end")
+    ap.add_argument("--force-dist", action="store_true", help="TEST ONLY: initialise the process group even for one rank")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -77,7 +78,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.share_gpu:
         local_rank = 0
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
         if args.backend == "nccl":
@@ -99,7 +101,7 @@ def main():
 
     def sync():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -113,7 +115,7 @@ def main():
         stats = runner.train_iteration()
     sync()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -172,7 +174,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_rays, runner.renderer.n_samples, runner.renderer.n_importance)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

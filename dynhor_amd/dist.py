@@ -14,8 +14,7 @@ def world_info():
 def allreduce_sum_(flat_grad: torch.Tensor) -> torch.Tensor:
     """In-place SUM all-reduce of the 802,491-float gradient bucket; the 1/world mean is folded into the fused Adam
     (dh_adam_step grad_scale) so no extra pass over the bucket is needed."""
-    _, world = world_info()
-    if world > 1:
+    if dist.is_available() and dist.is_initialized():      # also with a single rank: keeps the collective path exercised
         dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM)
     return flat_grad
 

@@ -75,3 +75,19 @@ def test_product_package_never_imports_the_oracle():
             if f.endswith(".py"):
                 src = open(os.path.join(dp, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f"{f} imports the oracle"
+
+
+def test_example_configs_parse_into_upstream_constructor_kwargs():
+    """configs/*.yaml use the reference's flat-YAML style; their model blocks must be valid upstream ctor kwargs."""
+    import yaml
+    from dynhor_amd.fields import RenderingNetwork, SDFNetwork, SingleVarianceNetwork
+    from dynhor_amd.runner import DEFAULT_CONF, _merge
+    for name in ("custom_shoes.yaml", "synthetic.yaml"):
+        conf = _merge(DEFAULT_CONF, yaml.safe_load(open(os.path.join(ROOT, "configs", name))))
+        assert {"seq_name", "exp_name", "data_info", "train", "model"} <= set(conf)
+        sdf = SDFNetwork(**conf["model"]["sdf_network"])
+        col = RenderingNetwork(**conf["model"]["rendering_network"])
+        var = SingleVarianceNetwork(**conf["model"]["variance_network"])
+        assert sum(p.numel() for m in (sdf, col, var) for p in m.parameters()) == 802491
+        r = conf["model"]["neus_renderer"]
+        assert r["n_samples"] + r["n_importance"] <= 128 and r["n_outside"] == 0
