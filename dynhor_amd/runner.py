@@ -217,9 +217,18 @@ class Runner:
         m = (rays[..., 9:10] * rays[..., 10:11])
         mse = (((img - rays[..., 6:9]) ** 2) * m).sum() / (m.sum() * 3.0 + 1e-5)
         psnr = float(20.0 * torch.log10(1.0 / mse.sqrt()))
-        d = os.path.join(self.base_exp_dir, "validations_fine")
-        os.makedirs(d, exist_ok=True)
-        np.save(os.path.join(d, "{:0>8d}_{}.npy".format(self.iter_step, idx)), (img.clamp(0, 1) * 255).byte().cpu().numpy())
+        if self.rank == 0:
+            from PIL import Image
+            d = os.path.join(self.base_exp_dir, "validations_fine")
+            dn = os.path.join(self.base_exp_dir, "normals")
+            os.makedirs(d, exist_ok=True); os.makedirs(dn, exist_ok=True)
+            gt = (rays[..., 6:9].clamp(0, 1) * 255).byte().cpu().numpy()
+            pr = (img.clamp(0, 1) * 255).byte().cpu().numpy()
+            # upstream writes prediction and ground truth side by side
+            Image.fromarray(np.concatenate([pr, gt], axis=1)).save(os.path.join(d, "{:0>8d}_{}.png".format(self.iter_step, idx)))
+            n_cam = nrm @ self.dataset.R[idx].T                      # object -> camera frame (x_cam = R x_obj)
+            nimg = ((n_cam / (n_cam.norm(dim=-1, keepdim=True) + 1e-6)) * 0.5 + 0.5).clamp(0, 1)
+            Image.fromarray((nimg * 255).byte().cpu().numpy()).save(os.path.join(dn, "{:0>8d}_{}.png".format(self.iter_step, idx)))
         return psnr
 
     @torch.no_grad()
