@@ -32,6 +32,11 @@ SIGNATURES = {
     "dh_weight_grads_fold": (_i32, [_vp, _vp, _i64, _vp, _vp, _vp]),
     "dh_mlp_backward": (_i32, [_vp, _vp, _vp, _i64] + [_vp] * 7),
     "dh_adam_step": (_i32, [_vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _i64, _f32, _vp]),
+    "dh_hashgrid_entries": (_i64, []),
+    "dh_hashgrid_level": (_i32, [_i32, ctypes.POINTER(_f32), ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint32),
+                                 ctypes.POINTER(ctypes.c_uint32)]),
+    "dh_hashgrid_encode": (_i32, [_vp, _vp, _i64, _vp, _vp]),
+    "dh_hashgrid_encode_backward": (_i32, [_vp, _vp, _i64, _vp, _vp]),
     "dh_gen_rays": (_i32, [_vp] * 6 + [_i32, _i32, _i32, _i32, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),
     "dh_coarse_samples": (_i32, [_vp] * 5 + [_i64, _i32, _vp, _vp, _vp]),
     "dh_upsample_step": (_i32, [_vp] * 4 + [_i64, _i32, _i32, _f32, _vp, _vp, _vp]),

@@ -247,4 +247,26 @@ int dh_neus_loss(const float* color, const float* weight_sum, const float* norma
                        d_color, d_weight_sum, d_normal_map, eik_coef, static_cast<hipStream_t>(stream));
 }
 
+int64_t dh_hashgrid_entries(void) { return hashgrid_entries(); }
+
+int dh_hashgrid_level(int level, float* scale, uint32_t* resolution, uint32_t* offset, uint32_t* dense) {
+    if (!scale || !resolution || !offset || !dense) return DH_ERR_BAD_ARG;
+    return hashgrid_level(level, scale, resolution, offset, dense) ? DH_ERR_BAD_ARG : DH_OK;
+}
+
+int dh_hashgrid_encode(const float* table, const float* x01, int64_t n, float* out, void* stream) {
+    if (n < 0) return DH_ERR_BAD_ARG;
+    if (n == 0) return DH_OK;
+    if (!table || !x01 || !out || (reinterpret_cast<uintptr_t>(table) & 7u) || (reinterpret_cast<uintptr_t>(out) & 7u))
+        return DH_ERR_BAD_ARG;
+    return launch_hashgrid_fwd(table, x01, n, out, static_cast<hipStream_t>(stream));
+}
+
+int dh_hashgrid_encode_backward(const float* x01, const float* d_out, int64_t n, float* d_table, void* stream) {
+    if (n < 0) return DH_ERR_BAD_ARG;
+    if (n == 0) return DH_OK;
+    if (!x01 || !d_out || !d_table || (reinterpret_cast<uintptr_t>(d_out) & 7u)) return DH_ERR_BAD_ARG;
+    return launch_hashgrid_bwd(x01, d_out, n, d_table, static_cast<hipStream_t>(stream));
+}
+
 }  // extern "C"

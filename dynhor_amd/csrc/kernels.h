@@ -59,4 +59,10 @@ int launch_weight_grads_fold(const Workspace& w, float* slabs, float* tred, int 
 int launch_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2, float eps,
                 int64_t step, float grad_scale, hipStream_t st);
 
+// multiresolution hash-grid encoding (hashgrid.hip)
+int64_t hashgrid_entries();
+int hashgrid_level(int l, float* scale, uint32_t* res, uint32_t* offset, uint32_t* dense);
+int launch_hashgrid_fwd(const float* table, const float* x01, int64_t n, float* out, hipStream_t st);
+int launch_hashgrid_bwd(const float* x01, const float* d_out, int64_t n, float* d_table, hipStream_t st);
+
 }  // namespace dh

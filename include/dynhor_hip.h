@@ -152,6 +152,16 @@ int dh_neus_loss(const float* color, const float* weight_sum, const float* norma
 int dh_adam_step(float* params, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
                  float beta2, float eps, int64_t step, float grad_scale, void* stream);
 
+/* ---- multiresolution hash-grid encoding (BASELINE.json configs[3]) -------------------------
+ * The instant-nsr-pl variant the reference names as its direction (README.md:11,13; code on an unmounted branch).
+ * Fixed geometry: 16 levels x 2 features, 2^19 entries per hashed level, resolutions 16 .. 2049; dense indexing on the
+ * levels whose grid fits the table.  table: [dh_hashgrid_entries(), 2] fp32; x01 [n,3] in [0,1]; out [n,32].
+ * Backward ACCUMULATES into d_table with float atomics (caller zeroes it). */
+int64_t dh_hashgrid_entries(void);
+int dh_hashgrid_level(int level, float* scale, uint32_t* resolution, uint32_t* offset, uint32_t* dense);
+int dh_hashgrid_encode(const float* table, const float* x01, int64_t n, float* out, void* stream);
+int dh_hashgrid_encode_backward(const float* x01, const float* d_out, int64_t n, float* d_table, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -29,13 +29,17 @@ def main():
     ap.add_argument("--batch", type=int, default=2048)
     ap.add_argument("--frames", type=int, default=64)
     ap.add_argument("--res", type=int, default=512)
+    ap.add_argument("--seed", type=int, default=777, help="ray / perturbation RNG seed (shared by both paths)")
+    ap.add_argument("--weight-seed", type=int, default=1234)
+    ap.add_argument("--noise-floor", action="store_true",
+                    help="replace the HIP path by a SECOND oracle whose initial weights differ by 1e-7 relative: how far apart do two fp32 runs of the oracle itself land?")
     ap.add_argument("--out", type=str, default=os.path.join(ROOT, "profiles", "psnr_parity_r01.json"))
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     conf = {"seq_name": "psnr_parity", "exp_name": "hip",
             "data_info": {"synthetic": {"n_frames": args.frames, "H": args.res, "W": args.res, "seed": 4321}},
             "train": {"batch_size": args.batch, "normal_weight": 0.05, "report_freq": 10 ** 9, "save_freq": 10 ** 9,
-                      "val_freq": 0, "end_iter": 300000, "warm_up_end": 5000, "anneal_end": 50000}}
+                      "val_freq": 0, "end_iter": 300000, "warm_up_end": 5000, "anneal_end": 50000, "seed": args.weight_seed}}
     runner = Runner(conf=conf, device=dev, exp_root="/tmp/dynhor_psnr")
     ds = runner.dataset
     # oracle twin: identical initial weights
@@ -44,9 +48,18 @@ def main():
     o_var.load_state_dict(runner.deviation_network.state_dict())
     o_r = O.NeuSRenderer(None, o_sdf, o_var, o_col, 64, 64, 0, 4, 1.0)
     opt = torch.optim.Adam(list(o_sdf.parameters()) + list(o_var.parameters()) + list(o_col.parameters()), lr=5e-4)
+    if args.noise_floor:
+        t_sdf, t_col, t_var = O.build_models(seed=1234, device=dev)
+        t_sdf.load_state_dict(o_sdf.state_dict()); t_col.load_state_dict(o_col.state_dict()); t_var.load_state_dict(o_var.state_dict())
+        with torch.no_grad():
+            gp = torch.Generator(device=dev); gp.manual_seed(5)
+            for p in list(t_sdf.parameters()) + list(t_col.parameters()):
+                p.mul_(1.0 + 1e-7 * torch.randn(p.shape, device=dev, generator=gp))
+        t_r = O.NeuSRenderer(None, t_sdf, t_var, t_col, 64, 64, 0, 4, 1.0)
+        t_opt = torch.optim.Adam(list(t_sdf.parameters()) + list(t_var.parameters()) + list(t_col.parameters()), lr=5e-4)
     perm = runner.image_perm.clone()
-    gen_h = torch.Generator(device=dev); gen_h.manual_seed(777)
-    gen_o = torch.Generator(device=dev); gen_o.manual_seed(777)
+    gen_h = torch.Generator(device=dev); gen_h.manual_seed(args.seed)
+    gen_o = torch.Generator(device=dev); gen_o.manual_seed(args.seed)
 
     def draw(gen):
         px = torch.randint(0, ds.W, [args.batch], device=dev, generator=gen)
@@ -65,8 +78,14 @@ def main():
         px, py, tr = draw(gen_h)
         rays = ds.gen_rays_at_pixels(frame, px, py)
         near, far = ds._last_near_far
-        stats_h = runner.renderer.train_step_core(rays, near, far, ds.R[frame], car, 0.1, 0.1, 0.05, t_rand=tr)
-        runner.store.adam_step(lr)
+        if args.noise_floor:
+            for g in t_opt.param_groups:
+                g["lr"] = lr
+            l_t = O.train_step(t_r, t_opt, rays, car, 0.1, 0.1, 0.05, R=ds.R[frame], t_rand=tr)
+            stats_h = torch.tensor([float(l_t["loss"]), 0, 0, 0, 0, float(l_t["psnr"])])
+        else:
+            stats_h = runner.renderer.train_step_core(rays, near, far, ds.R[frame], car, 0.1, 0.1, 0.05, t_rand=tr)
+            runner.store.adam_step(lr)
         torch.cuda.synchronize(); t_h += time.perf_counter() - t0
         # ---- oracle, GPU eager, same rays
         t0 = time.perf_counter()
@@ -101,10 +120,17 @@ def main():
             out.append(r["color_fine"].detach())
         return torch.cat(out)
 
-    p_h = val_psnr(render_hip, ds, frames, 4)
+    def render_twin(rays, near, far):
+        out = []
+        for s in range(0, rays.shape[0], 2048):
+            o, d = rays[s:s + 2048, :3], rays[s:s + 2048, 3:6]
+            out.append(t_r.render(o, d, near[s:s + 2048], far[s:s + 2048], perturb_overwrite=0, cos_anneal_ratio=1.0)["color_fine"].detach())
+        return torch.cat(out)
+
+    p_h = val_psnr(render_twin if args.noise_floor else render_hip, ds, frames, 4)
     p_o = val_psnr(render_orc, ds, frames, 4)
-    res = {"iters": args.iters, "batch": args.batch, "frames": args.frames, "res": args.res,
-           "val_psnr_hip": p_h, "val_psnr_oracle_gpu_eager": p_o, "abs_diff_db": abs(p_h - p_o),
+    res = {"seed": args.seed, "weight_seed": args.weight_seed, "iters": args.iters, "batch": args.batch, "frames": args.frames, "res": args.res,
+           "mode": "noise_floor: oracle vs 1e-7-perturbed oracle" if args.noise_floor else "hip vs oracle", "val_psnr_hip": p_h, "val_psnr_oracle_gpu_eager": p_o, "abs_diff_db": abs(p_h - p_o),
            "sec_per_iter_hip": t_h / args.iters, "sec_per_iter_oracle_gpu_eager": t_o / args.iters,
            "note": "oracle = this repo's PyTorch restatement of NeuS (parity unpinned at the reference)", "curve": curve}
     os.makedirs(os.path.dirname(args.out), exist_ok=True)
