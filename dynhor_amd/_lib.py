@@ -37,6 +37,18 @@ SIGNATURES = {
                                  ctypes.POINTER(ctypes.c_uint32)]),
     "dh_hashgrid_encode": (_i32, [_vp, _vp, _i64, _vp, _vp]),
     "dh_hashgrid_encode_backward": (_i32, [_vp, _vp, _i64, _vp, _vp]),
+    "dh_hash_num_params": (_i64, []),
+    "dh_hash_packed_floats": (_i64, []),
+    "dh_hash_param_layout": (_i32, [_i32, _i32, ctypes.POINTER(_i64), ctypes.POINTER(_i64), ctypes.POINTER(_i64),
+                                    ctypes.POINTER(_i32), ctypes.POINTER(_i32)]),
+    "dh_hash_pack_weights": (_i32, [_vp, _vp, _vp]),
+    "dh_hash_workspace_floats": (_i64, [_i64]),
+    "dh_hash_sdf_nograd": (_i32, [_vp, _vp, _vp, _i64, _f32, _vp, _vp]),
+    "dh_hash_geo_forward": (_i32, [_vp, _vp, _vp, _i64, _f32, _f32, _vp, _vp, _vp, _vp]),
+    "dh_hash_color_forward": (_i32, [_vp, _vp, _vp, _vp, _i32, _i64, _vp, _vp]),
+    "dh_hash_color_backward": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i64, _vp, _vp, _vp, _vp]),
+    "dh_hash_geo_backward": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _f32, _f32, _vp, _vp]),
+    "dh_hash_weight_grads": (_i32, [_vp, _vp, _i64, _vp, _vp, _vp]),
     "dh_gen_rays": (_i32, [_vp] * 6 + [_i32, _i32, _i32, _i32, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),
     "dh_coarse_samples": (_i32, [_vp] * 5 + [_i64, _i32, _vp, _vp, _vp]),
     "dh_upsample_step": (_i32, [_vp] * 4 + [_i64, _i32, _i32, _f32, _vp, _vp, _vp]),

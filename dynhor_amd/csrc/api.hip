@@ -1,6 +1,7 @@
 // extern "C" boundary (include/dynhor_hip.h).  Argument checking + launch dispatch only.
 #include "../../include/dynhor_hip.h"
 #include "kernels.h"
+#include "hash_layout.h"
 #include "layout.h"
 #include "workspace.h"
 
@@ -267,6 +268,81 @@ int dh_hashgrid_encode_backward(const float* x01, const float* d_out, int64_t n,
     if (n == 0) return DH_OK;
     if (!x01 || !d_out || !d_table || (reinterpret_cast<uintptr_t>(d_out) & 7u)) return DH_ERR_BAD_ARG;
     return launch_hashgrid_bwd(x01, d_out, n, d_table, static_cast<hipStream_t>(stream));
+}
+
+int64_t dh_hash_num_params(void) { return hash_num_params(); }
+int64_t dh_hash_packed_floats(void) { return HP_TOTAL; }
+
+int dh_hash_param_layout(int net, int layer, int64_t* bias_off, int64_t* g_off, int64_t* v_off, int* out_dim, int* in_dim) {
+    if (!bias_off || !g_off || !v_off || !out_dim || !in_dim) return DH_ERR_BAD_ARG;
+    const HashParamOff P = make_hash_param_off(hashgrid_entries());
+    if (net == 0 && layer == 0) { *bias_off = P.g0_b; *g_off = P.g0_g; *v_off = P.g0_v; *out_dim = 64; *in_dim = HM_GIN; }
+    else if (net == 0 && layer == 1) { *bias_off = P.g1_b; *g_off = P.g1_g; *v_off = P.g1_v; *out_dim = HM_GOUT; *in_dim = 64; }
+    else if (net == 1 && layer == 0) { *bias_off = *g_off = *v_off = P.variance; *out_dim = 1; *in_dim = 1; }
+    else if (net == 2 && layer == 0) { *bias_off = P.c0_b; *g_off = P.c0_g; *v_off = P.c0_v; *out_dim = 64; *in_dim = HM_CIN; }
+    else if (net == 2 && layer == 1) { *bias_off = P.c1_b; *g_off = P.c1_g; *v_off = P.c1_v; *out_dim = 64; *in_dim = 64; }
+    else if (net == 2 && layer == 2) { *bias_off = P.c2_b; *g_off = P.c2_g; *v_off = P.c2_v; *out_dim = 3; *in_dim = 64; }
+    else if (net == 3 && layer == 0) { *bias_off = *g_off = *v_off = P.table; *out_dim = (int)hashgrid_entries(); *in_dim = 2; }
+    else return DH_ERR_BAD_ARG;
+    return DH_OK;
+}
+
+int dh_hash_pack_weights(const float* params, float* packed, void* stream) {
+    if (!params || !packed) return DH_ERR_BAD_ARG;
+    return launch_hash_pack(params, packed, static_cast<hipStream_t>(stream));
+}
+
+int64_t dh_hash_workspace_floats(int64_t npts) { return npts < 0 ? 0 : hash_workspace_floats(npts); }
+
+static inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+int dh_hash_sdf_nograd(const float* params, const float* packed, const float* pts, int64_t n, float radius, float* sdf,
+                       void* stream) {
+    if (n < 0 || !(radius > 0.f)) return DH_ERR_BAD_ARG;
+    if (n == 0) return DH_OK;
+    if (!params || !packed || !pts || !sdf || !al16(params) || !al16(packed)) return DH_ERR_BAD_ARG;
+    return launch_hash_sdf_nograd(params, packed, pts, n, radius, sdf, static_cast<hipStream_t>(stream));
+}
+
+int dh_hash_geo_forward(const float* params, const float* packed, const float* pts, int64_t n, float radius, float eps,
+                        float* sdf, float* feature, float* gradient, void* stream) {
+    if (n < 0 || !(radius > 0.f) || !(eps > 0.f)) return DH_ERR_BAD_ARG;
+    if (n == 0) return DH_OK;
+    if (!params || !packed || !pts || !sdf || !feature || !gradient || !al16(params) || !al16(packed)) return DH_ERR_BAD_ARG;
+    return launch_hash_geo_fwd(params, packed, pts, n, radius, eps, sdf, feature, gradient, static_cast<hipStream_t>(stream));
+}
+
+int dh_hash_color_forward(const float* packed, const float* feature, const float* normals, const float* dirs,
+                          int n_per_ray, int64_t n, float* color, void* stream) {
+    if (n < 0 || n_per_ray <= 0 || n % n_per_ray) return DH_ERR_BAD_ARG;
+    if (n == 0) return DH_OK;
+    if (!packed || !feature || !normals || !dirs || !color || !al16(packed)) return DH_ERR_BAD_ARG;
+    return launch_sh_color_fwd(packed, feature, normals, dirs, n_per_ray, n, color, static_cast<hipStream_t>(stream));
+}
+
+int dh_hash_color_backward(const float* packed, const float* feature, const float* normals, const float* dirs,
+                           const float* d_color, int n_per_ray, int64_t n, float* ws, float* d_feature, float* d_normals,
+                           void* stream) {
+    if (n <= 0 || n_per_ray <= 0 || n % n_per_ray) return DH_ERR_BAD_ARG;
+    if (!packed || !feature || !normals || !dirs || !d_color || !ws || !d_feature || !d_normals || !al16(packed) || !al16(ws))
+        return DH_ERR_BAD_ARG;
+    return launch_sh_color_bwd(packed, feature, normals, dirs, d_color, n_per_ray, n, ws, d_feature, d_normals,
+                               static_cast<hipStream_t>(stream));
+}
+
+int dh_hash_geo_backward(const float* params, const float* packed, const float* pts, const float* d_sdf,
+                         const float* d_feature, const float* d_normals, int64_t n, float radius, float eps, float* ws,
+                         void* stream) {
+    if (n <= 0 || !(radius > 0.f) || !(eps > 0.f)) return DH_ERR_BAD_ARG;
+    if (!params || !packed || !pts || !d_sdf || !d_feature || !d_normals || !ws || !al16(params) || !al16(packed) || !al16(ws))
+        return DH_ERR_BAD_ARG;
+    return launch_hash_geo_bwd(params, packed, pts, d_sdf, d_feature, d_normals, n, radius, eps, ws,
+                               static_cast<hipStream_t>(stream));
+}
+
+int dh_hash_weight_grads(const float* params, const float* packed, int64_t n, float* ws, float* grad, void* stream) {
+    if (n <= 0 || !params || !packed || !ws || !grad || !al16(ws)) return DH_ERR_BAD_ARG;
+    return launch_hash_weight_grads(params, packed, n, ws, grad, static_cast<hipStream_t>(stream));
 }
 
 }  // extern "C"

@@ -1,0 +1,509 @@
+// Hash-grid model family (BASELINE.json configs[3]): fused hash-grid encoding + 64-wide SDF MLP with
+// central-finite-difference normals, and the SH-4 colour MLP.  Gather-bound: one thread per sample point, the ~10 k
+// small weights of both MLPs staged whole into LDS (41 KB) and read as wave-uniform broadcasts; the MLP arithmetic is
+// VALU (a 35x64 + 64x13 network is ~3 kFMA per evaluation -- nothing for MFMA to win against the 128 table gathers).
+// Algorithm: oracle/hashgrid_oracle.py (parity unpinned, see its header).
+#include "tile.h"
+#include "kernels.h"
+#include "hash_layout.h"
+#include "hashgrid_dev.h"
+
+namespace dh {
+
+// ---------------------------------------------------------------- small-weight packing (weight-norm)
+struct HashLinDesc { int64_t b, g, v; int out, in, ld, dst, dstb, rowbase; };
+
+__global__ __launch_bounds__(64) void hash_pack_kernel(const float* __restrict__ params, float* __restrict__ hp,
+                                                       HashParamOff P) {
+    const HashLinDesc D[5] = {{P.g0_b, P.g0_g, P.g0_v, 64, HM_GIN, 36, HP_G0, HP_G0B, HP_ROW_G0},
+                              {P.g1_b, P.g1_g, P.g1_v, HM_GOUT, 64, 64, HP_G1, HP_G1B, HP_ROW_G1},
+                              {P.c0_b, P.c0_g, P.c0_v, 64, HM_CIN, 32, HP_C0, HP_C0B, HP_ROW_C0},
+                              {P.c1_b, P.c1_g, P.c1_v, 64, 64, 64, HP_C1, HP_C1B, HP_ROW_C1},
+                              {P.c2_b, P.c2_g, P.c2_v, 3, 64, 64, HP_C2, HP_C2B, HP_ROW_C2}};
+    const HashLinDesc L = D[blockIdx.y];
+    const int row = blockIdx.x, lane = threadIdx.x;
+    const int padded_rows = (blockIdx.y == 1) ? 16 : (blockIdx.y == 4 ? 4 : L.out);
+    if (row >= padded_rows) return;
+    if (row >= L.out) {                                   // zero padding rows
+        for (int k = lane; k < L.ld; k += 64) hp[L.dst + row * L.ld + k] = 0.f;
+        if (lane == 0) hp[L.dstb + row] = 0.f;
+        return;
+    }
+    const float* v = params + L.v + (int64_t)row * L.in;
+    float s = 0.f;
+    for (int k = lane; k < L.in; k += 64) s += v[k] * v[k];
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    const float inv = 1.f / sqrtf(s);
+    const float rs = params[L.g + row] * inv;
+    for (int k = lane; k < L.ld; k += 64) hp[L.dst + row * L.ld + k] = k < L.in ? rs * v[k] : 0.f;
+    if (lane == 0) {
+        hp[L.dstb + row] = params[L.b + row];
+        hp[HP_RS + L.rowbase + row] = rs;
+        hp[HP_INV + L.rowbase + row] = inv;
+    }
+}
+
+__device__ __forceinline__ void stage_weights(float* lds, const float* __restrict__ hp) {
+    for (int i = threadIdx.x; i < HP_WEIGHTS; i += blockDim.x) lds[i] = hp[i];
+    __syncthreads();
+}
+
+// ---------------------------------------------------------------- geometry network, one evaluation
+// x: world position; radius: scene box half-size (x01 = (x + r) / 2r).  FULL: all 13 outputs, else sdf only.
+template <bool FULL>
+__device__ __forceinline__ void geo_eval(const HashLevels& H, const float* __restrict__ table, const float* W,
+                                         const float (&x)[3], float radius, float (&out)[HM_GOUT]) {
+    float in[36];
+    float x01[3];
+    DH_UNROLL for (int c = 0; c < 3; ++c) { x01[c] = (x[c] + radius) / (2.f * radius); in[c] = x01[c] * 2.f - 1.f; }
+    DH_UNROLL for (int l = 0; l < HG_L; ++l) hg_encode_level(H, table, l, x01, in[3 + 2 * l], in[4 + 2 * l]);
+    in[35] = 0.f;
+    DH_UNROLL for (int c = 0; c < HM_GOUT; ++c) out[c] = W[HP_G1B + c];
+    for (int j = 0; j < HM_HID; ++j) {
+        const f32x4* wr = reinterpret_cast<const f32x4*>(W + HP_G0 + j * 36);
+        float a = W[HP_G0B + j];
+        DH_UNROLL for (int k4 = 0; k4 < 9; ++k4) {
+            const f32x4 w = wr[k4];
+            a = fmaf(w[0], in[4 * k4], a); a = fmaf(w[1], in[4 * k4 + 1], a);
+            a = fmaf(w[2], in[4 * k4 + 2], a); a = fmaf(w[3], in[4 * k4 + 3], a);
+        }
+        const float h = softplus100(a);
+        out[0] = fmaf(W[HP_G1 + j], h, out[0]);
+        if (FULL) { DH_UNROLL for (int c = 1; c < HM_GOUT; ++c) out[c] = fmaf(W[HP_G1 + c * 64 + j], h, out[c]); }
+    }
+}
+
+// sdf only (hierarchical up-sampling evaluations)
+__global__ __launch_bounds__(256) void hash_sdf_nograd_kernel(HashLevels H, const float* __restrict__ table,
+                                                              const float* __restrict__ hp, const float* __restrict__ pts,
+                                                              int64_t n, float radius, float* __restrict__ sdf) {
+    __shared__ __attribute__((aligned(16))) float W[HP_WEIGHTS + 4];
+    stage_weights(W, hp);
+    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= n) return;
+    const float x[3] = {pts[p * 3], pts[p * 3 + 1], pts[p * 3 + 2]};
+    float out[HM_GOUT];
+    geo_eval<false>(H, table, W, x, radius, out);
+    sdf[p] = out[0];
+}
+
+// training / rendering forward: sdf, feature (all 13 outputs), finite-difference gradient (App. of the oracle: eps 1e-3)
+__global__ __launch_bounds__(256) void hash_geo_fwd_kernel(HashLevels H, const float* __restrict__ table,
+                                                           const float* __restrict__ hp, const float* __restrict__ pts,
+                                                           int64_t n, float radius, float eps, float* __restrict__ sdf,
+                                                           float* __restrict__ feat, float* __restrict__ grad) {
+    __shared__ __attribute__((aligned(16))) float W[HP_WEIGHTS + 4];
+    stage_weights(W, hp);
+    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= n) return;
+    const float x[3] = {pts[p * 3], pts[p * 3 + 1], pts[p * 3 + 2]};
+    float out[HM_GOUT];
+    geo_eval<true>(H, table, W, x, radius, out);
+    sdf[p] = out[0];
+    DH_UNROLL for (int c = 0; c < HM_FEAT; ++c) feat[p * HM_FEAT + c] = out[c];
+    DH_UNROLL for (int i = 0; i < 3; ++i) {
+        float xp[3] = {x[0], x[1], x[2]}, xm[3] = {x[0], x[1], x[2]};
+        xp[i] += eps; xm[i] -= eps;
+        float op[HM_GOUT], om[HM_GOUT];
+        geo_eval<false>(H, table, W, xp, radius, op);
+        geo_eval<false>(H, table, W, xm, radius, om);
+        grad[p * 3 + i] = (op[0] - om[0]) * (0.5f / eps);
+    }
+}
+
+// ---------------------------------------------------------------- SH-4 colour network
+__device__ __forceinline__ void sh4_eval(const float (&d)[3], float (&y)[16]) {
+    const float x = d[0], yy_ = d[1], z = d[2];
+    const float xx = x * x, yy = yy_ * yy_, zz = z * z, xy = x * yy_, yz = yy_ * z, xz = x * z;
+    y[0] = 0.28209479177387814f;
+    y[1] = -0.48860251190291987f * yy_; y[2] = 0.48860251190291987f * z; y[3] = -0.48860251190291987f * x;
+    y[4] = 1.0925484305920792f * xy; y[5] = -1.0925484305920792f * yz;
+    y[6] = 0.94617469575755997f * zz - 0.31539156525251999f; y[7] = -1.0925484305920792f * xz;
+    y[8] = 0.54627421529603959f * (xx - yy);
+    y[9] = 0.59004358992664352f * yy_ * (-3.f * xx + yy); y[10] = 2.8906114426405538f * xy * z;
+    y[11] = 0.45704579946446572f * yy_ * (1.f - 5.f * zz); y[12] = 0.3731763325901154f * z * (5.f * zz - 3.f);
+    y[13] = 0.45704579946446572f * x * (1.f - 5.f * zz); y[14] = 1.4453057213202769f * z * (xx - yy);
+    y[15] = 0.59004358992664352f * x * (-xx + 3.f * yy);
+}
+
+__global__ __launch_bounds__(256) void sh_color_fwd_kernel(const float* __restrict__ hp, const float* __restrict__ feat,
+                                                           const float* __restrict__ normals, const float* __restrict__ dirs,
+                                                           int n_per_ray, int64_t n, float* __restrict__ color) {
+    __shared__ __attribute__((aligned(16))) float W[HP_WEIGHTS + 4];
+    stage_weights(W, hp);
+    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= n) return;
+    float in[HM_CIN];
+    DH_UNROLL for (int c = 0; c < HM_FEAT; ++c) in[c] = feat[p * HM_FEAT + c];
+    const int64_t ray = p / n_per_ray;
+    const float d[3] = {dirs[ray * 3], dirs[ray * 3 + 1], dirs[ray * 3 + 2]};
+    float y[16];
+    sh4_eval(d, y);
+    DH_UNROLL for (int c = 0; c < 16; ++c) in[HM_FEAT + c] = y[c];
+    DH_UNROLL for (int c = 0; c < 3; ++c) in[HM_FEAT + 16 + c] = normals[p * 3 + c];
+    float h1[HM_HID];
+    DH_UNROLL for (int j = 0; j < HM_HID; ++j) {
+        const f32x4* wr = reinterpret_cast<const f32x4*>(W + HP_C0 + j * HM_CIN);
+        float a = W[HP_C0B + j];
+        DH_UNROLL for (int k4 = 0; k4 < HM_CIN / 4; ++k4) {
+            const f32x4 w = wr[k4];
+            a = fmaf(w[0], in[4 * k4], a); a = fmaf(w[1], in[4 * k4 + 1], a);
+            a = fmaf(w[2], in[4 * k4 + 2], a); a = fmaf(w[3], in[4 * k4 + 3], a);
+        }
+        h1[j] = fmaxf(a, 0.f);
+    }
+    float o[3] = {W[HP_C2B], W[HP_C2B + 1], W[HP_C2B + 2]};
+    for (int j2 = 0; j2 < HM_HID; ++j2) {
+        const f32x4* wr = reinterpret_cast<const f32x4*>(W + HP_C1 + j2 * 64);
+        float a = W[HP_C1B + j2];
+        DH_UNROLL for (int k4 = 0; k4 < 16; ++k4) {
+            const f32x4 w = wr[k4];
+            a = fmaf(w[0], h1[4 * k4], a); a = fmaf(w[1], h1[4 * k4 + 1], a);
+            a = fmaf(w[2], h1[4 * k4 + 2], a); a = fmaf(w[3], h1[4 * k4 + 3], a);
+        }
+        const float h2 = fmaxf(a, 0.f);
+        DH_UNROLL for (int c = 0; c < 3; ++c) o[c] = fmaf(W[HP_C2 + c * 64 + j2], h2, o[c]);
+    }
+    DH_UNROLL for (int c = 0; c < 3; ++c) color[p * 3 + c] = 1.f / (1.f + __expf(-o[c]));
+}
+
+// ================================================================ backward
+// Workspace (floats, per point-count n; E = 7 geometry evaluations: centre, then +-eps per axis):
+//   colour  : DO [n][4] | H2 [n][64] | DZ2 [n][64] | H1 [n][64] | DZ1 [n][64] | CIN [n][32]
+//   geometry: X01 [E n][3] | DIN [E n][32] | DOUT [E n][16] | HH [E n][64] | DA [E n][64] | GIN [E n][36]
+//   partial weight-gradient slabs
+// The per-point kernels recompute the (tiny) forward and write each layer's input and pre-activation adjoint row-major;
+// the weight gradients are then plain  dW = sum_p dz[p]^T in[p]  reductions done by small_dw_kernel on MFMA, reading
+// the rows straight into the 32x32x2 operand layout (lane = feature, coalesced 128-B rows).
+struct HashWs {
+    int64_t d_o, h2, dz2, h1, dz1, cin, x01, din, dout, hh, da, gin, slabs, total;
+};
+constexpr int HW_E = 7;
+constexpr int HW_SLABS = 512;                    // partial-sum slabs of the weight-gradient reductions
+constexpr int HW_DW_FLOATS = 64 * 64 + 64;       // one job's slab: padded [64][64] tile + column sums
+constexpr int HW_JOBS = 5;
+inline HashWs make_hash_ws(int64_t n) {
+    HashWs w{};
+    int64_t o = 0;
+    auto take = [&](int64_t cnt) { int64_t r = o; o += (cnt + 63) / 64 * 64; return r; };
+    w.d_o = take(n * 4); w.h2 = take(n * 64); w.dz2 = take(n * 64); w.h1 = take(n * 64); w.dz1 = take(n * 64);
+    w.cin = take(n * 32);
+    w.x01 = take(HW_E * n * 3); w.din = take(HW_E * n * 32); w.dout = take(HW_E * n * 16); w.hh = take(HW_E * n * 64);
+    w.da = take(HW_E * n * 64); w.gin = take(HW_E * n * 36);
+    w.slabs = take((int64_t)HW_JOBS * HW_SLABS * HW_DW_FLOATS);
+    w.total = o;
+    return w;
+}
+
+__device__ __forceinline__ void store_row(float* dst, const float* v, int n4) {
+    DH_UNROLL for (int i = 0; i < n4; ++i)
+        *reinterpret_cast<f32x4*>(dst + 4 * i) = f32x4{v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]};
+}
+
+// colour network adjoint.  d_normals is read-modify-written (the render-scan adjoint is already in it).
+__global__ __launch_bounds__(256) void sh_color_bwd_kernel(const float* __restrict__ hp, const float* __restrict__ feat,
+                                                           const float* __restrict__ normals, const float* __restrict__ dirs,
+                                                           const float* __restrict__ d_color, int n_per_ray, int64_t n,
+                                                           float* __restrict__ ws, HashWs O, float* __restrict__ d_feat,
+                                                           float* __restrict__ d_normals) {
+    __shared__ __attribute__((aligned(16))) float W[HP_WEIGHTS + 4];
+    stage_weights(W, hp);
+    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= n) return;
+    float in[HM_CIN];
+    DH_UNROLL for (int c = 0; c < HM_FEAT; ++c) in[c] = feat[p * HM_FEAT + c];
+    const int64_t ray = p / n_per_ray;
+    const float d[3] = {dirs[ray * 3], dirs[ray * 3 + 1], dirs[ray * 3 + 2]};
+    {
+        float y[16];
+        sh4_eval(d, y);
+        DH_UNROLL for (int c = 0; c < 16; ++c) in[HM_FEAT + c] = y[c];
+    }
+    DH_UNROLL for (int c = 0; c < 3; ++c) in[HM_FEAT + 16 + c] = normals[p * 3 + c];
+    store_row(ws + O.cin + p * 32, in, 8);
+    float h1[HM_HID];
+    DH_UNROLL for (int j = 0; j < HM_HID; ++j) {
+        const f32x4* wr = reinterpret_cast<const f32x4*>(W + HP_C0 + j * HM_CIN);
+        float a = W[HP_C0B + j];
+        DH_UNROLL for (int k4 = 0; k4 < HM_CIN / 4; ++k4) {
+            const f32x4 w = wr[k4];
+            a = fmaf(w[0], in[4 * k4], a); a = fmaf(w[1], in[4 * k4 + 1], a);
+            a = fmaf(w[2], in[4 * k4 + 2], a); a = fmaf(w[3], in[4 * k4 + 3], a);
+        }
+        h1[j] = fmaxf(a, 0.f);
+    }
+    store_row(ws + O.h1 + p * 64, h1, 16);
+    // pass 1 over the second layer: the outputs
+    float o[3] = {W[HP_C2B], W[HP_C2B + 1], W[HP_C2B + 2]};
+    for (int j2 = 0; j2 < HM_HID; ++j2) {
+        const f32x4* wr = reinterpret_cast<const f32x4*>(W + HP_C1 + j2 * 64);
+        float a = W[HP_C1B + j2];
+        DH_UNROLL for (int k4 = 0; k4 < 16; ++k4) {
+            const f32x4 w = wr[k4];
+            a = fmaf(w[0], h1[4 * k4], a); a = fmaf(w[1], h1[4 * k4 + 1], a);
+            a = fmaf(w[2], h1[4 * k4 + 2], a); a = fmaf(w[3], h1[4 * k4 + 3], a);
+        }
+        const float h2 = fmaxf(a, 0.f);
+        DH_UNROLL for (int c = 0; c < 3; ++c) o[c] = fmaf(W[HP_C2 + c * 64 + j2], h2, o[c]);
+    }
+    float dob[4];
+    DH_UNROLL for (int c = 0; c < 3; ++c) {
+        const float col = 1.f / (1.f + __expf(-o[c]));
+        dob[c] = d_color[p * 3 + c] * col * (1.f - col);
+    }
+    dob[3] = 0.f;
+    store_row(ws + O.d_o + p * 4, dob, 1);
+    // pass 2: recompute h2 row by row, its adjoint, and pull back onto h1
+    float dh1[HM_HID];
+    DH_UNROLL for (int k = 0; k < HM_HID; ++k) dh1[k] = 0.f;
+    float* h2row = ws + O.h2 + p * 64;
+    float* dz2row = ws + O.dz2 + p * 64;
+    for (int j2 = 0; j2 < HM_HID; ++j2) {
+        const f32x4* wr = reinterpret_cast<const f32x4*>(W + HP_C1 + j2 * 64);
+        float a = W[HP_C1B + j2];
+        DH_UNROLL for (int k4 = 0; k4 < 16; ++k4) {
+            const f32x4 w = wr[k4];
+            a = fmaf(w[0], h1[4 * k4], a); a = fmaf(w[1], h1[4 * k4 + 1], a);
+            a = fmaf(w[2], h1[4 * k4 + 2], a); a = fmaf(w[3], h1[4 * k4 + 3], a);
+        }
+        const float h2 = fmaxf(a, 0.f);
+        float dz2 = W[HP_C2 + j2] * dob[0] + W[HP_C2 + 64 + j2] * dob[1] + W[HP_C2 + 128 + j2] * dob[2];
+        dz2 = a > 0.f ? dz2 : 0.f;
+        h2row[j2] = h2;
+        dz2row[j2] = dz2;
+        DH_UNROLL for (int k4 = 0; k4 < 16; ++k4) {
+            const f32x4 w = wr[k4];
+            dh1[4 * k4] = fmaf(w[0], dz2, dh1[4 * k4]); dh1[4 * k4 + 1] = fmaf(w[1], dz2, dh1[4 * k4 + 1]);
+            dh1[4 * k4 + 2] = fmaf(w[2], dz2, dh1[4 * k4 + 2]); dh1[4 * k4 + 3] = fmaf(w[3], dz2, dh1[4 * k4 + 3]);
+        }
+    }
+    DH_UNROLL for (int k = 0; k < HM_HID; ++k) dh1[k] = h1[k] > 0.f ? dh1[k] : 0.f;     // now dz1
+    store_row(ws + O.dz1 + p * 64, dh1, 16);
+    float din[HM_CIN];
+    DH_UNROLL for (int k = 0; k < HM_CIN; ++k) din[k] = 0.f;
+    DH_UNROLL for (int j = 0; j < HM_HID; ++j) {
+        const f32x4* wr = reinterpret_cast<const f32x4*>(W + HP_C0 + j * HM_CIN);
+        DH_UNROLL for (int k4 = 0; k4 < HM_CIN / 4; ++k4) {
+            if (k4 >= 4 && k4 < 7) continue;                      // SH inputs: the direction is not differentiated
+            const f32x4 w = wr[k4];
+            din[4 * k4] = fmaf(w[0], dh1[j], din[4 * k4]); din[4 * k4 + 1] = fmaf(w[1], dh1[j], din[4 * k4 + 1]);
+            din[4 * k4 + 2] = fmaf(w[2], dh1[j], din[4 * k4 + 2]); din[4 * k4 + 3] = fmaf(w[3], dh1[j], din[4 * k4 + 3]);
+        }
+    }
+    DH_UNROLL for (int c = 0; c < HM_FEAT; ++c) d_feat[p * HM_FEAT + c] = din[c];
+    DH_UNROLL for (int c = 0; c < 3; ++c) d_normals[p * 3 + c] += din[HM_FEAT + 16 + c];
+}
+
+// geometry adjoint: E = 7 evaluations per point (centre with the feature/sdf cotangent, +-eps per axis with
+// +-d_grad * 0.5/eps on the sdf output).  Writes the rows small_dw_kernel and the table scatter consume.
+__global__ __launch_bounds__(256) void hash_geo_bwd_kernel(HashLevels H, const float* __restrict__ table,
+                                                           const float* __restrict__ hp, const float* __restrict__ pts,
+                                                           const float* __restrict__ d_sdf, const float* __restrict__ d_feat,
+                                                           const float* __restrict__ d_grad, int64_t n, float radius,
+                                                           float eps, float* __restrict__ ws, HashWs O) {
+    __shared__ __attribute__((aligned(16))) float W[HP_WEIGHTS + 4];
+    stage_weights(W, hp);
+    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= n) return;
+    const float x[3] = {pts[p * 3], pts[p * 3 + 1], pts[p * 3 + 2]};
+    for (int e = 0; e < HW_E; ++e) {
+        float xe[3] = {x[0], x[1], x[2]};
+        float dout[16];
+        DH_UNROLL for (int c = 0; c < 16; ++c) dout[c] = 0.f;
+        if (e == 0) {
+            DH_UNROLL for (int c = 0; c < HM_FEAT; ++c) dout[c] = d_feat[p * HM_FEAT + c];
+            dout[0] += d_sdf[p];
+        } else {
+            const int axis = (e - 1) >> 1;
+            const float sgn = (e - 1) & 1 ? -1.f : 1.f;
+            DH_UNROLL for (int c = 0; c < 3; ++c) if (c == axis) xe[c] += sgn * eps;
+            dout[0] = sgn * d_grad[p * 3 + axis] * (0.5f / eps);
+        }
+        const int64_t row = (int64_t)e * n + p;
+        float in[36], x01[3];
+        DH_UNROLL for (int c = 0; c < 3; ++c) { x01[c] = (xe[c] + radius) / (2.f * radius); in[c] = x01[c] * 2.f - 1.f; }
+        DH_UNROLL for (int l = 0; l < HG_L; ++l) hg_encode_level(H, table, l, x01, in[3 + 2 * l], in[4 + 2 * l]);
+        in[35] = 1.f;                                   // ones column: dW0[:,35] accumulates the bias gradient
+        store_row(ws + O.gin + row * 36, in, 9);
+        in[35] = 0.f;
+        DH_UNROLL for (int c = 0; c < 3; ++c) ws[O.x01 + row * 3 + c] = x01[c];
+        store_row(ws + O.dout + row * 16, dout, 4);
+        float din[36];
+        DH_UNROLL for (int k = 0; k < 36; ++k) din[k] = 0.f;
+        float* hrow = ws + O.hh + row * 64;
+        float* darow = ws + O.da + row * 64;
+        for (int j = 0; j < HM_HID; ++j) {
+            const f32x4* wr = reinterpret_cast<const f32x4*>(W + HP_G0 + j * 36);
+            float a = W[HP_G0B + j];
+            DH_UNROLL for (int k4 = 0; k4 < 9; ++k4) {
+                const f32x4 w = wr[k4];
+                a = fmaf(w[0], in[4 * k4], a); a = fmaf(w[1], in[4 * k4 + 1], a);
+                a = fmaf(w[2], in[4 * k4 + 2], a); a = fmaf(w[3], in[4 * k4 + 3], a);
+            }
+            const float h = softplus100(a);
+            float dh = 0.f;
+            if (e == 0) { DH_UNROLL for (int c = 0; c < HM_GOUT; ++c) dh = fmaf(W[HP_G1 + c * 64 + j], dout[c], dh); }
+            else dh = W[HP_G1 + j] * dout[0];
+            const float da = dh / (1.f + __builtin_amdgcn_exp2f(-a * (SOFTPLUS_BETA * 1.44269504088896f)));
+            hrow[j] = h;
+            darow[j] = da;
+            DH_UNROLL for (int k4 = 0; k4 < 9; ++k4) {
+                const f32x4 w = wr[k4];
+                din[4 * k4] = fmaf(w[0], da, din[4 * k4]); din[4 * k4 + 1] = fmaf(w[1], da, din[4 * k4 + 1]);
+                din[4 * k4 + 2] = fmaf(w[2], da, din[4 * k4 + 2]); din[4 * k4 + 3] = fmaf(w[3], da, din[4 * k4 + 3]);
+            }
+        }
+        float* dinrow = ws + O.din + row * 32;
+        DH_UNROLL for (int k = 0; k < 32; ++k) dinrow[k] = din[3 + k];
+    }
+}
+
+// dW[m][k] = sum_p A[p][m] B[p][k]  (m < M <= 64, k < K <= 64), plus colsum[m] = sum_p A[p][m]; one wave per slab of
+// rows, fp32 MFMA 32x32x2 with the operands read from global directly in operand layout.
+struct SmallDwJob { int64_t a, b; int lda, ldb, M, K; int64_t rows; };
+struct SmallDwJobs { SmallDwJob j[HW_JOBS]; };
+
+__global__ __launch_bounds__(64) void small_dw_kernel(const float* __restrict__ ws, SmallDwJobs J, float* __restrict__ slabs) {
+    const SmallDwJob job = J.j[blockIdx.y];
+    const int lane = threadIdx.x, i = lane & 31, kk = lane >> 5;
+    const int64_t per = ((job.rows + HW_SLABS - 1) / HW_SLABS + 1) & ~int64_t(1);
+    const int64_t r0 = (int64_t)blockIdx.x * per, r1 = r0 + per < job.rows ? r0 + per : job.rows;
+    f32x16 acc[2][2];
+    DH_UNROLL for (int a = 0; a < 2; ++a) DH_UNROLL for (int b = 0; b < 2; ++b) DH_UNROLL for (int q = 0; q < 16; ++q) acc[a][b][q] = 0.f;
+    float cs[2] = {0.f, 0.f};
+    const float* A = ws + job.a;
+    const float* B = ws + job.b;
+    const bool am0 = i < job.M, am1 = i + 32 < job.M, bk0 = i < job.K, bk1 = i + 32 < job.K;
+    for (int64_t rp = r0; rp < r1; rp += 2) {          // wave-uniform trip count: MFMA must not run under divergence
+        const int64_t r = rp + kk;
+        const bool v = r < r1;
+        const float a0 = (v && am0) ? A[r * job.lda + i] : 0.f;
+        const float a1 = (v && am1) ? A[r * job.lda + 32 + i] : 0.f;
+        const float b0 = (v && bk0) ? B[r * job.ldb + i] : 0.f;
+        const float b1 = (v && bk1) ? B[r * job.ldb + 32 + i] : 0.f;
+        cs[0] += a0; cs[1] += a1;
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+    }
+    float* out = slabs + ((int64_t)blockIdx.y * HW_SLABS + blockIdx.x) * HW_DW_FLOATS;
+    DH_UNROLL for (int a = 0; a < 2; ++a) DH_UNROLL for (int b = 0; b < 2; ++b) DH_UNROLL for (int q = 0; q < 16; ++q) {
+        const int m = a * 32 + 8 * (q >> 2) + 4 * kk + (q & 3);      // accumulator layout of 32x32x2: row = 8*(q/4)+4*(lane/32)+q%4
+        out[m * 64 + b * 32 + i] = acc[a][b][q];
+    }
+    DH_UNROLL for (int a = 0; a < 2; ++a) {
+        const float t = cs[a] + __shfl_xor(cs[a], 32);
+        if (kk == 0) out[64 * 64 + a * 32 + i] = t;
+    }
+}
+
+// sum the slabs of every job (fixed order: deterministic) -> dwsum [HW_JOBS][HW_DW_FLOATS]
+__global__ __launch_bounds__(256) void small_dw_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ dwsum) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= HW_DW_FLOATS) return;
+    const float* s = slabs + (int64_t)blockIdx.y * HW_SLABS * HW_DW_FLOATS + e;
+    float t = 0.f;
+    for (int b = 0; b < HW_SLABS; ++b) t += s[(int64_t)b * HW_DW_FLOATS];
+    dwsum[blockIdx.y * HW_DW_FLOATS + e] = t;
+}
+
+// weight-norm fold of the five small linears: W = g v/||v||:  g_bar = (dW . v)/||v||,  v_bar = g/||v|| (dW - (dW . v) v/||v||^2)
+__global__ __launch_bounds__(64) void hash_fold_kernel(const float* __restrict__ params, const float* __restrict__ hp,
+                                                       const float* __restrict__ dwsum, HashParamOff P,
+                                                       float* __restrict__ grad) {
+    const HashLinDesc D[5] = {{P.g0_b, P.g0_g, P.g0_v, 64, HM_GIN, 36, HP_G0, HP_G0B, HP_ROW_G0},
+                              {P.g1_b, P.g1_g, P.g1_v, HM_GOUT, 64, 64, HP_G1, HP_G1B, HP_ROW_G1},
+                              {P.c0_b, P.c0_g, P.c0_v, 64, HM_CIN, 32, HP_C0, HP_C0B, HP_ROW_C0},
+                              {P.c1_b, P.c1_g, P.c1_v, 64, 64, 64, HP_C1, HP_C1B, HP_ROW_C1},
+                              {P.c2_b, P.c2_g, P.c2_v, 3, 64, 64, HP_C2, HP_C2B, HP_ROW_C2}};
+    const int job = blockIdx.y;
+    const HashLinDesc L = D[job];
+    const int row = blockIdx.x, lane = threadIdx.x;
+    if (row >= L.out) return;
+    const float* dW = dwsum + job * HW_DW_FLOATS + row * 64;
+    const float* v = params + L.v + (int64_t)row * L.in;
+    float dot = 0.f;
+    for (int k = lane; k < L.in; k += 64) dot += dW[k] * v[k];
+    for (int off = 32; off > 0; off >>= 1) dot += __shfl_xor(dot, off);
+    const float inv = hp[HP_INV + L.rowbase + row], rs = hp[HP_RS + L.rowbase + row];
+    for (int k = lane; k < L.in; k += 64) grad[L.v + (int64_t)row * L.in + k] = rs * (dW[k] - dot * v[k] * inv * inv);
+    if (lane == 0) {
+        grad[L.g + row] = dot * inv;
+        // bias: geometry lin0 keeps it in the ones column (k = 35); everyone else in the column sums of A
+        grad[L.b + row] = job == 0 ? dW[35] : dwsum[job * HW_DW_FLOATS + 64 * 64 + row];
+    }
+}
+
+// ---------------------------------------------------------------- launchers
+static inline int ok() { return hipGetLastError() == hipSuccess ? 0 : -3; }
+
+int64_t hash_num_params() { return make_hash_param_off(hashgrid_entries()).total; }
+HashParamOff hash_param_off() { return make_hash_param_off(hashgrid_entries()); }
+
+int launch_hash_pack(const float* params, float* hp, hipStream_t st) {
+    hipLaunchKernelGGL(hash_pack_kernel, dim3(64, 5), dim3(64), 0, st, params, hp, hash_param_off());
+    return ok();
+}
+int launch_hash_sdf_nograd(const float* params, const float* hp, const float* pts, int64_t n, float radius, float* sdf,
+                           hipStream_t st) {
+    hipLaunchKernelGGL(hash_sdf_nograd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, hashgrid_levels(),
+                       params + hash_param_off().table, hp, pts, n, radius, sdf);
+    return ok();
+}
+int launch_hash_geo_fwd(const float* params, const float* hp, const float* pts, int64_t n, float radius, float eps,
+                        float* sdf, float* feat, float* grad, hipStream_t st) {
+    hipLaunchKernelGGL(hash_geo_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, hashgrid_levels(),
+                       params + hash_param_off().table, hp, pts, n, radius, eps, sdf, feat, grad);
+    return ok();
+}
+int launch_sh_color_fwd(const float* hp, const float* feat, const float* normals, const float* dirs, int n_per_ray,
+                        int64_t n, float* color, hipStream_t st) {
+    hipLaunchKernelGGL(sh_color_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, hp, feat, normals, dirs,
+                       n_per_ray, n, color);
+    return ok();
+}
+
+}  // namespace dh
+
+namespace dh {
+
+int64_t hash_workspace_floats(int64_t n) { return make_hash_ws(n).total + (int64_t)HW_JOBS * HW_DW_FLOATS; }
+
+int launch_sh_color_bwd(const float* hp, const float* feat, const float* normals, const float* dirs, const float* d_color,
+                        int n_per_ray, int64_t n, float* ws, float* d_feat, float* d_normals, hipStream_t st) {
+    hipLaunchKernelGGL(sh_color_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, hp, feat, normals, dirs,
+                       d_color, n_per_ray, n, ws, make_hash_ws(n), d_feat, d_normals);
+    return ok();
+}
+
+int launch_hash_geo_bwd(const float* params, const float* hp, const float* pts, const float* d_sdf, const float* d_feat,
+                        const float* d_grad, int64_t n, float radius, float eps, float* ws, hipStream_t st) {
+    hipLaunchKernelGGL(hash_geo_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, hashgrid_levels(),
+                       params + hash_param_off().table, hp, pts, d_sdf, d_feat, d_grad, n, radius, eps, ws, make_hash_ws(n));
+    return ok();
+}
+
+// all parameter gradients of the hash family from the rows the two kernels above left in ws: grad [hash_num_params]
+int launch_hash_weight_grads(const float* params, const float* hp, int64_t n, float* ws, float* grad, hipStream_t st) {
+    const HashWs O = make_hash_ws(n);
+    const HashParamOff P = hash_param_off();
+    const int64_t en = (int64_t)HW_E * n;
+    SmallDwJobs J;
+    J.j[0] = {O.da, O.gin, 64, 36, 64, 36, en};        // geometry lin0 (ones column -> bias)
+    J.j[1] = {O.dout, O.hh, 16, 64, HM_GOUT, 64, en};  // geometry lin1
+    J.j[2] = {O.dz1, O.cin, 64, 32, 64, 32, n};        // colour lin0
+    J.j[3] = {O.dz2, O.h1, 64, 64, 64, 64, n};         // colour lin1
+    J.j[4] = {O.d_o, O.h2, 4, 64, 3, 64, n};           // colour lin2
+    float* slabs = ws + O.slabs;
+    float* dwsum = ws + O.total;
+    hipLaunchKernelGGL(small_dw_kernel, dim3(HW_SLABS, HW_JOBS), dim3(64), 0, st, ws, J, slabs);
+    hipLaunchKernelGGL(small_dw_reduce_kernel, dim3((HW_DW_FLOATS + 255) / 256, HW_JOBS), dim3(256), 0, st, slabs, dwsum);
+    hipLaunchKernelGGL(hash_fold_kernel, dim3(64, HW_JOBS), dim3(64), 0, st, params, hp, dwsum, P, grad);
+    // table: scatter the encoding adjoint of all E n evaluations
+    if (hipMemsetAsync(grad + P.table, 0, (size_t)hashgrid_entries() * 2 * sizeof(float), st) != hipSuccess) return -3;
+    if (launch_hashgrid_bwd(ws + O.x01, ws + O.din, en, grad + P.table, st)) return -3;
+    return ok();
+}
+
+}  // namespace dh

@@ -10,47 +10,9 @@
 #include <cmath>
 #include "tile.h"
 #include "kernels.h"
+#include "hashgrid_dev.h"
 
 namespace dh {
-
-constexpr int HG_L = 16, HG_F = 2;
-constexpr uint32_t HG_T = 1u << 19;
-constexpr int HG_BASE = 16, HG_MAX = 2048;
-
-struct HashLevels {
-    float scale[HG_L];
-    uint32_t res[HG_L];
-    uint32_t offset[HG_L];      // in entries (one entry = F floats)
-    uint32_t dense[HG_L];
-    uint32_t size[HG_L];        // entries of the level (dense: res^3 rounded up to 8; hashed: T)
-    uint32_t total;
-};
-
-static HashLevels make_levels() {
-    HashLevels h{};
-    const double pls = std::exp((std::log((double)HG_MAX) - std::log((double)HG_BASE)) / (HG_L - 1));
-    uint32_t off = 0;
-    for (int l = 0; l < HG_L; ++l) {
-        const double scale = HG_BASE * std::pow(pls, l) - 1.0;
-        const uint32_t res = (uint32_t)std::ceil(scale) + 1;
-        const uint64_t n = (uint64_t)res * res * res;
-        const bool dense = n <= HG_T;
-        const uint32_t size = dense ? (uint32_t)((n + 7) / 8 * 8) : HG_T;
-        h.scale[l] = (float)scale; h.res[l] = res; h.offset[l] = off; h.dense[l] = dense ? 1u : 0u; h.size[l] = size;
-        off += size;
-    }
-    h.total = off;
-    return h;
-}
-static const HashLevels& levels() { static const HashLevels h = make_levels(); return h; }
-
-__device__ __forceinline__ uint32_t hg_index(const HashLevels& H, int l, uint32_t x, uint32_t y, uint32_t z) {
-    const uint32_t res = H.res[l];
-    // dense corner coordinates reach `res` at the far faces: wrap inside the level (tcnn does the same)
-    const uint32_t idx = H.dense[l] ? ((x + y * res + z * res * res) % H.size[l])
-                                    : (((x * 1u) ^ (y * 2654435761u) ^ (z * 805459861u)) & (HG_T - 1));
-    return idx + H.offset[l];
-}
 
 __global__ __launch_bounds__(256) void hashgrid_fwd_kernel(HashLevels H, const float* __restrict__ table,
                                                            const float* __restrict__ x01, int64_t n, float* __restrict__ out) {

@@ -65,4 +65,20 @@ int hashgrid_level(int l, float* scale, uint32_t* res, uint32_t* offset, uint32_
 int launch_hashgrid_fwd(const float* table, const float* x01, int64_t n, float* out, hipStream_t st);
 int launch_hashgrid_bwd(const float* x01, const float* d_out, int64_t n, float* d_table, hipStream_t st);
 
+// hash-grid model family (hash_mlp.hip): fused encoding + small MLPs, forward and backward
+int64_t hash_num_params();
+int64_t hash_workspace_floats(int64_t n);
+int launch_hash_pack(const float* params, float* hp, hipStream_t st);
+int launch_hash_sdf_nograd(const float* params, const float* hp, const float* pts, int64_t n, float radius, float* sdf,
+                           hipStream_t st);
+int launch_hash_geo_fwd(const float* params, const float* hp, const float* pts, int64_t n, float radius, float eps,
+                        float* sdf, float* feat, float* grad, hipStream_t st);
+int launch_sh_color_fwd(const float* hp, const float* feat, const float* normals, const float* dirs, int n_per_ray,
+                        int64_t n, float* color, hipStream_t st);
+int launch_sh_color_bwd(const float* hp, const float* feat, const float* normals, const float* dirs, const float* d_color,
+                        int n_per_ray, int64_t n, float* ws, float* d_feat, float* d_normals, hipStream_t st);
+int launch_hash_geo_bwd(const float* params, const float* hp, const float* pts, const float* d_sdf, const float* d_feat,
+                        const float* d_grad, int64_t n, float radius, float eps, float* ws, hipStream_t st);
+int launch_hash_weight_grads(const float* params, const float* hp, int64_t n, float* ws, float* grad, hipStream_t st);
+
 }  // namespace dh

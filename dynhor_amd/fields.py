@@ -101,22 +101,11 @@ class ParamStore:
 
     def __init__(self, sdf_network: SDFNetwork, deviation_network: SingleVarianceNetwork, color_network: RenderingNetwork,
                  device):
-        L = _lib.lib()
+        _lib.lib()
         self.device = torch.device(device)
-        self.n = int(L.dh_num_params())
         self.modules = (sdf_network, deviation_network, color_network)
+        self.n, self.slices, self.var_off, packed_floats = self._layout(sdf_network, deviation_network, color_network)
         self.flat = torch.empty(self.n, device=self.device, dtype=torch.float32)
-        self.slices = []          # (param, offset, numel)
-        for net, mod in ((0, sdf_network), (2, color_network)):
-            n_layers = 9 if net == 0 else 5
-            for l in range(n_layers):
-                b, g, v, out_dim, in_dim = _lib.param_layout(net, l)
-                lin = getattr(mod, "lin" + str(l))
-                assert tuple(lin.weight_v.shape) == (out_dim, in_dim), (net, l, lin.weight_v.shape)
-                self.slices += [(lin.bias, b, out_dim), (lin.weight_g, g, out_dim), (lin.weight_v, v, out_dim * in_dim)]
-        _, _, voff, _, _ = _lib.param_layout(1, 0)
-        self.var_off = voff
-        self.slices.append((deviation_network.variance, voff, 1))
         self.slices.sort(key=lambda s: s[1])
         end = 0
         for p, off, n in self.slices:
@@ -125,13 +114,32 @@ class ParamStore:
             self.flat[off:off + n].copy_(p.detach().reshape(-1).to(self.device, torch.float32))
             p.data = self.flat[off:off + n].view(p.shape)
         assert end == self.n
-        self.packed = torch.empty(int(L.dh_packed_floats()), device=self.device, dtype=torch.float32)
+        self.packed = torch.empty(packed_floats, device=self.device, dtype=torch.float32)
         self._packed_version = None
         self.grad_flat = None
         self.exp_avg = torch.zeros_like(self.flat)
         self.exp_avg_sq = torch.zeros_like(self.flat)
         self.step_count = 0
         self._manual_version = 0
+
+    # -- model-family hooks (overridden by hash_fields.HashParamStore)
+    def _layout(self, sdf_network, deviation_network, color_network):
+        """(n_params, [(param, offset, numel)], variance offset, packed floats) per include/dynhor_hip.h:dh_param_layout."""
+        L = _lib.lib()
+        slices = []
+        for net, mod in ((0, sdf_network), (2, color_network)):
+            n_layers = 9 if net == 0 else 5
+            for l in range(n_layers):
+                b, g, v, out_dim, in_dim = _lib.param_layout(net, l)
+                lin = getattr(mod, "lin" + str(l))
+                assert tuple(lin.weight_v.shape) == (out_dim, in_dim), (net, l, lin.weight_v.shape)
+                slices += [(lin.bias, b, out_dim), (lin.weight_g, g, out_dim), (lin.weight_v, v, out_dim * in_dim)]
+        _, _, voff, _, _ = _lib.param_layout(1, 0)
+        slices.append((deviation_network.variance, voff, 1))
+        return int(L.dh_num_params()), slices, voff, int(L.dh_packed_floats())
+
+    def _pack(self):
+        _lib.check(_lib.lib().dh_pack_weights(_lib.ptr(self.flat), _lib.ptr(self.packed), _lib.stream()))
 
     def params(self):
         return [p for p, _, _ in self.slices]
@@ -144,7 +152,7 @@ class ParamStore:
         # p.data aliases flat but keeps its own version counter, so fold every counter in
         ver = (self.flat._version, self._manual_version, sum(p._version for p, _, _ in self.slices))
         if ver != self._packed_version:
-            _lib.check(_lib.lib().dh_pack_weights(_lib.ptr(self.flat), _lib.ptr(self.packed), _lib.stream()))
+            self._pack()
             self._packed_version = ver
         return self.packed
 

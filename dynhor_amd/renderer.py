@@ -100,26 +100,59 @@ class NeuSRenderer:
         self.n_outside = n_outside
         self.up_sample_steps = up_sample_steps
         self.perturb = perturb
-        self.store = store if store is not None else ParamStore(sdf_network, deviation_network, color_network, device)
+        self.store = store if store is not None else self._make_store(sdf_network, deviation_network, color_network, device)
         self._ws = None
         self._ws_token = 0
         self.timer = StageTimer()
 
+    def _make_store(self, sdf_network, deviation_network, color_network, device):
+        return ParamStore(sdf_network, deviation_network, color_network, device)
+
     # ------------------------------------------------------------------ workspace (caller-owned, reused)
-    def _workspace(self, npts: int, infer_only: bool = False) -> torch.Tensor:
+    def _workspace_need(self, npts: int, infer_only: bool) -> int:
         infer, _, total = _lib.workspace_floats(npts)
-        need = infer if infer_only else total
+        return infer if infer_only else total
+
+    def _workspace(self, npts: int, infer_only: bool = False) -> torch.Tensor:
+        need = self._workspace_need(npts, infer_only)
         if self._ws is None or self._ws.numel() < need:
             self._ws = None
             self._ws = torch.empty(need, device=self.store.device, dtype=torch.float32)
         return self._ws
+
+    # ------------------------------------------------------------------ network stages (the model-family hooks;
+    # hash_fields.HashNeuSRenderer overrides these three + _workspace_need)
+    def _net_sdf_nograd(self, tag, pts, n, out):
+        self.timer(tag, _lib.lib().dh_sdf_nograd, _p(self.store.packed), _p(pts), n, _p(out), _lib.stream())
+
+    def _net_forward(self, s, packed):
+        """pts [P,3] -> s.sdf, s.normals (d sdf / d x), s.colors; saves what _net_backward needs in s.ws."""
+        L, T = _lib.lib(), self.timer
+        P = s.B * s.n
+        T("sdf_forward", L.dh_sdf_forward, _p(packed), _p(s.pts), P, _p(s.ws), _p(s.sdf), _lib.stream())
+        save = 0 if s.infer_only else 1
+        T("sdf_gradient", L.dh_sdf_gradient, _p(packed), _p(s.pts), P, _p(s.ws), _p(s.normals), save, _lib.stream())
+        T("color_forward", L.dh_color_forward, _p(packed), _p(s.pts), _p(s.rays_d), s.n, _p(s.normals), P, _p(s.ws),
+          _p(s.colors), save, _lib.stream())
+
+    def _net_backward(self, s, d_sdf, d_normals, d_colors, grad):
+        """Adjoint of _net_forward into the flat gradient (every slot but `variance`)."""
+        L, T, st = _lib.lib(), self.timer, self.store
+        P = s.B * s.n
+        T("color_backward", L.dh_color_backward, _p(st.packed), _p(s.colors), _p(d_colors), P, _p(s.ws), _p(d_normals),
+          _lib.stream())
+        T("sdf_tangent", L.dh_sdf_tangent, _p(st.packed), _p(s.pts), _p(d_normals), P, _p(s.ws), _lib.stream())
+        T("sdf_backward", L.dh_sdf_backward, _p(st.packed), _p(d_sdf), P, _p(s.ws), _lib.stream())
+        T("weight_grads_gemm", L.dh_weight_grads_gemm, P, _p(s.ws), _lib.stream())
+        T("weight_grads_fold", L.dh_weight_grads_fold, _p(st.packed), _p(st.flat), P, _p(s.ws), _p(grad), _lib.stream())
 
     # ------------------------------------------------------------------ no-grad SDF queries
     def sdf(self, pts: torch.Tensor) -> torch.Tensor:
         """sdf_network.sdf(pts) under no_grad: [N,3] -> [N,1]."""
         pts = pts.contiguous().float()
         out = torch.empty(pts.shape[0], device=pts.device)
-        _lib.check(_lib.lib().dh_sdf_nograd(_p(self.store.ensure_packed()), _p(pts), pts.shape[0], _p(out), _lib.stream()))
+        self.store.ensure_packed()
+        self._net_sdf_nograd("sdf_nograd", pts, pts.shape[0], out)
         return out.view(-1, 1)
 
     # ------------------------------------------------------------------ hierarchical sampling (App. A.5/A.6)
@@ -144,7 +177,7 @@ class NeuSRenderer:
                                        B, ns, _p(z), _p(pts), _lib.stream()))
         if self.n_importance > 0:
             sdf = torch.empty(B * ns, device=dev)
-            self.timer("sdf_nograd_coarse", L.dh_sdf_nograd, _p(packed), _p(pts), B * ns, _p(sdf), _lib.stream())
+            self._net_sdf_nograd("sdf_nograd_coarse", pts, B * ns, sdf)
             n_new = self.n_importance // self.up_sample_steps
             n_cur = ns
             for i in range(self.up_sample_steps):
@@ -156,8 +189,7 @@ class NeuSRenderer:
                 z_out = torch.empty(B, n_cur + n_new, device=dev)
                 if not last:
                     sdf_new = torch.empty(B * n_new, device=dev)
-                    self.timer("sdf_nograd_fine", L.dh_sdf_nograd, _p(packed), _p(pts_new), B * n_new, _p(sdf_new),
-                               _lib.stream())
+                    self._net_sdf_nograd("sdf_nograd_fine", pts_new, B * n_new, sdf_new)
                     sdf_out = torch.empty(B * (n_cur + n_new), device=dev)
                     _lib.check(L.dh_merge_samples(_p(z), _p(z_new), _p(sdf), _p(sdf_new), B, n_cur, n_new, _p(z_out),
                                                   _p(sdf_out), _lib.stream()))
@@ -190,12 +222,7 @@ class NeuSRenderer:
         s.normals = torch.empty(P, 3, device=dev)
         s.colors = torch.empty(P, 3, device=dev)
         _lib.check(L.dh_midpoints(_p(rays_o), _p(rays_d), _p(z_vals), B, n, s.sample_dist, _p(s.pts), _lib.stream()))
-        T = self.timer
-        T("sdf_forward", L.dh_sdf_forward, _p(packed), _p(s.pts), P, _p(s.ws), _p(s.sdf), _lib.stream())
-        save = 0 if infer_only else 1
-        T("sdf_gradient", L.dh_sdf_gradient, _p(packed), _p(s.pts), P, _p(s.ws), _p(s.normals), save, _lib.stream())
-        T("color_forward", L.dh_color_forward, _p(packed), _p(s.pts), _p(rays_d), n, _p(s.normals), P, _p(s.ws),
-          _p(s.colors), save, _lib.stream())
+        self._net_forward(s, packed)
         s.inv_s = st.inv_s()
         s.weights = torch.empty(B, n, device=dev)
         s.color = torch.empty(B, 3, device=dev)
@@ -239,13 +266,7 @@ class NeuSRenderer:
         if d_sdf_out is not None:
             d_sdf = (d_sdf + d_sdf_out.reshape(-1)).contiguous()
         grad = torch.empty(st.n, device=dev)
-        T = self.timer
-        T("color_backward", L.dh_color_backward, _p(st.packed), _p(s.colors), _p(d_colors), P, _p(s.ws), _p(d_normals),
-          _lib.stream())
-        T("sdf_tangent", L.dh_sdf_tangent, _p(st.packed), _p(s.pts), _p(d_normals), P, _p(s.ws), _lib.stream())
-        T("sdf_backward", L.dh_sdf_backward, _p(st.packed), _p(d_sdf), P, _p(s.ws), _lib.stream())
-        T("weight_grads_gemm", L.dh_weight_grads_gemm, P, _p(s.ws), _lib.stream())
-        T("weight_grads_fold", L.dh_weight_grads_fold, _p(st.packed), _p(st.flat), P, _p(s.ws), _p(grad), _lib.stream())
+        self._net_backward(s, d_sdf, d_normals, d_colors, grad)
         # variance: inv_s = clip(exp(10 v), 1e-6, 1e6)
         raw = torch.exp(st.flat[st.var_off] * 10.0)
         passthrough = ((raw >= 1e-6) & (raw <= 1e6)).float()

@@ -162,6 +162,42 @@ int dh_hashgrid_level(int level, float* scale, uint32_t* resolution, uint32_t* o
 int dh_hashgrid_encode(const float* table, const float* x01, int64_t n, float* out, void* stream);
 int dh_hashgrid_encode_backward(const float* x01, const float* d_out, int64_t n, float* d_table, void* stream);
 
+/* ---- hash-grid model family: fused encoding + small MLPs (BASELINE.json configs[3]) ---------
+ * geometry: [2 x01 - 1 (3), hash encoding (32)] -> 64 softplus(100) -> 13 (out[0] = sdf, all 13 = feature), x01 =
+ * (x + radius) / (2 radius); normals by central finite differences with step eps (instant-nsr-pl 'finite_difference').
+ * colour: [feature(13), SH degree-4 of the view dir (16), normal(3)] -> 64 relu -> 64 relu -> 3 sigmoid.
+ * All five linears are weight-normed.  Flat parameter vector: the table first, then per linear bias | g | v (see
+ * dh_hash_param_layout), `variance` between the two networks.  `packed` (dh_hash_packed_floats) holds the effective
+ * weights; refresh it with dh_hash_pack_weights whenever params change.
+ * dh_hash_param_layout: net 0 = geometry (layers 0..1), 1 = variance, 2 = colour (layers 0..2), 3 = table
+ * (v_off = offset, out_dim = entries, in_dim = 2). */
+int64_t dh_hash_num_params(void);
+int64_t dh_hash_packed_floats(void);
+int dh_hash_param_layout(int net, int layer, int64_t* bias_off, int64_t* g_off, int64_t* v_off, int* out_dim, int* in_dim);
+int dh_hash_pack_weights(const float* params, float* packed, void* stream);
+int64_t dh_hash_workspace_floats(int64_t npts);
+/* sdf only (hierarchical up-sampling): pts [n,3] -> sdf [n] */
+int dh_hash_sdf_nograd(const float* params, const float* packed, const float* pts, int64_t n, float radius, float* sdf,
+                       void* stream);
+/* sdf [n], feature [n,13], finite-difference gradient [n,3] */
+int dh_hash_geo_forward(const float* params, const float* packed, const float* pts, int64_t n, float radius, float eps,
+                        float* sdf, float* feature, float* gradient, void* stream);
+/* colour [n,3]; dirs [n / n_per_ray, 3] */
+int dh_hash_color_forward(const float* packed, const float* feature, const float* normals, const float* dirs,
+                          int n_per_ray, int64_t n, float* color, void* stream);
+/* Adjoint, three calls in this order on one caller-owned workspace ws [dh_hash_workspace_floats(n)]:
+ *   colour   : d_color [n,3] -> d_feature [n,13] (written) and d_normals [n,3] (ACCUMULATED onto the caller's values)
+ *   geometry : d_sdf [n], d_feature, d_normals (= cotangent of the finite-difference gradient)
+ *   weights  : every parameter gradient -> grad [dh_hash_num_params()] (table part zeroed then scattered with float
+ *              atomics: order-dependent in the last bits, unlike the NeuS fp32 path); the variance slot is left untouched */
+int dh_hash_color_backward(const float* packed, const float* feature, const float* normals, const float* dirs,
+                           const float* d_color, int n_per_ray, int64_t n, float* ws, float* d_feature, float* d_normals,
+                           void* stream);
+int dh_hash_geo_backward(const float* params, const float* packed, const float* pts, const float* d_sdf,
+                         const float* d_feature, const float* d_normals, int64_t n, float radius, float eps, float* ws,
+                         void* stream);
+int dh_hash_weight_grads(const float* params, const float* packed, int64_t n, float* ws, float* grad, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

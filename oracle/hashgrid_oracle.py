@@ -49,11 +49,14 @@ class HashGridEncoding(nn.Module):
     def level_index(self, l: int, ix, iy, iz):
         """Table row of integer grid corner (ix,iy,iz) at level l (int64 tensors)."""
         res = self.resolutions[l]
+        m = 0xFFFFFFFF
+        # grid coordinates are uint32 (tcnn): points outside the box (the renderer's last mid-point can overshoot the unit
+        # sphere) wrap modulo 2^32 before the level's own modulo -- defined, harmless, and what the HIP kernels do
+        ix, iy, iz = ix & m, iy & m, iz & m
         if self.dense[l]:
             # corner coordinates reach `res` at the far faces (pos = x*scale + 0.5): wrap inside the level like tcnn does
-            idx = (ix + iy * res + iz * res * res) % self.sizes[l]
+            idx = ((ix + iy * res + iz * (res * res)) & m) % self.sizes[l]
         else:
-            m = 0xFFFFFFFF
             idx = ((ix * PRIMES[0]) & m) ^ ((iy * PRIMES[1]) & m) ^ ((iz * PRIMES[2]) & m)
             idx = idx % self.T
         return idx + self.offsets[l]

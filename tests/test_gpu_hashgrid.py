@@ -38,6 +38,9 @@ def test_encode_forward_matches_oracle(hiplib, n):
     x01 = torch.rand(n, 3, device=dev)
     x01[: min(n, 8)] = torch.tensor([[0, 0, 0], [1, 1, 1], [1, 0, 0.5], [0.5, 1, 0], [0.25, 0.75, 1], [1, 1, 0], [0, 1, 1],
                                      [0.999999, 0.5, 0.5]], device=dev)[: min(n, 8)]      # faces / corners of the box
+    if n >= 17:      # outside the box (the renderer's last mid-point can overshoot): uint32 wrap, same rows as the oracle
+        x01[8:16] = torch.rand(8, 3, device=dev) * 1.2 - 0.1
+        x01[16] = torch.tensor([-0.05, 0.5, 1.08], device=dev)
     got = _encode(hiplib, enc.table.detach().contiguous(), x01)
     with torch.no_grad():
         ref = enc(x01)
