@@ -3,6 +3,7 @@
 // small weights of both MLPs staged whole into LDS (41 KB) and read as wave-uniform broadcasts; the MLP arithmetic is
 // VALU (a 35x64 + 64x13 network is ~3 kFMA per evaluation -- nothing for MFMA to win against the 128 table gathers).
 // Algorithm: oracle/hashgrid_oracle.py (parity unpinned, see its header).
+#include <cstdlib>
 #include "tile.h"
 #include "kernels.h"
 #include "hash_layout.h"
@@ -353,8 +354,107 @@ __global__ __launch_bounds__(256) void hash_geo_bwd_kernel(HashLevels H, const f
                 din[4 * k4 + 2] = fmaf(w[2], da, din[4 * k4 + 2]); din[4 * k4 + 3] = fmaf(w[3], da, din[4 * k4 + 3]);
             }
         }
-        float* dinrow = ws + O.din + row * 32;
-        DH_UNROLL for (int k = 0; k < 32; ++k) dinrow[k] = din[3 + k];
+        // encoding adjoint, level-major [16][E n] float2: coalesced here and in hash_table_bwd_kernel
+        DH_UNROLL for (int l = 0; l < HG_L; ++l)
+            *reinterpret_cast<float2*>(ws + O.din + ((int64_t)l * HW_E * n + row) * 2) = make_float2(din[3 + 2 * l], din[4 + 2 * l]);
+    }
+}
+
+// Table gradient: one thread per (point, level); grid.y = level, so a wave is 64 consecutive samples of one ray at
+// one level.  Two merges cut the float atomics the naive per-evaluation scatter (tcnn's scheme) would issue:
+//   (a) the E = 7 evaluations of a point (centre, +-eps per axis) that fall in the centre's cell are blended into the
+//       same 8 corner accumulators in registers (all of them at the coarse levels, none at the finest);
+//   (b) consecutive samples of a ray that share a cell are summed across lanes (segmented scan, lane order = ray order)
+//       and only the last lane of each run issues the 16 atomics.
+__device__ __forceinline__ void hg_cell(const HashLevels& H, int l, const float (&x01)[3], uint32_t (&g)[3], float (&w)[3]) {
+    const float s = H.scale[l];
+    DH_UNROLL for (int c = 0; c < 3; ++c) {
+        const float pos = x01[c] * s + 0.5f;
+        const float f = floorf(pos);
+        w[c] = pos - f;
+        g[c] = (uint32_t)(int)f;
+    }
+}
+
+template <int MODE>   // 0: both merges; 1: no lane-run merge; 2: no evaluation merge (ablation / debugging)
+__global__ __launch_bounds__(256) void hash_table_bwd_kernel(HashLevels H, const float* __restrict__ ws, HashWs O, int64_t n,
+                                                             float* __restrict__ d_table) {
+    const int l = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool valid = p < n;
+    const int64_t pc = valid ? p : n - 1;
+    const float* X = ws + O.x01;
+    const float2* D = reinterpret_cast<const float2*>(ws + O.din) + (int64_t)l * HW_E * n;
+    const float x0[3] = {X[pc * 3], X[pc * 3 + 1], X[pc * 3 + 2]};
+    uint32_t g0[3];
+    float w0[3];
+    hg_cell(H, l, x0, g0, w0);
+    float acc[16];
+    {
+        const float2 d = valid ? D[pc] : make_float2(0.f, 0.f);
+        DH_UNROLL for (int corner = 0; corner < 8; ++corner) {
+            const int dx = corner & 1, dy = (corner >> 1) & 1, dz = corner >> 2;
+            const float wt = (dx ? w0[0] : 1.f - w0[0]) * (dy ? w0[1] : 1.f - w0[1]) * (dz ? w0[2] : 1.f - w0[2]);
+            acc[2 * corner] = wt * d.x; acc[2 * corner + 1] = wt * d.y;
+        }
+    }
+    DH_UNROLL for (int e = 1; e < HW_E; ++e) {
+        const int axis = (e - 1) >> 1;
+        const int64_t row = (int64_t)e * n + pc;
+        float xe[3] = {x0[0], x0[1], x0[2]};
+        DH_UNROLL for (int c = 0; c < 3; ++c) if (c == axis) xe[c] = X[row * 3 + c];
+        uint32_t g[3];
+        float w[3];
+        hg_cell(H, l, xe, g, w);
+        const float2 d = valid ? D[row] : make_float2(0.f, 0.f);
+        const bool same = MODE != 2 && g[0] == g0[0] && g[1] == g0[1] && g[2] == g0[2];
+        const float2 dm = same ? d : make_float2(0.f, 0.f);     // branch-free blend into the centre cell's corners
+        DH_UNROLL for (int corner = 0; corner < 8; ++corner) {
+            const int dx = corner & 1, dy = (corner >> 1) & 1, dz = corner >> 2;
+            const float wt = (dx ? w[0] : 1.f - w[0]) * (dy ? w[1] : 1.f - w[1]) * (dz ? w[2] : 1.f - w[2]);
+            acc[2 * corner] = fmaf(wt, dm.x, acc[2 * corner]); acc[2 * corner + 1] = fmaf(wt, dm.y, acc[2 * corner + 1]);
+        }
+        if (!same && valid) {
+            DH_UNROLL for (int corner = 0; corner < 8; ++corner) {
+                const int dx = corner & 1, dy = (corner >> 1) & 1, dz = corner >> 2;
+                const float wt = (dx ? w[0] : 1.f - w[0]) * (dy ? w[1] : 1.f - w[1]) * (dz ? w[2] : 1.f - w[2]);
+                const uint32_t idx = hg_index(H, l, g[0] + dx, g[1] + dy, g[2] + dz);
+                atomicAdd(d_table + (size_t)idx * HG_F + 0, wt * d.x);
+                atomicAdd(d_table + (size_t)idx * HG_F + 1, wt * d.y);
+            }
+        }
+    }
+    // (b) segmented sum over runs of lanes sharing the centre cell
+    // keys are the full uint32 cell coordinates (out-of-box samples wrap to large values: no packing); invalid lanes
+    // get a key no neighbour shares
+    const uint32_t k0 = valid ? g0[0] : 0x80000000u + (uint32_t)lane, k1 = g0[1], k2 = g0[2];
+    // every shuffle executes on all lanes (no short-circuit around a cross-lane read)
+    const uint32_t p0 = __shfl_up(k0, 1), p1 = __shfl_up(k1, 1), p2 = __shfl_up(k2, 1);
+    const uint32_t n0 = __shfl_down(k0, 1), n1 = __shfl_down(k1, 1), n2 = __shfl_down(k2, 1);
+    const bool eq_prev = ((p0 ^ k0) | (p1 ^ k1) | (p2 ^ k2)) == 0u;
+    const bool eq_next = ((n0 ^ k0) | (n1 ^ k1) | (n2 ^ k2)) == 0u;
+    const bool head = MODE == 1 || lane == 0 || !eq_prev;
+    const bool tail = MODE == 1 || lane == 63 || !eq_next;
+    int start = head ? lane : 0;
+    DH_UNROLL for (int off = 1; off < 64; off <<= 1) {
+        const int t = __shfl_up(start, off);
+        if (lane >= off) start = max(start, t);
+    }
+    DH_UNROLL for (int off = 1; off < 64; off <<= 1) {
+        const bool take = lane - off >= start;
+        DH_UNROLL for (int q = 0; q < 16; ++q) {
+            const float t = __shfl_up(acc[q], off);
+            acc[q] += take ? t : 0.f;
+        }
+    }
+    if (valid && tail) {
+        DH_UNROLL for (int corner = 0; corner < 8; ++corner) {
+            const int dx = corner & 1, dy = (corner >> 1) & 1, dz = corner >> 2;
+            const uint32_t idx = hg_index(H, l, g0[0] + dx, g0[1] + dy, g0[2] + dz);
+            atomicAdd(d_table + (size_t)idx * HG_F + 0, acc[2 * corner]);
+            atomicAdd(d_table + (size_t)idx * HG_F + 1, acc[2 * corner + 1]);
+        }
     }
 }
 
@@ -502,7 +602,11 @@ int launch_hash_weight_grads(const float* params, const float* hp, int64_t n, fl
     hipLaunchKernelGGL(hash_fold_kernel, dim3(64, HW_JOBS), dim3(64), 0, st, params, hp, dwsum, P, grad);
     // table: scatter the encoding adjoint of all E n evaluations
     if (hipMemsetAsync(grad + P.table, 0, (size_t)hashgrid_entries() * 2 * sizeof(float), st) != hipSuccess) return -3;
-    if (launch_hashgrid_bwd(ws + O.x01, ws + O.din, en, grad + P.table, st)) return -3;
+    static const int mode = getenv("DH_HASH_SCATTER_MODE") ? atoi(getenv("DH_HASH_SCATTER_MODE")) : 0;
+    const dim3 grid((unsigned)((n + 255) / 256), HG_L);
+    if (mode == 1) hipLaunchKernelGGL(hash_table_bwd_kernel<1>, grid, dim3(256), 0, st, hashgrid_levels(), ws, O, n, grad + P.table);
+    else if (mode == 2) hipLaunchKernelGGL(hash_table_bwd_kernel<2>, grid, dim3(256), 0, st, hashgrid_levels(), ws, O, n, grad + P.table);
+    else hipLaunchKernelGGL(hash_table_bwd_kernel<0>, grid, dim3(256), 0, st, hashgrid_levels(), ws, O, n, grad + P.table);
     return ok();
 }
 

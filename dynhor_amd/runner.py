@@ -30,7 +30,9 @@ DEFAULT_CONF = {
               "warm_up_end": 5000, "anneal_end": 50000, "igr_weight": 0.1, "mask_weight": 0.1, "normal_weight": 0.0,
               "save_freq": 10000, "val_freq": 2500, "report_freq": 100, "use_white_bkgd": False, "keep_only": False,
               "seed": 1234, "ray_seed": 4321},
-    "model": {"sdf_network": {}, "variance_network": {"init_val": 0.3}, "rendering_network": {},
+    # family "neus": the 8x256 / 4x256 fp32 MLPs (BASELINE.json configs[1]); "hash": hash-grid + shallow MLPs (configs[3])
+    "model": {"family": "neus", "sdf_network": {}, "variance_network": {"init_val": 0.3}, "rendering_network": {},
+              "hash_sdf_network": {}, "sh_rendering_network": {},
               "neus_renderer": {"n_samples": 64, "n_importance": 64, "n_outside": 0, "up_sample_steps": 4, "perturb": 1.0}},
 }
 
@@ -82,12 +84,22 @@ class Runner:
 
         with torch.random.fork_rng(devices=[]):
             torch.manual_seed(tr["seed"])          # identical initial weights on every rank
-            self.sdf_network = SDFNetwork(**self.conf["model"]["sdf_network"])
-            self.color_network = RenderingNetwork(**self.conf["model"]["rendering_network"])
+            family = self.conf["model"]["family"]
+            if family == "neus":
+                self.sdf_network = SDFNetwork(**self.conf["model"]["sdf_network"])
+                self.color_network = RenderingNetwork(**self.conf["model"]["rendering_network"])
+                store_cls, renderer_cls = ParamStore, NeuSRenderer
+            elif family == "hash":
+                from .hash_fields import HashNeuSRenderer, HashParamStore, HashSDFNetwork, SHRenderingNetwork
+                self.sdf_network = HashSDFNetwork(**self.conf["model"]["hash_sdf_network"])
+                self.color_network = SHRenderingNetwork(**self.conf["model"]["sh_rendering_network"])
+                store_cls, renderer_cls = HashParamStore, HashNeuSRenderer
+            else:
+                raise ValueError(f"model.family must be 'neus' or 'hash', got {family!r}")
             self.deviation_network = SingleVarianceNetwork(**self.conf["model"]["variance_network"])
         self.nerf_outside = None
-        self.store = ParamStore(self.sdf_network, self.deviation_network, self.color_network, self.device)
-        self.renderer = NeuSRenderer(self.nerf_outside, self.sdf_network, self.deviation_network, self.color_network,
+        self.store = store_cls(self.sdf_network, self.deviation_network, self.color_network, self.device)
+        self.renderer = renderer_cls(self.nerf_outside, self.sdf_network, self.deviation_network, self.color_network,
                                      store=self.store, device=self.device, **self.conf["model"]["neus_renderer"])
         self.ray_gen = torch.Generator(device=self.device)
         self.ray_gen.manual_seed(tr["ray_seed"] * 1000003 + self.rank)
