@@ -169,36 +169,41 @@ __global__ __launch_bounds__(256) void sh_color_fwd_kernel(const float* __restri
 }
 
 // ================================================================ backward
-// Workspace (floats, per point-count n; E = 7 geometry evaluations: centre, then +-eps per axis):
-//   colour  : DO [n][4] | H2 [n][64] | DZ2 [n][64] | H1 [n][64] | DZ1 [n][64] | CIN [n][32]
-//   geometry: X01 [E n][3] | DIN [E n][32] | DOUT [E n][16] | HH [E n][64] | DA [E n][64] | GIN [E n][36]
+// Workspace (floats, per point-count n; E = 7 geometry evaluations: centre, then +-eps per axis).  Everything is
+// FEATURE-MAJOR ([feature][row], row stride ld = rows rounded up to 8) so the per-point kernels (lane = row) write
+// full 256-B segments and small_dw_kernel reads 16-B row quads:
+//   colour  : DO [4][ldn] | H2 [64][ldn] | DZ2 [64][ldn] | H1 [64][ldn] | DZ1 [64][ldn] | CIN [32][ldn]
+//   geometry: X01 [3][lde] | DIN [16 levels][E n] float2 | DOUT [16][lde] | HH [64][lde] | DA [64][lde] | GIN [36][lde]
 //   partial weight-gradient slabs
-// The per-point kernels recompute the (tiny) forward and write each layer's input and pre-activation adjoint row-major;
-// the weight gradients are then plain  dW = sum_p dz[p]^T in[p]  reductions done by small_dw_kernel on MFMA, reading
-// the rows straight into the 32x32x2 operand layout (lane = feature, coalesced 128-B rows).
+// The per-point kernels recompute the (tiny) forward and leave each layer's input and pre-activation adjoint; the
+// weight gradients are then plain  dW = sum_p dz[p]^T in[p]  reductions done by small_dw_kernel on MFMA.
 struct HashWs {
     int64_t d_o, h2, dz2, h1, dz1, cin, x01, din, dout, hh, da, gin, slabs, total;
+    int64_t ldn, lde;
 };
 constexpr int HW_E = 7;
-constexpr int HW_SLABS = 512;                    // partial-sum slabs of the weight-gradient reductions
+constexpr int HW_SLABS = 1024;                   // partial-sum slabs of the weight-gradient reductions
 constexpr int HW_DW_FLOATS = 64 * 64 + 64;       // one job's slab: padded [64][64] tile + column sums
 constexpr int HW_JOBS = 5;
 inline HashWs make_hash_ws(int64_t n) {
     HashWs w{};
     int64_t o = 0;
     auto take = [&](int64_t cnt) { int64_t r = o; o += (cnt + 63) / 64 * 64; return r; };
-    w.d_o = take(n * 4); w.h2 = take(n * 64); w.dz2 = take(n * 64); w.h1 = take(n * 64); w.dz1 = take(n * 64);
-    w.cin = take(n * 32);
-    w.x01 = take(HW_E * n * 3); w.din = take(HW_E * n * 32); w.dout = take(HW_E * n * 16); w.hh = take(HW_E * n * 64);
-    w.da = take(HW_E * n * 64); w.gin = take(HW_E * n * 36);
+    w.ldn = (n + 7) / 8 * 8;
+    w.lde = (HW_E * n + 7) / 8 * 8;
+    w.d_o = take(w.ldn * 4); w.h2 = take(w.ldn * 64); w.dz2 = take(w.ldn * 64); w.h1 = take(w.ldn * 64);
+    w.dz1 = take(w.ldn * 64); w.cin = take(w.ldn * 32);
+    w.x01 = take(w.lde * 3); w.din = take(HW_E * n * 32); w.dout = take(w.lde * 16); w.hh = take(w.lde * 64);
+    w.da = take(w.lde * 64); w.gin = take(w.lde * 36);
     w.slabs = take((int64_t)HW_JOBS * HW_SLABS * HW_DW_FLOATS);
     w.total = o;
     return w;
 }
 
-__device__ __forceinline__ void store_row(float* dst, const float* v, int n4) {
-    DH_UNROLL for (int i = 0; i < n4; ++i)
-        *reinterpret_cast<f32x4*>(dst + 4 * i) = f32x4{v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]};
+// feature-major store of a register row: element k of row r -> base[k * ld + r] (coalesced across lanes)
+template <int N>
+__device__ __forceinline__ void store_col(float* base, int64_t ld, int64_t r, const float (&v)[N], int cnt = N) {
+    DH_UNROLL for (int k = 0; k < N; ++k) if (k < cnt) base[k * ld + r] = v[k];
 }
 
 // colour network adjoint.  d_normals is read-modify-written (the render-scan adjoint is already in it).
@@ -221,7 +226,7 @@ __global__ __launch_bounds__(256) void sh_color_bwd_kernel(const float* __restri
         DH_UNROLL for (int c = 0; c < 16; ++c) in[HM_FEAT + c] = y[c];
     }
     DH_UNROLL for (int c = 0; c < 3; ++c) in[HM_FEAT + 16 + c] = normals[p * 3 + c];
-    store_row(ws + O.cin + p * 32, in, 8);
+    store_col(ws + O.cin, O.ldn, p, in);
     float h1[HM_HID];
     DH_UNROLL for (int j = 0; j < HM_HID; ++j) {
         const f32x4* wr = reinterpret_cast<const f32x4*>(W + HP_C0 + j * HM_CIN);
@@ -233,7 +238,7 @@ __global__ __launch_bounds__(256) void sh_color_bwd_kernel(const float* __restri
         }
         h1[j] = fmaxf(a, 0.f);
     }
-    store_row(ws + O.h1 + p * 64, h1, 16);
+    store_col(ws + O.h1, O.ldn, p, h1);
     // pass 1 over the second layer: the outputs
     float o[3] = {W[HP_C2B], W[HP_C2B + 1], W[HP_C2B + 2]};
     for (int j2 = 0; j2 < HM_HID; ++j2) {
@@ -253,12 +258,10 @@ __global__ __launch_bounds__(256) void sh_color_bwd_kernel(const float* __restri
         dob[c] = d_color[p * 3 + c] * col * (1.f - col);
     }
     dob[3] = 0.f;
-    store_row(ws + O.d_o + p * 4, dob, 1);
+    store_col(ws + O.d_o, O.ldn, p, dob);
     // pass 2: recompute h2 row by row, its adjoint, and pull back onto h1
     float dh1[HM_HID];
     DH_UNROLL for (int k = 0; k < HM_HID; ++k) dh1[k] = 0.f;
-    float* h2row = ws + O.h2 + p * 64;
-    float* dz2row = ws + O.dz2 + p * 64;
     for (int j2 = 0; j2 < HM_HID; ++j2) {
         const f32x4* wr = reinterpret_cast<const f32x4*>(W + HP_C1 + j2 * 64);
         float a = W[HP_C1B + j2];
@@ -270,8 +273,8 @@ __global__ __launch_bounds__(256) void sh_color_bwd_kernel(const float* __restri
         const float h2 = fmaxf(a, 0.f);
         float dz2 = W[HP_C2 + j2] * dob[0] + W[HP_C2 + 64 + j2] * dob[1] + W[HP_C2 + 128 + j2] * dob[2];
         dz2 = a > 0.f ? dz2 : 0.f;
-        h2row[j2] = h2;
-        dz2row[j2] = dz2;
+        ws[O.h2 + j2 * O.ldn + p] = h2;
+        ws[O.dz2 + j2 * O.ldn + p] = dz2;
         DH_UNROLL for (int k4 = 0; k4 < 16; ++k4) {
             const f32x4 w = wr[k4];
             dh1[4 * k4] = fmaf(w[0], dz2, dh1[4 * k4]); dh1[4 * k4 + 1] = fmaf(w[1], dz2, dh1[4 * k4 + 1]);
@@ -279,7 +282,7 @@ __global__ __launch_bounds__(256) void sh_color_bwd_kernel(const float* __restri
         }
     }
     DH_UNROLL for (int k = 0; k < HM_HID; ++k) dh1[k] = h1[k] > 0.f ? dh1[k] : 0.f;     // now dz1
-    store_row(ws + O.dz1 + p * 64, dh1, 16);
+    store_col(ws + O.dz1, O.ldn, p, dh1);
     float din[HM_CIN];
     DH_UNROLL for (int k = 0; k < HM_CIN; ++k) din[k] = 0.f;
     DH_UNROLL for (int j = 0; j < HM_HID; ++j) {
@@ -325,14 +328,12 @@ __global__ __launch_bounds__(256) void hash_geo_bwd_kernel(HashLevels H, const f
         DH_UNROLL for (int c = 0; c < 3; ++c) { x01[c] = (xe[c] + radius) / (2.f * radius); in[c] = x01[c] * 2.f - 1.f; }
         DH_UNROLL for (int l = 0; l < HG_L; ++l) hg_encode_level(H, table, l, x01, in[3 + 2 * l], in[4 + 2 * l]);
         in[35] = 1.f;                                   // ones column: dW0[:,35] accumulates the bias gradient
-        store_row(ws + O.gin + row * 36, in, 9);
+        store_col(ws + O.gin, O.lde, row, in);
         in[35] = 0.f;
-        DH_UNROLL for (int c = 0; c < 3; ++c) ws[O.x01 + row * 3 + c] = x01[c];
-        store_row(ws + O.dout + row * 16, dout, 4);
+        store_col(ws + O.x01, O.lde, row, x01);
+        store_col(ws + O.dout, O.lde, row, dout);
         float din[36];
         DH_UNROLL for (int k = 0; k < 36; ++k) din[k] = 0.f;
-        float* hrow = ws + O.hh + row * 64;
-        float* darow = ws + O.da + row * 64;
         for (int j = 0; j < HM_HID; ++j) {
             const f32x4* wr = reinterpret_cast<const f32x4*>(W + HP_G0 + j * 36);
             float a = W[HP_G0B + j];
@@ -346,8 +347,8 @@ __global__ __launch_bounds__(256) void hash_geo_bwd_kernel(HashLevels H, const f
             if (e == 0) { DH_UNROLL for (int c = 0; c < HM_GOUT; ++c) dh = fmaf(W[HP_G1 + c * 64 + j], dout[c], dh); }
             else dh = W[HP_G1 + j] * dout[0];
             const float da = dh / (1.f + __builtin_amdgcn_exp2f(-a * (SOFTPLUS_BETA * 1.44269504088896f)));
-            hrow[j] = h;
-            darow[j] = da;
+            ws[O.hh + j * O.lde + row] = h;
+            ws[O.da + j * O.lde + row] = da;
             DH_UNROLL for (int k4 = 0; k4 < 9; ++k4) {
                 const f32x4 w = wr[k4];
                 din[4 * k4] = fmaf(w[0], da, din[4 * k4]); din[4 * k4 + 1] = fmaf(w[1], da, din[4 * k4 + 1]);
@@ -362,8 +363,9 @@ __global__ __launch_bounds__(256) void hash_geo_bwd_kernel(HashLevels H, const f
 
 // Table gradient: one thread per (point, level); grid.y = level, so a wave is 64 consecutive samples of one ray at
 // one level.  Two merges cut the float atomics the naive per-evaluation scatter (tcnn's scheme) would issue:
-//   (a) the E = 7 evaluations of a point (centre, +-eps per axis) that fall in the centre's cell are blended into the
-//       same 8 corner accumulators in registers (all of them at the coarse levels, none at the finest);
+//   (a) the corner planes of a point's E = 7 evaluations (centre, +-eps per axis) that coincide with corners of the
+//       centre's cell -- the whole cell when the evaluation stays inside it (coarse levels), the shared face when it
+//       lands in the neighbour (fine levels) -- are blended into the centre's 8 corner accumulators in registers;
 //   (b) consecutive samples of a ray that share a cell are summed across lanes (segmented scan, lane order = ray order)
 //       and only the last lane of each run issues the 16 atomics.
 __device__ __forceinline__ void hg_cell(const HashLevels& H, int l, const float (&x01)[3], uint32_t (&g)[3], float (&w)[3]) {
@@ -386,7 +388,7 @@ __global__ __launch_bounds__(256) void hash_table_bwd_kernel(HashLevels H, const
     const int64_t pc = valid ? p : n - 1;
     const float* X = ws + O.x01;
     const float2* D = reinterpret_cast<const float2*>(ws + O.din) + (int64_t)l * HW_E * n;
-    const float x0[3] = {X[pc * 3], X[pc * 3 + 1], X[pc * 3 + 2]};
+    const float x0[3] = {X[pc], X[O.lde + pc], X[2 * O.lde + pc]};
     uint32_t g0[3];
     float w0[3];
     hg_cell(H, l, x0, g0, w0);
@@ -399,29 +401,39 @@ __global__ __launch_bounds__(256) void hash_table_bwd_kernel(HashLevels H, const
             acc[2 * corner] = wt * d.x; acc[2 * corner + 1] = wt * d.y;
         }
     }
+    const float s = H.scale[l];
     DH_UNROLL for (int e = 1; e < HW_E; ++e) {
-        const int axis = (e - 1) >> 1;
+        // the +-eps evaluation along axis a sits in the centre's cell or one of its a-neighbours: its corner plane(s)
+        // that coincide with centre corners (all 8 when the cell is the same, the shared face when it is the
+        // neighbour) blend into the centre accumulators; only the plane(s) beyond go out as atomics of their own
+        const int a = (e - 1) >> 1, b = (a + 1) % 3, c = (a + 2) % 3;
         const int64_t row = (int64_t)e * n + pc;
-        float xe[3] = {x0[0], x0[1], x0[2]};
-        DH_UNROLL for (int c = 0; c < 3; ++c) if (c == axis) xe[c] = X[row * 3 + c];
-        uint32_t g[3];
-        float w[3];
-        hg_cell(H, l, xe, g, w);
+        const float pos = X[a * O.lde + row] * s + 0.5f;
+        const float fl = floorf(pos);
+        const float wa = pos - fl;
+        const uint32_t ga = (uint32_t)(int)fl;
+        const int delta = (int)(ga - g0[a]);
         const float2 d = valid ? D[row] : make_float2(0.f, 0.f);
-        const bool same = MODE != 2 && g[0] == g0[0] && g[1] == g0[1] && g[2] == g0[2];
-        const float2 dm = same ? d : make_float2(0.f, 0.f);     // branch-free blend into the centre cell's corners
-        DH_UNROLL for (int corner = 0; corner < 8; ++corner) {
-            const int dx = corner & 1, dy = (corner >> 1) & 1, dz = corner >> 2;
-            const float wt = (dx ? w[0] : 1.f - w[0]) * (dy ? w[1] : 1.f - w[1]) * (dz ? w[2] : 1.f - w[2]);
-            acc[2 * corner] = fmaf(wt, dm.x, acc[2 * corner]); acc[2 * corner + 1] = fmaf(wt, dm.y, acc[2 * corner + 1]);
-        }
-        if (!same && valid) {
-            DH_UNROLL for (int corner = 0; corner < 8; ++corner) {
-                const int dx = corner & 1, dy = (corner >> 1) & 1, dz = corner >> 2;
-                const float wt = (dx ? w[0] : 1.f - w[0]) * (dy ? w[1] : 1.f - w[1]) * (dz ? w[2] : 1.f - w[2]);
-                const uint32_t idx = hg_index(H, l, g[0] + dx, g[1] + dy, g[2] + dz);
-                atomicAdd(d_table + (size_t)idx * HG_F + 0, wt * d.x);
-                atomicAdd(d_table + (size_t)idx * HG_F + 1, wt * d.y);
+        DH_UNROLL for (int ba = 0; ba < 2; ++ba) {
+            const int t = delta + ba;                            // plane position relative to the centre cell: 0/1 = shared
+            const bool to_centre = MODE != 2 && (unsigned)t < 2u;
+            const float wpa = ba ? wa : 1.f - wa;
+            DH_UNROLL for (int bb = 0; bb < 2; ++bb) DH_UNROLL for (int bc = 0; bc < 2; ++bc) {
+                const float wt = wpa * (bb ? w0[b] : 1.f - w0[b]) * (bc ? w0[c] : 1.f - w0[c]);
+                const int c0 = (bb << b) | (bc << c), c1 = c0 | (1 << a);
+                const float m0 = (to_centre && t == 0) ? wt : 0.f, m1 = (to_centre && t == 1) ? wt : 0.f;
+                acc[2 * c0] = fmaf(m0, d.x, acc[2 * c0]); acc[2 * c0 + 1] = fmaf(m0, d.y, acc[2 * c0 + 1]);
+                acc[2 * c1] = fmaf(m1, d.x, acc[2 * c1]); acc[2 * c1 + 1] = fmaf(m1, d.y, acc[2 * c1 + 1]);
+            }
+            if (!to_centre && valid) {
+                DH_UNROLL for (int bb = 0; bb < 2; ++bb) DH_UNROLL for (int bc = 0; bc < 2; ++bc) {
+                    const float wt = wpa * (bb ? w0[b] : 1.f - w0[b]) * (bc ? w0[c] : 1.f - w0[c]);
+                    uint32_t cc[3];
+                    cc[a] = ga + ba; cc[b] = g0[b] + bb; cc[c] = g0[c] + bc;
+                    const uint32_t idx = hg_index(H, l, cc[0], cc[1], cc[2]);
+                    atomicAdd(d_table + (size_t)idx * HG_F + 0, wt * d.x);
+                    atomicAdd(d_table + (size_t)idx * HG_F + 1, wt * d.y);
+                }
             }
         }
     }
@@ -458,34 +470,42 @@ __global__ __launch_bounds__(256) void hash_table_bwd_kernel(HashLevels H, const
     }
 }
 
-// dW[m][k] = sum_p A[p][m] B[p][k]  (m < M <= 64, k < K <= 64), plus colsum[m] = sum_p A[p][m]; one wave per slab of
-// rows, fp32 MFMA 32x32x2 with the operands read from global directly in operand layout.
-struct SmallDwJob { int64_t a, b; int lda, ldb, M, K; int64_t rows; };
+// dW[m][k] = sum_r A[m][r] B[k][r]  (feature-major operands, m < M <= 64, k < K <= 64), plus colsum[m] = sum_r A[m][r];
+// one wave per slab of rows, fp32 MFMA 32x32x2: lane (i, kk) reads the 16-B quad rows r..r+3 (kk = 0) / r+4..r+7
+// (kk = 1) of feature i and feeds them to four MFMAs (contraction pairs (r+u, r+4+u)).
+struct SmallDwJob { int64_t a, b; int M, K; int64_t rows, ld; };
 struct SmallDwJobs { SmallDwJob j[HW_JOBS]; };
 
 __global__ __launch_bounds__(64) void small_dw_kernel(const float* __restrict__ ws, SmallDwJobs J, float* __restrict__ slabs) {
     const SmallDwJob job = J.j[blockIdx.y];
     const int lane = threadIdx.x, i = lane & 31, kk = lane >> 5;
-    const int64_t per = ((job.rows + HW_SLABS - 1) / HW_SLABS + 1) & ~int64_t(1);
+    const int64_t per = ((job.rows + HW_SLABS - 1) / HW_SLABS + 7) & ~int64_t(7);
     const int64_t r0 = (int64_t)blockIdx.x * per, r1 = r0 + per < job.rows ? r0 + per : job.rows;
     f32x16 acc[2][2];
     DH_UNROLL for (int a = 0; a < 2; ++a) DH_UNROLL for (int b = 0; b < 2; ++b) DH_UNROLL for (int q = 0; q < 16; ++q) acc[a][b][q] = 0.f;
     float cs[2] = {0.f, 0.f};
-    const float* A = ws + job.a;
-    const float* B = ws + job.b;
     const bool am0 = i < job.M, am1 = i + 32 < job.M, bk0 = i < job.K, bk1 = i + 32 < job.K;
-    for (int64_t rp = r0; rp < r1; rp += 2) {          // wave-uniform trip count: MFMA must not run under divergence
-        const int64_t r = rp + kk;
-        const bool v = r < r1;
-        const float a0 = (v && am0) ? A[r * job.lda + i] : 0.f;
-        const float a1 = (v && am1) ? A[r * job.lda + 32 + i] : 0.f;
-        const float b0 = (v && bk0) ? B[r * job.ldb + i] : 0.f;
-        const float b1 = (v && bk1) ? B[r * job.ldb + 32 + i] : 0.f;
-        cs[0] += a0; cs[1] += a1;
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+    const float* A0 = ws + job.a + (int64_t)(am0 ? i : 0) * job.ld + 4 * kk;
+    const float* A1 = ws + job.a + (int64_t)(am1 ? i + 32 : 0) * job.ld + 4 * kk;
+    const float* B0 = ws + job.b + (int64_t)(bk0 ? i : 0) * job.ld + 4 * kk;
+    const float* B1 = ws + job.b + (int64_t)(bk1 ? i + 32 : 0) * job.ld + 4 * kk;
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+    for (int64_t rp = r0; rp < r1; rp += 8) {            // wave-uniform trip count: MFMA must not run under divergence
+        f32x4 a0 = am0 ? *reinterpret_cast<const f32x4*>(A0 + rp) : z4;
+        f32x4 a1 = am1 ? *reinterpret_cast<const f32x4*>(A1 + rp) : z4;
+        f32x4 b0 = bk0 ? *reinterpret_cast<const f32x4*>(B0 + rp) : z4;
+        f32x4 b1 = bk1 ? *reinterpret_cast<const f32x4*>(B1 + rp) : z4;
+        if (rp + 8 > r1) {                               // ragged tail: rows past the end hold garbage
+            DH_UNROLL for (int u = 0; u < 4; ++u)
+                if (rp + 4 * kk + u >= r1) { a0[u] = 0.f; a1[u] = 0.f; b0[u] = 0.f; b1[u] = 0.f; }
+        }
+        DH_UNROLL for (int u = 0; u < 4; ++u) {
+            cs[0] += a0[u]; cs[1] += a1[u];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[u], b0[u], acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[u], b1[u], acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[u], b0[u], acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[u], b1[u], acc[1][1], 0, 0, 0);
+        }
     }
     float* out = slabs + ((int64_t)blockIdx.y * HW_SLABS + blockIdx.x) * HW_DW_FLOATS;
     DH_UNROLL for (int a = 0; a < 2; ++a) DH_UNROLL for (int b = 0; b < 2; ++b) DH_UNROLL for (int q = 0; q < 16; ++q) {
@@ -590,11 +610,11 @@ int launch_hash_weight_grads(const float* params, const float* hp, int64_t n, fl
     const HashParamOff P = hash_param_off();
     const int64_t en = (int64_t)HW_E * n;
     SmallDwJobs J;
-    J.j[0] = {O.da, O.gin, 64, 36, 64, 36, en};        // geometry lin0 (ones column -> bias)
-    J.j[1] = {O.dout, O.hh, 16, 64, HM_GOUT, 64, en};  // geometry lin1
-    J.j[2] = {O.dz1, O.cin, 64, 32, 64, 32, n};        // colour lin0
-    J.j[3] = {O.dz2, O.h1, 64, 64, 64, 64, n};         // colour lin1
-    J.j[4] = {O.d_o, O.h2, 4, 64, 3, 64, n};           // colour lin2
+    J.j[0] = {O.da, O.gin, 64, 36, en, O.lde};         // geometry lin0 (ones column -> bias)
+    J.j[1] = {O.dout, O.hh, HM_GOUT, 64, en, O.lde};   // geometry lin1
+    J.j[2] = {O.dz1, O.cin, 64, 32, n, O.ldn};         // colour lin0
+    J.j[3] = {O.dz2, O.h1, 64, 64, n, O.ldn};          // colour lin1
+    J.j[4] = {O.d_o, O.h2, 3, 64, n, O.ldn};           // colour lin2
     float* slabs = ws + O.slabs;
     float* dwsum = ws + O.total;
     hipLaunchKernelGGL(small_dw_kernel, dim3(HW_SLABS, HW_JOBS), dim3(64), 0, st, ws, J, slabs);

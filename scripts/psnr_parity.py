@@ -8,6 +8,7 @@ import torch
 from dynhor_amd.runner import Runner
 from dynhor_amd import schedules
 from oracle import neus_oracle as O
+from oracle import hashgrid_oracle as HO
 
 
 def val_psnr(render_fn, ds, frames, level):
@@ -31,6 +32,8 @@ def main():
     ap.add_argument("--res", type=int, default=512)
     ap.add_argument("--seed", type=int, default=777, help="ray / perturbation RNG seed (shared by both paths)")
     ap.add_argument("--weight-seed", type=int, default=1234)
+    ap.add_argument("--family", choices=["neus", "hash"], default="neus", help="model family (BASELINE.json configs[1] / configs[3])")
+    ap.add_argument("--lr", type=float, default=5e-4)
     ap.add_argument("--noise-floor", action="store_true",
                     help="replace the HIP path by a SECOND oracle whose initial weights differ by 1e-7 relative: how far apart do two fp32 runs of the oracle itself land?")
     ap.add_argument("--out", type=str, default=os.path.join(ROOT, "profiles", "psnr_parity_r01.json"))
@@ -39,24 +42,31 @@ def main():
     conf = {"seq_name": "psnr_parity", "exp_name": "hip",
             "data_info": {"synthetic": {"n_frames": args.frames, "H": args.res, "W": args.res, "seed": 4321}},
             "train": {"batch_size": args.batch, "normal_weight": 0.05, "report_freq": 10 ** 9, "save_freq": 10 ** 9,
-                      "val_freq": 0, "end_iter": 300000, "warm_up_end": 5000, "anneal_end": 50000, "seed": args.weight_seed}}
+                      "val_freq": 0, "end_iter": 300000, "warm_up_end": 5000, "anneal_end": 50000, "seed": args.weight_seed},
+            "model": {"family": args.family}}
     runner = Runner(conf=conf, device=dev, exp_root="/tmp/dynhor_psnr")
     ds = runner.dataset
     # oracle twin: identical initial weights
-    o_sdf, o_col, o_var = O.build_models(seed=1234, device=dev)
+    def build_oracle_models():
+        if args.family == "hash":
+            a, b = HO.build_models(seed=1234, device=dev)
+            return a, b, O.SingleVarianceNetwork(0.3).to(dev)
+        return O.build_models(seed=1234, device=dev)
+
+    o_sdf, o_col, o_var = build_oracle_models()
     o_sdf.load_state_dict(runner.sdf_network.state_dict()); o_col.load_state_dict(runner.color_network.state_dict())
     o_var.load_state_dict(runner.deviation_network.state_dict())
     o_r = O.NeuSRenderer(None, o_sdf, o_var, o_col, 64, 64, 0, 4, 1.0)
-    opt = torch.optim.Adam(list(o_sdf.parameters()) + list(o_var.parameters()) + list(o_col.parameters()), lr=5e-4)
+    opt = torch.optim.Adam(list(o_sdf.parameters()) + list(o_var.parameters()) + list(o_col.parameters()), lr=args.lr)
     if args.noise_floor:
-        t_sdf, t_col, t_var = O.build_models(seed=1234, device=dev)
+        t_sdf, t_col, t_var = build_oracle_models()
         t_sdf.load_state_dict(o_sdf.state_dict()); t_col.load_state_dict(o_col.state_dict()); t_var.load_state_dict(o_var.state_dict())
         with torch.no_grad():
             gp = torch.Generator(device=dev); gp.manual_seed(5)
             for p in list(t_sdf.parameters()) + list(t_col.parameters()):
                 p.mul_(1.0 + 1e-7 * torch.randn(p.shape, device=dev, generator=gp))
         t_r = O.NeuSRenderer(None, t_sdf, t_var, t_col, 64, 64, 0, 4, 1.0)
-        t_opt = torch.optim.Adam(list(t_sdf.parameters()) + list(t_var.parameters()) + list(t_col.parameters()), lr=5e-4)
+        t_opt = torch.optim.Adam(list(t_sdf.parameters()) + list(t_var.parameters()) + list(t_col.parameters()), lr=args.lr)
     perm = runner.image_perm.clone()
     gen_h = torch.Generator(device=dev); gen_h.manual_seed(args.seed)
     gen_o = torch.Generator(device=dev); gen_o.manual_seed(args.seed)
@@ -72,7 +82,7 @@ def main():
     for it in range(args.iters):
         frame = int(perm[it % ds.n_images])
         car = schedules.cos_anneal_ratio(it, 50000)
-        lr = 5e-4 * (schedules.lr_factor(it, 5000, 300000, 0.05) if it > 0 else 1.0 / 5000)
+        lr = args.lr * (schedules.lr_factor(it, 5000, 300000, 0.05) if it > 0 else 1.0 / 5000)
         # ---- HIP path
         torch.cuda.synchronize(); t0 = time.perf_counter()
         px, py, tr = draw(gen_h)
@@ -129,7 +139,7 @@ def main():
 
     p_h = val_psnr(render_twin if args.noise_floor else render_hip, ds, frames, 4)
     p_o = val_psnr(render_orc, ds, frames, 4)
-    res = {"seed": args.seed, "weight_seed": args.weight_seed, "iters": args.iters, "batch": args.batch, "frames": args.frames, "res": args.res,
+    res = {"family": args.family, "lr": args.lr, "seed": args.seed, "weight_seed": args.weight_seed, "iters": args.iters, "batch": args.batch, "frames": args.frames, "res": args.res,
            "mode": "noise_floor: oracle vs 1e-7-perturbed oracle" if args.noise_floor else "hip vs oracle", "val_psnr_hip": p_h, "val_psnr_oracle_gpu_eager": p_o, "abs_diff_db": abs(p_h - p_o),
            "sec_per_iter_hip": t_h / args.iters, "sec_per_iter_oracle_gpu_eager": t_o / args.iters,
            "note": "oracle = this repo's PyTorch restatement of NeuS (parity unpinned at the reference)", "curve": curve}
