@@ -361,13 +361,20 @@ __global__ __launch_bounds__(256) void hash_geo_bwd_kernel(HashLevels H, const f
     }
 }
 
-// Table gradient: one thread per (point, level); grid.y = level, so a wave is 64 consecutive samples of one ray at
-// one level.  Two merges cut the float atomics the naive per-evaluation scatter (tcnn's scheme) would issue:
-//   (a) the corner planes of a point's E = 7 evaluations (centre, +-eps per axis) that coincide with corners of the
-//       centre's cell -- the whole cell when the evaluation stays inside it (coarse levels), the shared face when it
-//       lands in the neighbour (fine levels) -- are blended into the centre's 8 corner accumulators in registers;
-//   (b) consecutive samples of a ray that share a cell are summed across lanes (segmented scan, lane order = ray order)
-//       and only the last lane of each run issues the 16 atomics.
+// Table gradient.  Float atomics execute at the memory side in 64-B requests (MI355X_MICROARCH.md "Global float
+// atomics": ~20 G requests/s chip-wide when every lane hits its own segment), so the kernel is built to issue as few
+// 64-B requests as possible:
+//   * four lanes per (point, level): lane (dx, f) owns feature f of the corners with x-offset dx, so the two features of
+//     an entry and -- hash prime 1 on x / dense x-major order -- with probability 7/8 its x-neighbour entry fall in one
+//     request of the same wave instruction;
+//   * (a) the corner planes of a point's E = 7 evaluations (centre, +-eps per axis) that coincide with corners of the
+//     centre's cell -- the whole cell when the evaluation stays inside it (coarse levels), the shared face when it
+//     lands in the neighbour (fine levels) -- are blended into the centre's accumulators in registers;
+//   * (b) consecutive samples of a ray that share a cell are summed across lanes (segmented scan over quads, lane order
+//     = ray order; grid.y = level, so a wave is 16 consecutive samples at one level) and only the last quad of each run
+//     issues the centre's atomics.
+// Against the per-evaluation scatter (tcnn's scheme: E x 8 corners x 2 features atomics per point and level) this is
+// 24.9 ms -> see DESIGN.md for the measured ladder.  DH_HASH_SCATTER_MODE=1 / 2 switch (b) / (a) off for ablation.
 __device__ __forceinline__ void hg_cell(const HashLevels& H, int l, const float (&x01)[3], uint32_t (&g)[3], float (&w)[3]) {
     const float s = H.scale[l];
     DH_UNROLL for (int c = 0; c < 3; ++c) {
@@ -383,89 +390,96 @@ __global__ __launch_bounds__(256) void hash_table_bwd_kernel(HashLevels H, const
                                                              float* __restrict__ d_table) {
     const int l = blockIdx.y;
     const int lane = threadIdx.x & 63;
-    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t p = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 2;
+    const int dx = (threadIdx.x >> 1) & 1, f = threadIdx.x & 1;
     const bool valid = p < n;
     const int64_t pc = valid ? p : n - 1;
     const float* X = ws + O.x01;
-    const float2* D = reinterpret_cast<const float2*>(ws + O.din) + (int64_t)l * HW_E * n;
+    const float* D = ws + O.din + (int64_t)l * HW_E * n * 2 + f;          // feature f of the level-major float2 rows
+    float* T = d_table + f;
     const float x0[3] = {X[pc], X[O.lde + pc], X[2 * O.lde + pc]};
     uint32_t g0[3];
     float w0[3];
     hg_cell(H, l, x0, g0, w0);
-    float acc[16];
+    const float wx = dx ? w0[0] : 1.f - w0[0];
+    float acc[4];                                                          // centre corners (dx, dy, dz): index dy + 2 dz
     {
-        const float2 d = valid ? D[pc] : make_float2(0.f, 0.f);
-        DH_UNROLL for (int corner = 0; corner < 8; ++corner) {
-            const int dx = corner & 1, dy = (corner >> 1) & 1, dz = corner >> 2;
-            const float wt = (dx ? w0[0] : 1.f - w0[0]) * (dy ? w0[1] : 1.f - w0[1]) * (dz ? w0[2] : 1.f - w0[2]);
-            acc[2 * corner] = wt * d.x; acc[2 * corner + 1] = wt * d.y;
-        }
+        const float d = valid ? D[pc * 2] : 0.f;
+        DH_UNROLL for (int k = 0; k < 4; ++k)
+            acc[k] = wx * ((k & 1) ? w0[1] : 1.f - w0[1]) * ((k >> 1) ? w0[2] : 1.f - w0[2]) * d;
     }
     const float s = H.scale[l];
     DH_UNROLL for (int e = 1; e < HW_E; ++e) {
-        // the +-eps evaluation along axis a sits in the centre's cell or one of its a-neighbours: its corner plane(s)
-        // that coincide with centre corners (all 8 when the cell is the same, the shared face when it is the
-        // neighbour) blend into the centre accumulators; only the plane(s) beyond go out as atomics of their own
-        const int a = (e - 1) >> 1, b = (a + 1) % 3, c = (a + 2) % 3;
+        const int a = (e - 1) >> 1;
         const int64_t row = (int64_t)e * n + pc;
         const float pos = X[a * O.lde + row] * s + 0.5f;
         const float fl = floorf(pos);
         const float wa = pos - fl;
         const uint32_t ga = (uint32_t)(int)fl;
         const int delta = (int)(ga - g0[a]);
-        const float2 d = valid ? D[row] : make_float2(0.f, 0.f);
+        const float d = valid ? D[row * 2] : 0.f;
         DH_UNROLL for (int ba = 0; ba < 2; ++ba) {
-            const int t = delta + ba;                            // plane position relative to the centre cell: 0/1 = shared
+            const int t = delta + ba;                    // plane position relative to the centre cell: 0 / 1 = shared
             const bool to_centre = MODE != 2 && (unsigned)t < 2u;
-            const float wpa = ba ? wa : 1.f - wa;
-            DH_UNROLL for (int bb = 0; bb < 2; ++bb) DH_UNROLL for (int bc = 0; bc < 2; ++bc) {
-                const float wt = wpa * (bb ? w0[b] : 1.f - w0[b]) * (bc ? w0[c] : 1.f - w0[c]);
-                const int c0 = (bb << b) | (bc << c), c1 = c0 | (1 << a);
-                const float m0 = (to_centre && t == 0) ? wt : 0.f, m1 = (to_centre && t == 1) ? wt : 0.f;
-                acc[2 * c0] = fmaf(m0, d.x, acc[2 * c0]); acc[2 * c0 + 1] = fmaf(m0, d.y, acc[2 * c0 + 1]);
-                acc[2 * c1] = fmaf(m1, d.x, acc[2 * c1]); acc[2 * c1 + 1] = fmaf(m1, d.y, acc[2 * c1 + 1]);
-            }
-            if (!to_centre && valid) {
-                DH_UNROLL for (int bb = 0; bb < 2; ++bb) DH_UNROLL for (int bc = 0; bc < 2; ++bc) {
-                    const float wt = wpa * (bb ? w0[b] : 1.f - w0[b]) * (bc ? w0[c] : 1.f - w0[c]);
-                    uint32_t cc[3];
-                    cc[a] = ga + ba; cc[b] = g0[b] + bb; cc[c] = g0[c] + bc;
-                    const uint32_t idx = hg_index(H, l, cc[0], cc[1], cc[2]);
-                    atomicAdd(d_table + (size_t)idx * HG_F + 0, wt * d.x);
-                    atomicAdd(d_table + (size_t)idx * HG_F + 1, wt * d.y);
+            const float wpa = (ba ? wa : 1.f - wa) * d;
+            if (a == 0) {
+                // plane of constant x: the lanes whose dx equals t own the matching centre corners
+                const float m = (to_centre && t == dx) ? wpa : 0.f;
+                DH_UNROLL for (int k = 0; k < 4; ++k)
+                    acc[k] = fmaf(m, ((k & 1) ? w0[1] : 1.f - w0[1]) * ((k >> 1) ? w0[2] : 1.f - w0[2]), acc[k]);
+                if (!to_centre && valid) {               // outer plane: the quad's dx bit picks the y half instead
+                    DH_UNROLL for (int bz = 0; bz < 2; ++bz) {
+                        const float wt = wpa * (dx ? w0[1] : 1.f - w0[1]) * (bz ? w0[2] : 1.f - w0[2]);
+                        const uint32_t idx = hg_index(H, l, ga + ba, g0[1] + dx, g0[2] + bz);
+                        atomicAdd(T + (size_t)idx * HG_F, wt);
+                    }
+                }
+            } else {
+                // plane of constant y (a = 1) or z (a = 2); o = the other in-plane axis besides x
+                const int o = a == 1 ? 2 : 1;
+                DH_UNROLL for (int bo = 0; bo < 2; ++bo) {
+                    const float wt = wx * wpa * (bo ? w0[o] : 1.f - w0[o]);
+                    const int k0 = a == 1 ? 2 * bo : bo, k1 = a == 1 ? 1 + 2 * bo : bo + 2;   // centre corner with bit_a = 0 / 1
+                    acc[k0] += (to_centre && t == 0) ? wt : 0.f;
+                    acc[k1] += (to_centre && t == 1) ? wt : 0.f;
+                }
+                if (!to_centre && valid) {
+                    DH_UNROLL for (int bo = 0; bo < 2; ++bo) {
+                        const float wt = wx * wpa * (bo ? w0[o] : 1.f - w0[o]);
+                        uint32_t cc[3];
+                        cc[0] = g0[0] + dx; cc[a] = ga + ba; cc[o] = g0[o] + bo;
+                        const uint32_t idx = hg_index(H, l, cc[0], cc[1], cc[2]);
+                        atomicAdd(T + (size_t)idx * HG_F, wt);
+                    }
                 }
             }
         }
     }
-    // (b) segmented sum over runs of lanes sharing the centre cell
-    // keys are the full uint32 cell coordinates (out-of-box samples wrap to large values: no packing); invalid lanes
-    // get a key no neighbour shares
+    // (b) segmented sum over runs of quads sharing the centre cell.  Keys are the full uint32 cell coordinates
+    // (out-of-box samples wrap to large values: no packing); every shuffle executes on all lanes.
     const uint32_t k0 = valid ? g0[0] : 0x80000000u + (uint32_t)lane, k1 = g0[1], k2 = g0[2];
-    // every shuffle executes on all lanes (no short-circuit around a cross-lane read)
-    const uint32_t p0 = __shfl_up(k0, 1), p1 = __shfl_up(k1, 1), p2 = __shfl_up(k2, 1);
-    const uint32_t n0 = __shfl_down(k0, 1), n1 = __shfl_down(k1, 1), n2 = __shfl_down(k2, 1);
+    const uint32_t p0 = __shfl_up(k0, 4), p1 = __shfl_up(k1, 4), p2 = __shfl_up(k2, 4);
+    const uint32_t n0 = __shfl_down(k0, 4), n1 = __shfl_down(k1, 4), n2 = __shfl_down(k2, 4);
     const bool eq_prev = ((p0 ^ k0) | (p1 ^ k1) | (p2 ^ k2)) == 0u;
     const bool eq_next = ((n0 ^ k0) | (n1 ^ k1) | (n2 ^ k2)) == 0u;
-    const bool head = MODE == 1 || lane == 0 || !eq_prev;
-    const bool tail = MODE == 1 || lane == 63 || !eq_next;
-    int start = head ? lane : 0;
-    DH_UNROLL for (int off = 1; off < 64; off <<= 1) {
-        const int t = __shfl_up(start, off);
-        if (lane >= off) start = max(start, t);
+    const bool head = MODE == 1 || lane < 4 || !eq_prev;
+    const bool tail = MODE == 1 || lane >= 60 || !eq_next;
+    int start = head ? lane : 0;                          // first lane (same sub-lane) of this quad's run
+    DH_UNROLL for (int off = 4; off < 64; off <<= 1) {
+        const int tt = __shfl_up(start, off);
+        if (lane >= off) start = max(start, (tt & ~3) | (lane & 3));
     }
-    DH_UNROLL for (int off = 1; off < 64; off <<= 1) {
+    DH_UNROLL for (int off = 4; off < 64; off <<= 1) {
         const bool take = lane - off >= start;
-        DH_UNROLL for (int q = 0; q < 16; ++q) {
-            const float t = __shfl_up(acc[q], off);
-            acc[q] += take ? t : 0.f;
+        DH_UNROLL for (int q = 0; q < 4; ++q) {
+            const float tq = __shfl_up(acc[q], off);
+            acc[q] += take ? tq : 0.f;
         }
     }
     if (valid && tail) {
-        DH_UNROLL for (int corner = 0; corner < 8; ++corner) {
-            const int dx = corner & 1, dy = (corner >> 1) & 1, dz = corner >> 2;
-            const uint32_t idx = hg_index(H, l, g0[0] + dx, g0[1] + dy, g0[2] + dz);
-            atomicAdd(d_table + (size_t)idx * HG_F + 0, acc[2 * corner]);
-            atomicAdd(d_table + (size_t)idx * HG_F + 1, acc[2 * corner + 1]);
+        DH_UNROLL for (int k = 0; k < 4; ++k) {
+            const uint32_t idx = hg_index(H, l, g0[0] + dx, g0[1] + (k & 1), g0[2] + (k >> 1));
+            atomicAdd(T + (size_t)idx * HG_F, acc[k]);
         }
     }
 }
@@ -623,7 +637,7 @@ int launch_hash_weight_grads(const float* params, const float* hp, int64_t n, fl
     // table: scatter the encoding adjoint of all E n evaluations
     if (hipMemsetAsync(grad + P.table, 0, (size_t)hashgrid_entries() * 2 * sizeof(float), st) != hipSuccess) return -3;
     static const int mode = getenv("DH_HASH_SCATTER_MODE") ? atoi(getenv("DH_HASH_SCATTER_MODE")) : 0;
-    const dim3 grid((unsigned)((n + 255) / 256), HG_L);
+    const dim3 grid((unsigned)((4 * n + 255) / 256), HG_L);
     if (mode == 1) hipLaunchKernelGGL(hash_table_bwd_kernel<1>, grid, dim3(256), 0, st, hashgrid_levels(), ws, O, n, grad + P.table);
     else if (mode == 2) hipLaunchKernelGGL(hash_table_bwd_kernel<2>, grid, dim3(256), 0, st, hashgrid_levels(), ws, O, n, grad + P.table);
     else hipLaunchKernelGGL(hash_table_bwd_kernel<0>, grid, dim3(256), 0, st, hashgrid_levels(), ws, O, n, grad + P.table);
