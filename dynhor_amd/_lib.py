@@ -42,9 +42,9 @@ SIGNATURES = {
     "dh_hash_param_layout": (_i32, [_i32, _i32, ctypes.POINTER(_i64), ctypes.POINTER(_i64), ctypes.POINTER(_i64),
                                     ctypes.POINTER(_i32), ctypes.POINTER(_i32)]),
     "dh_hash_pack_weights": (_i32, [_vp, _vp, _vp]),
-    "dh_hash_workspace_floats": (_i64, [_i64]),
+    "dh_hash_workspace_floats": (_i32, [_i64, ctypes.POINTER(_i64), ctypes.POINTER(_i64)]),
     "dh_hash_sdf_nograd": (_i32, [_vp, _vp, _vp, _i64, _f32, _vp, _vp]),
-    "dh_hash_geo_forward": (_i32, [_vp, _vp, _vp, _i64, _f32, _f32, _vp, _vp, _vp, _vp]),
+    "dh_hash_geo_forward": (_i32, [_vp, _vp, _vp, _i64, _f32, _f32, _vp, _i32, _vp, _vp, _vp, _vp]),
     "dh_hash_color_forward": (_i32, [_vp, _vp, _vp, _vp, _i32, _i64, _vp, _vp]),
     "dh_hash_color_backward": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i64, _vp, _vp, _vp, _vp]),
     "dh_hash_geo_backward": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _f32, _f32, _vp, _vp]),

@@ -292,7 +292,12 @@ int dh_hash_pack_weights(const float* params, float* packed, void* stream) {
     return launch_hash_pack(params, packed, static_cast<hipStream_t>(stream));
 }
 
-int64_t dh_hash_workspace_floats(int64_t npts) { return npts < 0 ? 0 : hash_workspace_floats(npts); }
+int dh_hash_workspace_floats(int64_t npts, int64_t* infer_floats, int64_t* total_floats) {
+    if (npts < 0 || !infer_floats || !total_floats) return DH_ERR_BAD_ARG;
+    *infer_floats = hash_infer_workspace_floats(npts);
+    *total_floats = hash_workspace_floats(npts);
+    return DH_OK;
+}
 
 static inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
@@ -305,11 +310,13 @@ int dh_hash_sdf_nograd(const float* params, const float* packed, const float* pt
 }
 
 int dh_hash_geo_forward(const float* params, const float* packed, const float* pts, int64_t n, float radius, float eps,
-                        float* sdf, float* feature, float* gradient, void* stream) {
+                        float* ws, int save, float* sdf, float* feature, float* gradient, void* stream) {
     if (n < 0 || !(radius > 0.f) || !(eps > 0.f)) return DH_ERR_BAD_ARG;
     if (n == 0) return DH_OK;
-    if (!params || !packed || !pts || !sdf || !feature || !gradient || !al16(params) || !al16(packed)) return DH_ERR_BAD_ARG;
-    return launch_hash_geo_fwd(params, packed, pts, n, radius, eps, sdf, feature, gradient, static_cast<hipStream_t>(stream));
+    if (!params || !packed || !pts || !ws || !sdf || !feature || !gradient || !al16(params) || !al16(packed) || !al16(ws))
+        return DH_ERR_BAD_ARG;
+    return launch_hash_geo_fwd(params, packed, pts, n, radius, eps, ws, save, sdf, feature, gradient,
+                               static_cast<hipStream_t>(stream));
 }
 
 int dh_hash_color_forward(const float* packed, const float* feature, const float* normals, const float* dirs,

@@ -49,6 +49,16 @@ __device__ __forceinline__ void stage_weights(float* lds, const float* __restric
     __syncthreads();
 }
 
+__device__ __forceinline__ void hg_cell(const HashLevels& H, int l, const float (&x01)[3], uint32_t (&g)[3], float (&w)[3]) {
+    const float s = H.scale[l];
+    DH_UNROLL for (int c = 0; c < 3; ++c) {
+        const float pos = x01[c] * s + 0.5f;
+        const float f = floorf(pos);
+        w[c] = pos - f;
+        g[c] = (uint32_t)(int)f;
+    }
+}
+
 // ---------------------------------------------------------------- geometry network, one evaluation
 // x: world position; radius: scene box half-size (x01 = (x + r) / 2r).  FULL: all 13 outputs, else sdf only.
 template <bool FULL>
@@ -88,27 +98,132 @@ __global__ __launch_bounds__(256) void hash_sdf_nograd_kernel(HashLevels H, cons
     sdf[p] = out[0];
 }
 
-// training / rendering forward: sdf, feature (all 13 outputs), finite-difference gradient (App. of the oracle: eps 1e-3)
-__global__ __launch_bounds__(256) void hash_geo_fwd_kernel(HashLevels H, const float* __restrict__ table,
-                                                           const float* __restrict__ hp, const float* __restrict__ pts,
-                                                           int64_t n, float radius, float eps, float* __restrict__ sdf,
-                                                           float* __restrict__ feat, float* __restrict__ grad) {
+// training / rendering forward: sdf, feature (all 13 outputs), finite-difference gradient (eps: oracle fd_eps = 1e-3).
+// Two kernels so the gathers run at high occupancy and are shared between a point's E = 7 evaluations:
+//   1. hash_encode7_kernel -- one thread per (point, level), grid.y = level (a wave = 64 consecutive samples of a ray
+//      at one level).  The centre cell's 8 corners are gathered once; a +-eps evaluation re-uses them when it stays in
+//      the cell and re-uses the shared face when it lands in the neighbour (4 new gathers), so a point costs ~216
+//      8-byte gathers instead of 7 x 128.  Writes the encodings feature-major into rows 3..34 of GIN [36][lde]
+//      (row r = e n + p) -- the same rows the backward's weight-gradient GEMM reads, so nothing is gathered twice.
+//   2. hash_geo_mlp_fwd_kernel -- one thread per point: the 35 -> 64 -> 13 MLP on the 7 encoded inputs (weights in LDS).
+__global__ __launch_bounds__(256) void hash_encode7_kernel(HashLevels H, const float* __restrict__ table,
+                                                           const float* __restrict__ pts, int64_t n, float radius, float eps,
+                                                           float* __restrict__ gin, int64_t lde) {
+    const int l = blockIdx.y;
+    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= n) return;
+    const float x[3] = {pts[p * 3], pts[p * 3 + 1], pts[p * 3 + 2]};
+    float x01[3];
+    DH_UNROLL for (int c = 0; c < 3; ++c) x01[c] = (x[c] + radius) / (2.f * radius);
+    uint32_t g0[3];
+    float w0[3];
+    hg_cell(H, l, x01, g0, w0);
+    float2 cf[8];
+    DH_UNROLL for (int corner = 0; corner < 8; ++corner) {
+        const uint32_t idx = hg_index(H, l, g0[0] + (corner & 1), g0[1] + ((corner >> 1) & 1), g0[2] + (corner >> 2));
+        cf[corner] = *reinterpret_cast<const float2*>(table + (size_t)idx * HG_F);
+    }
+    float* o0 = gin + (int64_t)(3 + 2 * l) * lde + p;
+    float* o1 = o0 + lde;
+    {
+        float a0 = 0.f, a1 = 0.f;
+        DH_UNROLL for (int corner = 0; corner < 8; ++corner) {
+            const int dx = corner & 1, dy = (corner >> 1) & 1, dz = corner >> 2;
+            const float wt = (dx ? w0[0] : 1.f - w0[0]) * (dy ? w0[1] : 1.f - w0[1]) * (dz ? w0[2] : 1.f - w0[2]);
+            a0 = fmaf(wt, cf[corner].x, a0);
+            a1 = fmaf(wt, cf[corner].y, a1);
+        }
+        o0[0] = a0; o1[0] = a1;
+    }
+    const float s = H.scale[l];
+    DH_UNROLL for (int e = 1; e < 7; ++e) {
+        const int a = (e - 1) >> 1, b = (a + 1) % 3, c = (a + 2) % 3;
+        const float xe = x[a] + ((e - 1) & 1 ? -eps : eps);
+        const float pos = ((xe + radius) / (2.f * radius)) * s + 0.5f;
+        const float fl = floorf(pos);
+        const float wa = pos - fl;
+        const uint32_t ga = (uint32_t)(int)fl;
+        const int delta = (int)(ga - g0[a]);
+        float a0 = 0.f, a1 = 0.f;
+        DH_UNROLL for (int ba = 0; ba < 2; ++ba) {
+            const int t = delta + ba;                    // plane position relative to the centre cell: 0 / 1 = already held
+            const bool shared = (unsigned)t < 2u;
+            const float wpa = ba ? wa : 1.f - wa;
+            float2 v[4];
+            DH_UNROLL for (int q = 0; q < 4; ++q) {
+                const int c0 = ((q & 1) << b) | ((q >> 1) << c), c1 = c0 | (1 << a);
+                v[q].x = t ? cf[c1].x : cf[c0].x;
+                v[q].y = t ? cf[c1].y : cf[c0].y;
+            }
+            if (!shared) {
+                DH_UNROLL for (int q = 0; q < 4; ++q) {
+                    uint32_t cc[3];
+                    cc[a] = ga + ba; cc[b] = g0[b] + (q & 1); cc[c] = g0[c] + (q >> 1);
+                    const uint32_t idx = hg_index(H, l, cc[0], cc[1], cc[2]);
+                    v[q] = *reinterpret_cast<const float2*>(table + (size_t)idx * HG_F);
+                }
+            }
+            DH_UNROLL for (int q = 0; q < 4; ++q) {
+                const float wt = wpa * ((q & 1) ? w0[b] : 1.f - w0[b]) * ((q >> 1) ? w0[c] : 1.f - w0[c]);
+                a0 = fmaf(wt, v[q].x, a0);
+                a1 = fmaf(wt, v[q].y, a1);
+            }
+        }
+        o0[(int64_t)e * n] = a0; o1[(int64_t)e * n] = a1;
+    }
+}
+
+// the geometry MLP on one encoded input (rows 3..34 of GIN); FULL: all 13 outputs, else sdf only
+template <bool FULL>
+__device__ __forceinline__ void geo_mlp(const float* W, const float (&in)[36], float (&out)[HM_GOUT]) {
+    DH_UNROLL for (int c = 0; c < HM_GOUT; ++c) out[c] = W[HP_G1B + c];
+    for (int j = 0; j < HM_HID; ++j) {
+        const f32x4* wr = reinterpret_cast<const f32x4*>(W + HP_G0 + j * 36);
+        float a = W[HP_G0B + j];
+        DH_UNROLL for (int k4 = 0; k4 < 9; ++k4) {
+            const f32x4 w = wr[k4];
+            a = fmaf(w[0], in[4 * k4], a); a = fmaf(w[1], in[4 * k4 + 1], a);
+            a = fmaf(w[2], in[4 * k4 + 2], a); a = fmaf(w[3], in[4 * k4 + 3], a);
+        }
+        const float h = softplus100(a);
+        out[0] = fmaf(W[HP_G1 + j], h, out[0]);
+        if (FULL) { DH_UNROLL for (int c = 1; c < HM_GOUT; ++c) out[c] = fmaf(W[HP_G1 + c * 64 + j], h, out[c]); }
+    }
+}
+
+__device__ __forceinline__ void load_geo_input(const float* __restrict__ gin, int64_t lde, int64_t row, const float (&xe)[3],
+                                               float radius, float (&in)[36]) {
+    DH_UNROLL for (int c = 0; c < 3; ++c) in[c] = ((xe[c] + radius) / (2.f * radius)) * 2.f - 1.f;
+    DH_UNROLL for (int k = 3; k < 35; ++k) in[k] = gin[(int64_t)k * lde + row];
+    in[35] = 0.f;
+}
+
+__global__ __launch_bounds__(256) void hash_geo_mlp_fwd_kernel(const float* __restrict__ hp, const float* __restrict__ pts,
+                                                               int64_t n, float radius, float eps,
+                                                               const float* __restrict__ gin, int64_t lde,
+                                                               float* __restrict__ sdf, float* __restrict__ feat,
+                                                               float* __restrict__ grad) {
     __shared__ __attribute__((aligned(16))) float W[HP_WEIGHTS + 4];
     stage_weights(W, hp);
     const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (p >= n) return;
     const float x[3] = {pts[p * 3], pts[p * 3 + 1], pts[p * 3 + 2]};
-    float out[HM_GOUT];
-    geo_eval<true>(H, table, W, x, radius, out);
+    float in[36], out[HM_GOUT];
+    load_geo_input(gin, lde, p, x, radius, in);
+    geo_mlp<true>(W, in, out);
     sdf[p] = out[0];
     DH_UNROLL for (int c = 0; c < HM_FEAT; ++c) feat[p * HM_FEAT + c] = out[c];
     DH_UNROLL for (int i = 0; i < 3; ++i) {
-        float xp[3] = {x[0], x[1], x[2]}, xm[3] = {x[0], x[1], x[2]};
-        xp[i] += eps; xm[i] -= eps;
-        float op[HM_GOUT], om[HM_GOUT];
-        geo_eval<false>(H, table, W, xp, radius, op);
-        geo_eval<false>(H, table, W, xm, radius, om);
-        grad[p * 3 + i] = (op[0] - om[0]) * (0.5f / eps);
+        float sd[2];
+        DH_UNROLL for (int sg = 0; sg < 2; ++sg) {
+            float xe[3] = {x[0], x[1], x[2]};
+            xe[i] += sg ? -eps : eps;
+            load_geo_input(gin, lde, (int64_t)(1 + 2 * i + sg) * n + p, xe, radius, in);
+            float o[HM_GOUT];
+            geo_mlp<false>(W, in, o);
+            sd[sg] = o[0];
+        }
+        grad[p * 3 + i] = (sd[0] - sd[1]) * (0.5f / eps);
     }
 }
 
@@ -300,8 +415,7 @@ __global__ __launch_bounds__(256) void sh_color_bwd_kernel(const float* __restri
 
 // geometry adjoint: E = 7 evaluations per point (centre with the feature/sdf cotangent, +-eps per axis with
 // +-d_grad * 0.5/eps on the sdf output).  Writes the rows small_dw_kernel and the table scatter consume.
-__global__ __launch_bounds__(256) void hash_geo_bwd_kernel(HashLevels H, const float* __restrict__ table,
-                                                           const float* __restrict__ hp, const float* __restrict__ pts,
+__global__ __launch_bounds__(256) void hash_geo_bwd_kernel(const float* __restrict__ hp, const float* __restrict__ pts,
                                                            const float* __restrict__ d_sdf, const float* __restrict__ d_feat,
                                                            const float* __restrict__ d_grad, int64_t n, float radius,
                                                            float eps, float* __restrict__ ws, HashWs O) {
@@ -325,11 +439,10 @@ __global__ __launch_bounds__(256) void hash_geo_bwd_kernel(HashLevels H, const f
         }
         const int64_t row = (int64_t)e * n + p;
         float in[36], x01[3];
-        DH_UNROLL for (int c = 0; c < 3; ++c) { x01[c] = (xe[c] + radius) / (2.f * radius); in[c] = x01[c] * 2.f - 1.f; }
-        DH_UNROLL for (int l = 0; l < HG_L; ++l) hg_encode_level(H, table, l, x01, in[3 + 2 * l], in[4 + 2 * l]);
-        in[35] = 1.f;                                   // ones column: dW0[:,35] accumulates the bias gradient
-        store_col(ws + O.gin, O.lde, row, in);
-        in[35] = 0.f;
+        DH_UNROLL for (int c = 0; c < 3; ++c) x01[c] = (xe[c] + radius) / (2.f * radius);
+        load_geo_input(ws + O.gin, O.lde, row, xe, radius, in);       // encodings: rows 3..34 left by the forward
+        DH_UNROLL for (int c = 0; c < 3; ++c) ws[O.gin + c * O.lde + row] = in[c];
+        ws[O.gin + 35 * O.lde + row] = 1.f;             // ones column: dW0[:,35] accumulates the bias gradient
         store_col(ws + O.x01, O.lde, row, x01);
         store_col(ws + O.dout, O.lde, row, dout);
         float din[36];
@@ -375,16 +488,6 @@ __global__ __launch_bounds__(256) void hash_geo_bwd_kernel(HashLevels H, const f
 //     issues the centre's atomics.
 // Against the per-evaluation scatter (tcnn's scheme: E x 8 corners x 2 features atomics per point and level) this is
 // 24.9 ms -> see DESIGN.md for the measured ladder.  DH_HASH_SCATTER_MODE=1 / 2 switch (b) / (a) off for ablation.
-__device__ __forceinline__ void hg_cell(const HashLevels& H, int l, const float (&x01)[3], uint32_t (&g)[3], float (&w)[3]) {
-    const float s = H.scale[l];
-    DH_UNROLL for (int c = 0; c < 3; ++c) {
-        const float pos = x01[c] * s + 0.5f;
-        const float f = floorf(pos);
-        w[c] = pos - f;
-        g[c] = (uint32_t)(int)f;
-    }
-}
-
 template <int MODE>   // 0: both merges; 1: no lane-run merge; 2: no evaluation merge (ablation / debugging)
 __global__ __launch_bounds__(256) void hash_table_bwd_kernel(HashLevels H, const float* __restrict__ ws, HashWs O, int64_t n,
                                                              float* __restrict__ d_table) {
@@ -586,9 +689,13 @@ int launch_hash_sdf_nograd(const float* params, const float* hp, const float* pt
     return ok();
 }
 int launch_hash_geo_fwd(const float* params, const float* hp, const float* pts, int64_t n, float radius, float eps,
-                        float* sdf, float* feat, float* grad, hipStream_t st) {
-    hipLaunchKernelGGL(hash_geo_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, hashgrid_levels(),
-                       params + hash_param_off().table, hp, pts, n, radius, eps, sdf, feat, grad);
+                        float* ws, int save, float* sdf, float* feat, float* grad, hipStream_t st) {
+    const HashWs O = make_hash_ws(n);
+    float* gin = save ? ws + O.gin : ws;               // forward-only callers hand over just the GIN rows
+    const unsigned nb = (unsigned)((n + 255) / 256);
+    hipLaunchKernelGGL(hash_encode7_kernel, dim3(nb, HG_L), dim3(256), 0, st, hashgrid_levels(),
+                       params + hash_param_off().table, pts, n, radius, eps, gin, O.lde);
+    hipLaunchKernelGGL(hash_geo_mlp_fwd_kernel, dim3(nb), dim3(256), 0, st, hp, pts, n, radius, eps, gin, O.lde, sdf, feat, grad);
     return ok();
 }
 int launch_sh_color_fwd(const float* hp, const float* feat, const float* normals, const float* dirs, int n_per_ray,
@@ -603,6 +710,7 @@ int launch_sh_color_fwd(const float* hp, const float* feat, const float* normals
 namespace dh {
 
 int64_t hash_workspace_floats(int64_t n) { return make_hash_ws(n).total + (int64_t)HW_JOBS * HW_DW_FLOATS; }
+int64_t hash_infer_workspace_floats(int64_t n) { return make_hash_ws(n).lde * 36; }
 
 int launch_sh_color_bwd(const float* hp, const float* feat, const float* normals, const float* dirs, const float* d_color,
                         int n_per_ray, int64_t n, float* ws, float* d_feat, float* d_normals, hipStream_t st) {
@@ -613,8 +721,9 @@ int launch_sh_color_bwd(const float* hp, const float* feat, const float* normals
 
 int launch_hash_geo_bwd(const float* params, const float* hp, const float* pts, const float* d_sdf, const float* d_feat,
                         const float* d_grad, int64_t n, float radius, float eps, float* ws, hipStream_t st) {
-    hipLaunchKernelGGL(hash_geo_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, hashgrid_levels(),
-                       params + hash_param_off().table, hp, pts, d_sdf, d_feat, d_grad, n, radius, eps, ws, make_hash_ws(n));
+    (void)params;
+    hipLaunchKernelGGL(hash_geo_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, hp, pts, d_sdf, d_feat,
+                       d_grad, n, radius, eps, ws, make_hash_ws(n));
     return ok();
 }
 

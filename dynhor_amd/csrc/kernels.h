@@ -71,8 +71,9 @@ int64_t hash_workspace_floats(int64_t n);
 int launch_hash_pack(const float* params, float* hp, hipStream_t st);
 int launch_hash_sdf_nograd(const float* params, const float* hp, const float* pts, int64_t n, float radius, float* sdf,
                            hipStream_t st);
+int64_t hash_infer_workspace_floats(int64_t n);
 int launch_hash_geo_fwd(const float* params, const float* hp, const float* pts, int64_t n, float radius, float eps,
-                        float* sdf, float* feat, float* grad, hipStream_t st);
+                        float* ws, int save, float* sdf, float* feat, float* grad, hipStream_t st);
 int launch_sh_color_fwd(const float* hp, const float* feat, const float* normals, const float* dirs, int n_per_ray,
                         int64_t n, float* color, hipStream_t st);
 int launch_sh_color_bwd(const float* hp, const float* feat, const float* normals, const float* dirs, const float* d_color,

@@ -109,7 +109,10 @@ class HashNeuSRenderer(NeuSRenderer):
         return HashParamStore(sdf_network, deviation_network, color_network, device)
 
     def _workspace_need(self, npts: int, infer_only: bool) -> int:
-        return 64 if infer_only else int(_lib.lib().dh_hash_workspace_floats(npts))
+        import ctypes
+        infer, total = ctypes.c_int64(), ctypes.c_int64()
+        _lib.check(_lib.lib().dh_hash_workspace_floats(npts, ctypes.byref(infer), ctypes.byref(total)))
+        return infer.value if infer_only else total.value
 
     def _net_sdf_nograd(self, tag, pts, n, out):
         st = self.store
@@ -121,7 +124,7 @@ class HashNeuSRenderer(NeuSRenderer):
         P = s.B * s.n
         s.feat = torch.empty(P, 13, device=s.pts.device)
         T("hash_geo_forward", L.dh_hash_geo_forward, _p(st.flat), _p(packed), _p(s.pts), P, self.radius, self.fd_eps,
-          _p(s.sdf), _p(s.feat), _p(s.normals), _lib.stream())
+          _p(s.ws), 0 if s.infer_only else 1, _p(s.sdf), _p(s.feat), _p(s.normals), _lib.stream())
         T("hash_color_forward", L.dh_hash_color_forward, _p(packed), _p(s.feat), _p(s.normals), _p(s.rays_d), s.n, P,
           _p(s.colors), _lib.stream())
 

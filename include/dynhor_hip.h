@@ -175,17 +175,19 @@ int64_t dh_hash_num_params(void);
 int64_t dh_hash_packed_floats(void);
 int dh_hash_param_layout(int net, int layer, int64_t* bias_off, int64_t* g_off, int64_t* v_off, int* out_dim, int* in_dim);
 int dh_hash_pack_weights(const float* params, float* packed, void* stream);
-int64_t dh_hash_workspace_floats(int64_t npts);
+/* workspace sizes (floats): *infer for dh_hash_geo_forward(save = 0), *total for a forward that a backward follows */
+int dh_hash_workspace_floats(int64_t npts, int64_t* infer_floats, int64_t* total_floats);
 /* sdf only (hierarchical up-sampling): pts [n,3] -> sdf [n] */
 int dh_hash_sdf_nograd(const float* params, const float* packed, const float* pts, int64_t n, float radius, float* sdf,
                        void* stream);
-/* sdf [n], feature [n,13], finite-difference gradient [n,3] */
+/* sdf [n], feature [n,13], finite-difference gradient [n,3].  ws: caller-owned workspace (save = 0: *infer floats; save =
+ * 1: *total floats, and the encodings of the 7 evaluations stay in it for the three backward calls below). */
 int dh_hash_geo_forward(const float* params, const float* packed, const float* pts, int64_t n, float radius, float eps,
-                        float* sdf, float* feature, float* gradient, void* stream);
+                        float* ws, int save, float* sdf, float* feature, float* gradient, void* stream);
 /* colour [n,3]; dirs [n / n_per_ray, 3] */
 int dh_hash_color_forward(const float* packed, const float* feature, const float* normals, const float* dirs,
                           int n_per_ray, int64_t n, float* color, void* stream);
-/* Adjoint, three calls in this order on one caller-owned workspace ws [dh_hash_workspace_floats(n)]:
+/* Adjoint, three calls in this order on the workspace dh_hash_geo_forward(save = 1) filled:
  *   colour   : d_color [n,3] -> d_feature [n,13] (written) and d_normals [n,3] (ACCUMULATED onto the caller's values)
  *   geometry : d_sdf [n], d_feature, d_normals (= cotangent of the finite-difference gradient)
  *   weights  : every parameter gradient -> grad [dh_hash_num_params()] (table part zeroed then scattered with float

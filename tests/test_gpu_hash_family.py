@@ -70,6 +70,7 @@ def test_geo_forward_matches_oracle(n):
     got_sdf = p_r.sdf(x)
     s = type("S", (), {})()
     s.B, s.n, s.pts, s.rays_d, s.infer_only = n, 1, x, x, True
+    s.ws = p_r._workspace(n, infer_only=True)
     s.sdf = torch.empty(n, device="cuda"); s.normals = torch.empty(n, 3, device="cuda"); s.colors = torch.empty(n, 3, device="cuda")
     p_r._net_forward(s, p_r.store.ensure_packed())
     torch.cuda.synchronize()
