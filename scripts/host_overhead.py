@@ -5,7 +5,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from dynhor_amd.runner import Runner
 conf = {"seq_name": "h", "exp_name": "h", "data_info": {"synthetic": {"n_frames": 8, "H": 512, "W": 512, "seed": 1}},
-        "train": {"batch_size": 2048, "normal_weight": 0.05, "report_freq": 10 ** 9, "save_freq": 10 ** 9, "val_freq": 0}}
+        "train": {"batch_size": 2048, "normal_weight": 0.05, "report_freq": 10 ** 9, "save_freq": 10 ** 9, "val_freq": 0},
+        "model": {"family": sys.argv[1] if len(sys.argv) > 1 else "neus"}}
 r = Runner(conf=conf, device="cuda:0", exp_root="/tmp/dh_host")
 for _ in range(5):
     r.train_iteration()
