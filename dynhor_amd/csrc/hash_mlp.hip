@@ -297,7 +297,7 @@ struct HashWs {
     int64_t ldn, lde;
 };
 constexpr int HW_E = 7;
-constexpr int HW_SLABS = 1024;                   // partial-sum slabs of the weight-gradient reductions
+constexpr int HW_SLABS = 256;                    // partial-sum slabs of the weight-gradient reductions
 constexpr int HW_DW_FLOATS = 64 * 64 + 64;       // one job's slab: padded [64][64] tile + column sums
 constexpr int HW_JOBS = 5;
 inline HashWs make_hash_ws(int64_t n) {
@@ -587,51 +587,71 @@ __global__ __launch_bounds__(256) void hash_table_bwd_kernel(HashLevels H, const
     }
 }
 
-// dW[m][k] = sum_r A[m][r] B[k][r]  (feature-major operands, m < M <= 64, k < K <= 64), plus colsum[m] = sum_r A[m][r];
-// one wave per slab of rows, fp32 MFMA 32x32x2: lane (i, kk) reads the 16-B quad rows r..r+3 (kk = 0) / r+4..r+7
-// (kk = 1) of feature i and feeds them to four MFMAs (contraction pairs (r+u, r+4+u)).
+// dW[m][k] = sum_r A[m][r] B[k][r]  (feature-major operands, m < M <= 64, k < K <= 64), plus colsum[m] = sum_r A[m][r].
+// One 4-wave workgroup per slab of rows: 64-row tiles of both operands are loaded as coalesced 16-B row quads (16
+// lanes cover one feature's 256 B), staged in LDS (row stride 65: the operand reads of a 32-lane half hit 32 banks), and
+// each wave accumulates one 32x32 quadrant of dW with fp32 MFMA 32x32x2; the next tile's global loads are in flight
+// while the current one is multiplied.
 struct SmallDwJob { int64_t a, b; int M, K; int64_t rows, ld; };
 struct SmallDwJobs { SmallDwJob j[HW_JOBS]; };
+constexpr int DWT = 64, DWS = DWT + 1;
 
-__global__ __launch_bounds__(64) void small_dw_kernel(const float* __restrict__ ws, SmallDwJobs J, float* __restrict__ slabs) {
+__global__ __launch_bounds__(256) void small_dw_kernel(const float* __restrict__ ws, SmallDwJobs J, float* __restrict__ slabs) {
+    __shared__ float At[64 * DWS], Bt[64 * DWS];
     const SmallDwJob job = J.j[blockIdx.y];
-    const int lane = threadIdx.x, i = lane & 31, kk = lane >> 5;
-    const int64_t per = ((job.rows + HW_SLABS - 1) / HW_SLABS + 7) & ~int64_t(7);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 31, kk = lane >> 5;
+    const int mt = wave >> 1, kt = wave & 1;
+    const int64_t per = ((job.rows + HW_SLABS - 1) / HW_SLABS + DWT - 1) / DWT * DWT;
     const int64_t r0 = (int64_t)blockIdx.x * per, r1 = r0 + per < job.rows ? r0 + per : job.rows;
-    f32x16 acc[2][2];
-    DH_UNROLL for (int a = 0; a < 2; ++a) DH_UNROLL for (int b = 0; b < 2; ++b) DH_UNROLL for (int q = 0; q < 16; ++q) acc[a][b][q] = 0.f;
-    float cs[2] = {0.f, 0.f};
-    const bool am0 = i < job.M, am1 = i + 32 < job.M, bk0 = i < job.K, bk1 = i + 32 < job.K;
-    const float* A0 = ws + job.a + (int64_t)(am0 ? i : 0) * job.ld + 4 * kk;
-    const float* A1 = ws + job.a + (int64_t)(am1 ? i + 32 : 0) * job.ld + 4 * kk;
-    const float* B0 = ws + job.b + (int64_t)(bk0 ? i : 0) * job.ld + 4 * kk;
-    const float* B1 = ws + job.b + (int64_t)(bk1 ? i + 32 : 0) * job.ld + 4 * kk;
+    const int lf = tid >> 4, lc = tid & 15;              // loader: features lf + 16 q, rows 4 lc .. 4 lc + 3 of the tile
+    const float* A = ws + job.a;
+    const float* B = ws + job.b;
+    f32x16 acc;
+    DH_UNROLL for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+    float cs[4] = {0.f, 0.f, 0.f, 0.f};
+    f32x4 ra[4], rb[4];
     const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-    for (int64_t rp = r0; rp < r1; rp += 8) {            // wave-uniform trip count: MFMA must not run under divergence
-        f32x4 a0 = am0 ? *reinterpret_cast<const f32x4*>(A0 + rp) : z4;
-        f32x4 a1 = am1 ? *reinterpret_cast<const f32x4*>(A1 + rp) : z4;
-        f32x4 b0 = bk0 ? *reinterpret_cast<const f32x4*>(B0 + rp) : z4;
-        f32x4 b1 = bk1 ? *reinterpret_cast<const f32x4*>(B1 + rp) : z4;
-        if (rp + 8 > r1) {                               // ragged tail: rows past the end hold garbage
-            DH_UNROLL for (int u = 0; u < 4; ++u)
-                if (rp + 4 * kk + u >= r1) { a0[u] = 0.f; a1[u] = 0.f; b0[u] = 0.f; b1[u] = 0.f; }
+    auto load = [&](int64_t rt) {
+        const int64_t r = rt + 4 * lc;
+        DH_UNROLL for (int q = 0; q < 4; ++q) {
+            const int f = lf + 16 * q;
+            ra[q] = (f < job.M && r < r1) ? *reinterpret_cast<const f32x4*>(A + (int64_t)f * job.ld + r) : z4;
+            rb[q] = (f < job.K && r < r1) ? *reinterpret_cast<const f32x4*>(B + (int64_t)f * job.ld + r) : z4;
+            if (r + 4 > r1) {                            // ragged tail: rows past the end hold garbage
+                DH_UNROLL for (int u = 0; u < 4; ++u) if (r + u >= r1) { ra[q][u] = 0.f; rb[q][u] = 0.f; }
+            }
         }
-        DH_UNROLL for (int u = 0; u < 4; ++u) {
-            cs[0] += a0[u]; cs[1] += a1[u];
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[u], b0[u], acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[u], b1[u], acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[u], b0[u], acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[u], b1[u], acc[1][1], 0, 0, 0);
+    };
+    if (r0 < r1) load(r0);
+    const bool active = mt * 32 < job.M && kt * 32 < job.K;          // wave-uniform
+    for (int64_t rt = r0; rt < r1; rt += DWT) {
+        __syncthreads();                                 // the previous tile's readers are done
+        DH_UNROLL for (int q = 0; q < 4; ++q) {
+            const int f = lf + 16 * q;
+            DH_UNROLL for (int u = 0; u < 4; ++u) {
+                At[f * DWS + 4 * lc + u] = ra[q][u];
+                Bt[f * DWS + 4 * lc + u] = rb[q][u];
+            }
+            cs[q] += (ra[q][0] + ra[q][1]) + (ra[q][2] + ra[q][3]);
+        }
+        __syncthreads();
+        if (rt + DWT < r1) load(rt + DWT);
+        if (active) {
+            const float* ap = At + (mt * 32 + i) * DWS + kk;
+            const float* bp = Bt + (kt * 32 + i) * DWS + kk;
+            DH_UNROLL for (int s2 = 0; s2 < DWT / 2; ++s2)
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * s2], bp[2 * s2], acc, 0, 0, 0);
         }
     }
     float* out = slabs + ((int64_t)blockIdx.y * HW_SLABS + blockIdx.x) * HW_DW_FLOATS;
-    DH_UNROLL for (int a = 0; a < 2; ++a) DH_UNROLL for (int b = 0; b < 2; ++b) DH_UNROLL for (int q = 0; q < 16; ++q) {
-        const int m = a * 32 + 8 * (q >> 2) + 4 * kk + (q & 3);      // accumulator layout of 32x32x2: row = 8*(q/4)+4*(lane/32)+q%4
-        out[m * 64 + b * 32 + i] = acc[a][b][q];
+    DH_UNROLL for (int q = 0; q < 16; ++q) {
+        const int m = mt * 32 + 8 * (q >> 2) + 4 * kk + (q & 3);     // accumulator layout of 32x32x2: row = 8*(q/4)+4*(lane/32)+q%4
+        out[m * 64 + kt * 32 + i] = acc[q];
     }
-    DH_UNROLL for (int a = 0; a < 2; ++a) {
-        const float t = cs[a] + __shfl_xor(cs[a], 32);
-        if (kk == 0) out[64 * 64 + a * 32 + i] = t;
+    DH_UNROLL for (int q = 0; q < 4; ++q) {              // column sums: reduce over the 16 lanes sharing a feature
+        float t = cs[q];
+        DH_UNROLL for (int off = 1; off < 16; off <<= 1) t += __shfl_xor(t, off);
+        if (lc == 0) out[64 * 64 + lf + 16 * q] = t;
     }
 }
 
@@ -740,7 +760,7 @@ int launch_hash_weight_grads(const float* params, const float* hp, int64_t n, fl
     J.j[4] = {O.d_o, O.h2, 3, 64, n, O.ldn};           // colour lin2
     float* slabs = ws + O.slabs;
     float* dwsum = ws + O.total;
-    hipLaunchKernelGGL(small_dw_kernel, dim3(HW_SLABS, HW_JOBS), dim3(64), 0, st, ws, J, slabs);
+    hipLaunchKernelGGL(small_dw_kernel, dim3(HW_SLABS, HW_JOBS), dim3(256), 0, st, ws, J, slabs);
     hipLaunchKernelGGL(small_dw_reduce_kernel, dim3((HW_DW_FLOATS + 255) / 256, HW_JOBS), dim3(256), 0, st, slabs, dwsum);
     hipLaunchKernelGGL(hash_fold_kernel, dim3(64, HW_JOBS), dim3(64), 0, st, params, hp, dwsum, P, grad);
     // table: scatter the encoding adjoint of all E n evaluations

@@ -155,6 +155,27 @@ class NeuSRenderer:
         self._net_sdf_nograd("sdf_nograd", pts, pts.shape[0], out)
         return out.view(-1, 1)
 
+    # ------------------------------------------------------------------ geometry extraction (upstream extract_geometry)
+    @torch.no_grad()
+    def extract_geometry(self, bound_min, bound_max, resolution, threshold=0.0):
+        """Upstream NeuSRenderer.extract_geometry(bound_min, bound_max, resolution, threshold): -sdf on a regular grid
+        (HIP no-grad SDF kernel, 64^3-point chunks), iso-surface at `threshold`.  Returns (vertices [V,3], triangles [F,3])
+        as device tensors; the iso-surface is extracted by marching tetrahedra (dynhor_amd/mesh.py) because PyMCubes,
+        which upstream calls, is not installable here."""
+        from .mesh import marching_tetrahedra
+        dev = self.store.device
+        N = int(resolution)
+        ax = [torch.linspace(float(bound_min[i]), float(bound_max[i]), N, device=dev) for i in range(3)]
+        u = torch.empty(N, N, N, device=dev)
+        step = 64
+        for xi in range(0, N, step):
+            for yi in range(0, N, step):
+                for zi in range(0, N, step):
+                    gx, gy, gz = torch.meshgrid(ax[0][xi:xi + step], ax[1][yi:yi + step], ax[2][zi:zi + step], indexing="ij")
+                    pts = torch.stack([gx, gy, gz], dim=-1).reshape(-1, 3).contiguous()
+                    u[xi:xi + step, yi:yi + step, zi:zi + step] = -self.sdf(pts).reshape(gx.shape)
+        return marching_tetrahedra(u, threshold, bound_min, bound_max)
+
     # ------------------------------------------------------------------ hierarchical sampling (App. A.5/A.6)
     @torch.no_grad()
     def sample_z(self, rays_o, rays_d, near, far, perturb_overwrite=-1, t_rand=None):

@@ -248,20 +248,9 @@ class Runner:
         """Upstream Runner.validate_mesh / NeuSRenderer.extract_geometry: -sdf on a regular grid over
         the object bounding box (HIP no-grad SDF kernel, 64^3-point chunks), iso-surface by marching tetrahedra
         (dynhor_amd/mesh.py; mcubes is not available), written as meshes/<iter>.ply.  Returns (vertices, triangles)."""
-        from .mesh import marching_tetrahedra, write_ply
-        N = resolution
+        from .mesh import write_ply
         bmin, bmax = self.dataset.object_bbox_min, self.dataset.object_bbox_max
-        ax = [torch.linspace(float(bmin[i]), float(bmax[i]), N, device=self.device) for i in range(3)]
-        u = torch.empty(N, N, N, device=self.device)
-        step = 64
-        for xi in range(0, N, step):
-            for yi in range(0, N, step):
-                for zi in range(0, N, step):
-                    gx, gy, gz = torch.meshgrid(ax[0][xi:xi + step], ax[1][yi:yi + step], ax[2][zi:zi + step], indexing="ij")
-                    pts = torch.stack([gx, gy, gz], dim=-1).reshape(-1, 3).contiguous()
-                    val = -self.renderer.sdf(pts).reshape(gx.shape)
-                    u[xi:xi + step, yi:yi + step, zi:zi + step] = val
-        verts, faces = marching_tetrahedra(u, threshold, bmin, bmax)
+        verts, faces = self.renderer.extract_geometry(bmin, bmax, resolution=resolution, threshold=threshold)
         if save and self.rank == 0:
             d = os.path.join(self.base_exp_dir, "meshes")
             os.makedirs(d, exist_ok=True)

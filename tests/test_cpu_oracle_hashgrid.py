@@ -65,3 +65,32 @@ def test_plugs_into_the_neus_renderer_and_trains():
     assert out["color_fine"].shape == (24, 3) and torch.isfinite(out["color_fine"]).all()
     (out["color_fine"].sum() + out["gradient_error"]).backward()
     assert sdf.lin0.weight_v.grad.abs().sum().item() > 0 and col.lin2.weight_v.grad.abs().sum().item() > 0
+
+
+def test_out_of_box_coordinates_wrap_as_uint32():
+    """Samples just outside the box (the renderer's last mid-point overshoots the unit sphere) index the table with
+    uint32 wrap-around, the convention the HIP kernels implement: checked against independent numpy uint32 arithmetic."""
+    import numpy as np
+    e = H.HashGridEncoding()
+    g = torch.Generator().manual_seed(3)
+    c = torch.randint(-40, 60, (500, 3), generator=g)
+    for l in (0, 4, 5, 15):                                  # two dense, two hashed levels
+        got = e.level_index(l, c[:, 0], c[:, 1], c[:, 2]).numpy() - e.offsets[l]
+        u = c.numpy().astype(np.int64).astype(np.uint32)     # two's-complement wrap
+        res = np.uint32(e.resolutions[l])
+        with np.errstate(over="ignore"):
+            if e.dense[l]:
+                ref = (u[:, 0] + u[:, 1] * res + u[:, 2] * res * res) % np.uint32(e.sizes[l])
+            else:
+                ref = ((u[:, 0] * np.uint32(1)) ^ (u[:, 1] * np.uint32(2654435761)) ^ (u[:, 2] * np.uint32(805459861))) \
+                      % np.uint32(e.T)
+        assert (got == ref.astype(np.int64)).all(), l
+        assert got.min() >= 0 and got.max() < e.sizes[l]
+    # the encoding stays finite and continuous across the box face
+    e = e.double()
+    with torch.no_grad():
+        e.table.copy_(torch.randn_like(e.table))
+    x = torch.tensor([[1.0 - 1e-9, 0.3, 0.7], [1.0 + 1e-9, 0.3, 0.7], [-1e-9, 0.5, 0.5], [1e-9, 0.5, 0.5]], dtype=torch.float64)
+    out = e(x)
+    assert torch.isfinite(out).all()
+    assert (out[0] - out[1]).abs().max() < 1e-4 and (out[2] - out[3]).abs().max() < 1e-4
