@@ -234,6 +234,153 @@ __device__ __forceinline__ void dw_body_lds(const DwJob& J, int64_t t0, int64_t 
         }
 }
 
+// ---------------------------------------------------------------- split-bf16 variant (default)
+// Same native-tile operands and slab layout as the kernels above; only the multiply changes.  Each operand value is split
+// into three bf16 pieces x = x1 + x2 + x3 (24 mantissa bits, exact residuals) and the six products a1b1, a1b2, a2b1, a1b3,
+// a2b2, a3b1 are accumulated in fp32 by v_mfma_f32_32x32x16_bf16: the sum reproduces the fp32 product to 2^-24 (the
+// dropped terms are <= 2^-24 relative; scripts/micro/bf16_split_accuracy.py: 1.1e-7 vs fp64 against 2.9e-7 for the fp32
+// GEMM) while a 16-point k-step costs 6 x 32 cycles instead of 8 x 64 (v_mfma_f32_32x32x2_f32).  Two consecutive k-quads
+// of the native tiles give a lane its 8 k-values (4 + 4 points of its kk half); A and B use the same point <-> k-slot
+// map and the contraction index is a dummy, so no shuffling is needed.
+typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 bf16x8;
+struct Bf3 { bf16x8 p[3]; };
+
+__device__ __forceinline__ Bf3 split3(const f32x4& lo, const f32x4& hi) {
+    Bf3 r;
+    DH_UNROLL for (int e = 0; e < 8; ++e) {
+        const float v = e < 4 ? lo[e] : hi[e - 4];
+        const __bf16 h1 = (__bf16)v;
+        const float r1 = v - (float)h1;
+        const __bf16 h2 = (__bf16)r1;
+        const float r2 = r1 - (float)h2;
+        r.p[0][e] = h1; r.p[1][e] = h2; r.p[2][e] = (__bf16)r2;
+    }
+    return r;
+}
+
+__device__ __forceinline__ f32x16 mfma6(const Bf3& a, const Bf3& b, f32x16 c) {
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p[2], b.p[0], c, 0, 0, 0);      // smallest terms first
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p[1], b.p[1], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p[0], b.p[2], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p[1], b.p[0], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p[0], b.p[1], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p[0], b.p[0], c, 0, 0, 0);
+    return c;
+}
+
+// Piece staging: every operand tile of a k-pair (8 A tiles + NB B tiles of 16 points) is split ONCE per workgroup -- wave w
+// loads A tile w and B tile w (two f32x4 per tile and lane, straight from the native tiles: 1 KiB coalesced), splits them
+// and writes the three bf16x8 pieces lane-linear into a double-buffered 48 KiB LDS image; after one barrier every wave
+// reads the pieces of its 2 A + 4 B tiles (conflict-free ds_read_b128) and issues its 48 MFMAs.  (Splitting inside each
+// consumer wave instead costs 3x the VALU work -- 2 + 4 tiles per wave against 16 unique per workgroup: measured 4.43 ms
+// against 4.02 ms for this form and 5.65 ms for the native-fp32 kernel.)
+constexpr int DWP_TILE = 3 * 1024;                 // bytes of one tile's three pieces (64 lanes x 16 B each)
+constexpr int DWP_BUF = 16 * DWP_TILE;             // one k-pair: A tiles 0..7, B tiles 8..15
+
+template <int NB>
+__device__ __forceinline__ void dw_body_pieces(const DwJob& J, int64_t t0, int64_t t1, float* __restrict__ out, int wave,
+                                               int lane, char* lds) {
+    constexpr int KQ = MT * 4;
+    constexpr int BT = (NB == 8) ? TILE_F : AUXT_F;
+    constexpr int NA = DwShape<NB>::NA, NBW = DwShape<NB>::NBW;
+    f32x16 acc[NA][NBW];
+    DH_UNROLL for (int i = 0; i < NA; ++i) DH_UNROLL for (int j = 0; j < NBW; ++j) DH_UNROLL for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int T = (int)(t1 - t0);
+    const int npairs = J.A2 ? 2 : 1;
+    const int NP = npairs * T * (KQ / 2);                 // k-pairs (16 points each)
+    const bool has_b = NB == 8 || wave < 2;               // NB == 2: only two B tiles exist
+    struct Raw { f32x4 a0, a1, b0, b1; };
+    // load-side cursor over (operand pair, tile, k-pair)
+    int ld_pair = 0, ld_kp = 0;
+    int64_t ld_tile = t0;
+    auto load = [&](Raw& r) {
+        const float* A = ld_pair ? J.A2 : J.A1;
+        const float* Bm = ld_pair ? J.B2 : J.B1;
+        const int kq = 2 * ld_kp, m = kq >> 2, r4 = kq & 3;                       // r4 is 0 or 2: the pair is (r4, r4 + 1)
+        const f32x4* ga = reinterpret_cast<const f32x4*>(A + ld_tile * TILE_F) + ((((wave >> 1) * MT + m) * 2 + (wave & 1)) * 4 + r4) * 64 + lane;
+        r.a0 = ga[0]; r.a1 = ga[64];
+        if (has_b) {
+            const int bn = (NB == 8) ? wave : (wave & 1);
+            const int bi = (NB == 8) ? ((((bn >> 1) * MT + m) * 2 + (bn & 1)) * 4 + r4) : ((m * 2 + bn) * 4 + r4);
+            const f32x4* gb = reinterpret_cast<const f32x4*>(Bm + ld_tile * BT) + bi * 64 + lane;
+            r.b0 = gb[0]; r.b1 = gb[64];
+        }
+        if (++ld_kp == KQ / 2) {
+            ld_kp = 0;
+            if (++ld_tile == t1) { ld_tile = t0; ++ld_pair; }
+        }
+    };
+    auto publish = [&](const Raw& r, int par) {           // split this wave's two tiles and write their pieces
+        char* base = lds + par * DWP_BUF + lane * 16;
+        const Bf3 pa = split3(r.a0, r.a1);
+        DH_UNROLL for (int p = 0; p < 3; ++p) *reinterpret_cast<bf16x8*>(base + wave * DWP_TILE + p * 1024) = pa.p[p];
+        if (has_b) {
+            const Bf3 pb = split3(r.b0, r.b1);
+            const int bn = (NB == 8) ? wave : (wave & 1);
+            DH_UNROLL for (int p = 0; p < 3; ++p) *reinterpret_cast<bf16x8*>(base + (8 + bn) * DWP_TILE + p * 1024) = pb.p[p];
+        }
+    };
+    auto piece = [&](int par, int tile) {
+        Bf3 f;
+        const char* base = lds + par * DWP_BUF + tile * DWP_TILE + lane * 16;
+        DH_UNROLL for (int p = 0; p < 3; ++p) f.p[p] = *reinterpret_cast<const bf16x8*>(base + p * 1024);
+        return f;
+    };
+    if (NP > 0) {
+        Raw r0, r1;
+        load(r0);
+        if (NP > 1) load(r1);
+        __builtin_amdgcn_sched_barrier(0);
+        publish(r0, 0);
+        if (NP > 2) load(r0);                              // pair 2 in flight
+        __syncthreads();
+        constexpr int H = NBW / 2;
+        for (int p = 0; p < NP; ++p) {
+            const int par = p & 1;
+            Bf3 a[NA], b[H];
+            DH_UNROLL for (int ii = 0; ii < NA; ++ii) a[ii] = piece(par, (NB == 8) ? ((wave >> 1) * 2 + ii) : wave);
+            DH_UNROLL for (int j = 0; j < H; ++j) b[j] = piece(par, 8 + ((NB == 8) ? ((wave & 1) * 4 + j) : j));
+            __builtin_amdgcn_sched_barrier(0);
+            // the next pair's split + piece writes go under the LDS latency of the reads above (buffer par^1 was last read
+            // before the barrier that ended the previous iteration)
+            if (p + 1 < NP) publish((p & 1) ? r0 : r1, par ^ 1);
+            __builtin_amdgcn_sched_barrier(0);
+            DH_UNROLL for (int ii = 0; ii < NA; ++ii)
+                DH_UNROLL for (int j = 0; j < H; ++j) acc[ii][j] = mfma6(a[ii], b[j], acc[ii][j]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (H < NBW) {
+                DH_UNROLL for (int j = 0; j < H; ++j) b[j] = piece(par, 8 + ((NB == 8) ? ((wave & 1) * 4 + H + j) : (H + j)));
+            }
+            if (p + 3 < NP) load((p & 1) ? r0 : r1);       // pair p+3 into the registers publish() just consumed
+            __builtin_amdgcn_sched_barrier(0);
+            DH_UNROLL for (int ii = 0; ii < NA; ++ii)
+                DH_UNROLL for (int j = 0; j < H; ++j) acc[ii][H + j] = mfma6(a[ii], b[j], acc[ii][H + j]);
+            __builtin_amdgcn_sched_barrier(0);
+            __syncthreads();
+        }
+    }
+    DH_UNROLL for (int i = 0; i < NA; ++i)
+        DH_UNROLL for (int j = 0; j < NBW; ++j) {
+            const int ot = (NB == 8) ? ((wave >> 1) * 2 + i) : wave;
+            const int nt = (NB == 8) ? ((wave & 1) * 4 + j) : j;
+            float* o = out + ((int64_t)ot * NB + nt) * 1024 + lane;
+            DH_UNROLL for (int r = 0; r < 16; ++r) o[r * 64] = acc[i][j][r];
+        }
+}
+
+__global__ __launch_bounds__(512, 1) void dw_bf16x3_kernel(DwJobs jobs, int64_t ntiles, float* __restrict__ slabs, int64_t gstride) {
+    __shared__ __attribute__((aligned(16))) char pieces[2 * DWP_BUF];
+    const int G = gridDim.x, g = blockIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int64_t t0 = ntiles * g / G, t1 = ntiles * (g + 1) / G;
+    float* base = slabs + (int64_t)g * gstride;
+    for (int job = 0; job < jobs.n; ++job) {
+        const DwJob J = jobs.j[job];
+        if (J.nb == 8) dw_body_pieces<8>(J, t0, t1, base + J.off, wave, lane, pieces);
+        else dw_body_pieces<2>(J, t0, t1, base + J.off, wave, lane, pieces);
+    }
+}
+
 __global__ __launch_bounds__(512, 2) void dw_lds_kernel(DwJobs jobs, int64_t ntiles, float* __restrict__ slabs, int64_t gstride) {
     __shared__ __attribute__((aligned(16))) char ring[DW_STAGES * DW_STAGE_BYTES];
     const int G = gridDim.x, g = blockIdx.x;
@@ -409,8 +556,10 @@ int launch_weight_grads_gemm(const Workspace& w, float* slabs, int G, hipStream_
     SlabPtrs S{};
     build_dw_jobs(w, slabs + (int64_t)G * gstride, J, S);
     static const bool use_regs = getenv("DH_DW_REGS") != nullptr;     // A/B switch: register-streamed variant
+    static const bool use_f32 = getenv("DH_DW_F32") != nullptr;       // A/B switch: native fp32-MFMA LDS-DMA variant
     if (use_regs) hipLaunchKernelGGL(dw_kernel, dim3(G), dim3(512), 0, st, J, w.ntiles, slabs, gstride, (int64_t)-1);
-    else hipLaunchKernelGGL(dw_lds_kernel, dim3(G), dim3(512), 0, st, J, w.ntiles, slabs, gstride);
+    else if (use_f32) hipLaunchKernelGGL(dw_lds_kernel, dim3(G), dim3(512), 0, st, J, w.ntiles, slabs, gstride);
+    else hipLaunchKernelGGL(dw_bf16x3_kernel, dim3(G), dim3(512), 0, st, J, w.ntiles, slabs, gstride);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 
