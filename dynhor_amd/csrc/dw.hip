@@ -307,7 +307,7 @@ __device__ __forceinline__ void dw_body_pieces(const DwJob& J, int64_t t0, int64
         }
         if (++ld_kp == KQ / 2) {
             ld_kp = 0;
-            if (++ld_tile == t1) { ld_tile = t0; ++ld_pair; }
+            if (++ld_tile == t1) { ld_tile = t0; if (++ld_pair == npairs) ld_pair = 0; }    // past the end: wrap (harmless re-read)
         }
     };
     auto publish = [&](const Raw& r, int par) {           // split this wave's two tiles and write their pieces
@@ -329,21 +329,23 @@ __device__ __forceinline__ void dw_body_pieces(const DwJob& J, int64_t t0, int64
     if (NP > 0) {
         Raw r0, r1;
         load(r0);
-        if (NP > 1) load(r1);
+        load(r1);
         __builtin_amdgcn_sched_barrier(0);
         publish(r0, 0);
-        if (NP > 2) load(r0);                              // pair 2 in flight
+        load(r0);                                          // pair 2 in flight
         __syncthreads();
         constexpr int H = NBW / 2;
-        for (int p = 0; p < NP; ++p) {
-            const int par = p & 1;
+        // one k-pair; `nxt` holds the raw operands of pair p+1 (published here) and is refilled with pair p+3.  The two
+        // register sets alternate STATICALLY (the loop is unrolled by two): selecting the set with a run-time index makes the
+        // compiler load into temporaries and wait for them on the spot, which exposes the full HBM latency every pair.
+        auto step = [&](int p, int par, Raw& nxt) {
             Bf3 a[NA], b[H];
             DH_UNROLL for (int ii = 0; ii < NA; ++ii) a[ii] = piece(par, (NB == 8) ? ((wave >> 1) * 2 + ii) : wave);
             DH_UNROLL for (int j = 0; j < H; ++j) b[j] = piece(par, 8 + ((NB == 8) ? ((wave & 1) * 4 + j) : j));
             __builtin_amdgcn_sched_barrier(0);
             // the next pair's split + piece writes go under the LDS latency of the reads above (buffer par^1 was last read
-            // before the barrier that ended the previous iteration)
-            if (p + 1 < NP) publish((p & 1) ? r0 : r1, par ^ 1);
+            // before the barrier that ended the previous step)
+            if (p + 1 < NP) publish(nxt, par ^ 1);
             __builtin_amdgcn_sched_barrier(0);
             DH_UNROLL for (int ii = 0; ii < NA; ++ii)
                 DH_UNROLL for (int j = 0; j < H; ++j) acc[ii][j] = mfma6(a[ii], b[j], acc[ii][j]);
@@ -351,13 +353,20 @@ __device__ __forceinline__ void dw_body_pieces(const DwJob& J, int64_t t0, int64
             if (H < NBW) {
                 DH_UNROLL for (int j = 0; j < H; ++j) b[j] = piece(par, 8 + ((NB == 8) ? ((wave & 1) * 4 + H + j) : (H + j)));
             }
-            if (p + 3 < NP) load((p & 1) ? r0 : r1);       // pair p+3 into the registers publish() just consumed
+            load(nxt);      // pair p+3; UNCONDITIONAL so the compiler can count on it being in flight (vmcnt(4..7) at the next
+                            // publish instead of draining everything); past the end the cursor wraps onto valid memory
             __builtin_amdgcn_sched_barrier(0);
             DH_UNROLL for (int ii = 0; ii < NA; ++ii)
                 DH_UNROLL for (int j = 0; j < H; ++j) acc[ii][H + j] = mfma6(a[ii], b[j], acc[ii][H + j]);
             __builtin_amdgcn_sched_barrier(0);
             __syncthreads();
+        };
+        int p = 0;
+        for (; p + 1 < NP; p += 2) {
+            step(p, 0, r1);
+            step(p + 1, 1, r0);
         }
+        if (p < NP) step(p, 0, r1);
     }
     DH_UNROLL for (int i = 0; i < NA; ++i)
         DH_UNROLL for (int j = 0; j < NBW; ++j) {

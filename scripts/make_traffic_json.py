@@ -6,7 +6,7 @@ come from separate --pmc passes (TCC slots)."""
 import json, sys
 src, dst = sys.argv[1], sys.argv[2]
 p = json.load(open(src))
-stage_of = {"dw_lds_kernel": "weight_grads_gemm", "sdf_fwd_train_kernel": "sdf_forward", "sdf_grad_kernel": "sdf_gradient",
+stage_of = {"dw_lds_kernel": "weight_grads_gemm", "dw_bf16x3_kernel": "weight_grads_gemm", "sdf_fwd_train_kernel": "sdf_forward", "sdf_grad_kernel": "sdf_gradient",
             "color_fwd_kernel": "color_forward", "color_bwd_kernel": "color_backward", "sdf_tangent_kernel": "sdf_tangent",
             "sdf_bwd_kernel": "sdf_backward"}
 out = {}
