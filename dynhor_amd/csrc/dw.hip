@@ -7,7 +7,7 @@
 // (128 accumulator VGPRs at NB=8); split-K over tiles across gridDim.x workgroups, slabs reduced in fold_kernel
 // (deterministic: no float atomics).
 #include <cstdlib>
-#include "tile.h"
+#include "tile16.h"
 #include "kernels.h"
 #include "workspace.h"
 
@@ -242,32 +242,6 @@ __device__ __forceinline__ void dw_body_lds(const DwJob& J, int64_t t0, int64_t 
 // GEMM) while a 16-point k-step costs 6 x 32 cycles instead of 8 x 64 (v_mfma_f32_32x32x2_f32).  Two consecutive k-quads
 // of the native tiles give a lane its 8 k-values (4 + 4 points of its kk half); A and B use the same point <-> k-slot
 // map and the contraction index is a dummy, so no shuffling is needed.
-typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 bf16x8;
-struct Bf3 { bf16x8 p[3]; };
-
-__device__ __forceinline__ Bf3 split3(const f32x4& lo, const f32x4& hi) {
-    Bf3 r;
-    DH_UNROLL for (int e = 0; e < 8; ++e) {
-        const float v = e < 4 ? lo[e] : hi[e - 4];
-        const __bf16 h1 = (__bf16)v;
-        const float r1 = v - (float)h1;
-        const __bf16 h2 = (__bf16)r1;
-        const float r2 = r1 - (float)h2;
-        r.p[0][e] = h1; r.p[1][e] = h2; r.p[2][e] = (__bf16)r2;
-    }
-    return r;
-}
-
-__device__ __forceinline__ f32x16 mfma6(const Bf3& a, const Bf3& b, f32x16 c) {
-    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p[2], b.p[0], c, 0, 0, 0);      // smallest terms first
-    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p[1], b.p[1], c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p[0], b.p[2], c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p[1], b.p[0], c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p[0], b.p[1], c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p[0], b.p[0], c, 0, 0, 0);
-    return c;
-}
-
 // Piece staging: every operand tile of a k-pair (8 A tiles + NB B tiles of 16 points) is split ONCE per workgroup -- wave w
 // loads A tile w and B tile w (two f32x4 per tile and lane, straight from the native tiles: 1 KiB coalesced), splits them
 // and writes the three bf16x8 pieces lane-linear into a double-buffered 48 KiB LDS image; after one barrier every wave

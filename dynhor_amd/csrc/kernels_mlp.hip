@@ -1,8 +1,10 @@
+#include <cstdlib>
 // Tile-resident MLP chain kernels (SDF no-grad / train forward / input-gradient / colour forward and the
 // backward chains).  See tile.h for the tile GEMM primitives and layouts, DESIGN.md for the math.
 #include "tile.h"
 #include "kernels.h"
 #include "mlp_common.h"
+#include "tile16.h"
 
 namespace dh {
 
@@ -33,6 +35,56 @@ __global__ __launch_bounds__(256, TM == 128 ? 1 : 2) void sdf_nograd_kernel(SdfP
             __syncthreads();
         }
         const float s = row_dot256(smain, P.w8row0, tid) + P.b8_0[0];
+        const int64_t gp = tile * TM + tid / TPP;
+        if (tid % TPP == 0 && gp < npts) sdf_out[gp] = s;
+        __syncthreads();                     // smain/saux are rewritten by the next tile
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1 on the bf16 matrix cores at fp32 accuracy (tile16.h): same chain as sdf_nograd_kernel, the activation image is
+// three bf16 piece planes (122 KB with the aux planes -> one workgroup per CU), every product is six bf16 MFMAs.
+// ------------------------------------------------------------------------------------------------
+struct Sdf16Ptrs {
+    const bf16x8* main16[N_SDF];
+    const bf16x8* aux16[N_SDF];
+    const float* bias[N_SDF];
+    const float* w8row0;
+    const float* b8_0;
+};
+static inline Sdf16Ptrs make_sdf16_ptrs(const float* packed) {
+    Sdf16Ptrs P;
+    for (int l = 0; l < N_SDF; ++l) {
+        P.main16[l] = reinterpret_cast<const bf16x8*>(packed + PACK16.sdf_fwd_main[l]);
+        P.aux16[l] = reinterpret_cast<const bf16x8*>(packed + PACK16.sdf_fwd_aux[l]);
+        P.bias[l] = packed + PACK.sdf_bias[l];
+    }
+    P.w8row0 = packed + PACK.sdf_w8row0;
+    P.b8_0 = packed + PACK.sdf_b8_0;
+    return P;
+}
+
+__global__ __launch_bounds__(256, 1) void sdf_nograd16_kernel(Sdf16Ptrs P, const float* __restrict__ pts, int64_t npts,
+                                                              float* __restrict__ sdf_out) {
+    __shared__ __attribute__((aligned(16))) __bf16 smain[3 * P_MAIN];
+    __shared__ __attribute__((aligned(16))) __bf16 saux[3 * P_AUX];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int64_t ntiles = (npts + TM - 1) / TM;
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        embed_tile16(pts, tile * TM, npts, saux, tid);
+        __syncthreads();
+        f32x16 acc[MT][2];
+        for (int l = 0; l < 8; ++l) {
+            acc_zero(acc);
+            if (l > 0) gemm16_rows(acc, smain, P_MAIN, LDB, l == 4 ? 14 : 16, P.main16[l], wave, lane);
+            if (l == 0 || l == 4) gemm16_rows(acc, saux, P_AUX, LDA16, AUX_KC, P.aux16[l], wave, lane);
+            const float b0 = P.bias[l][acc_col(wave, 0, lane)], b1 = P.bias[l][acc_col(wave, 1, lane)];
+            acc_map(acc, [&](int, int t, int, float v) { return softplus100(v + (t ? b1 : b0)); });
+            __syncthreads();                 // every wave finished reading smain as the A operand
+            acc_to_lds16(acc, smain, wave, lane);
+            __syncthreads();
+        }
+        const float s = row_dot256_16(smain, P.w8row0, tid) + P.b8_0[0];
         const int64_t gp = tile * TM + tid / TPP;
         if (tid % TPP == 0 && gp < npts) sdf_out[gp] = s;
         __syncthreads();                     // smain/saux are rewritten by the next tile
@@ -254,7 +306,9 @@ int launch_sdf_nograd(const float* packed, const float* pts, int64_t npts, float
     if (npts <= 0) return 0;
     const int64_t ntiles = (npts + TM - 1) / TM;
     const int g = (int)(ntiles < grid ? ntiles : grid);
-    hipLaunchKernelGGL(sdf_nograd_kernel, dim3(g), dim3(256), 0, stream, make_sdf_ptrs(packed), pts, npts, sdf);
+    static const bool f32 = getenv("DH_NOGRAD_F32") != nullptr;        // A/B switch: native fp32-MFMA chain
+    if (f32) hipLaunchKernelGGL(sdf_nograd_kernel, dim3(g), dim3(256), 0, stream, make_sdf_ptrs(packed), pts, npts, sdf);
+    else hipLaunchKernelGGL(sdf_nograd16_kernel, dim3(g < 256 ? g : 256), dim3(256), 0, stream, make_sdf16_ptrs(packed), pts, npts, sdf);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 

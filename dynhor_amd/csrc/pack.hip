@@ -1,6 +1,6 @@
 // Weight preparation: weight-norm row scales, then MFMA-operand packing of every linear (layout.h).
 // Runs once per optimiser step (weights change every iteration); ~5 MB written, L2-resident afterwards.
-#include "tile.h"
+#include "tile16.h"
 #include "kernels.h"
 
 namespace dh {
@@ -93,6 +93,54 @@ __global__ __launch_bounds__(256) void pack_small_kernel(const float* __restrict
     }
 }
 
+// split-bf16 B operands (tile16.h): same job description as pack_kernel with nkg = number of 16-deep k-chunks
+__global__ __launch_bounds__(256) void pack16_kernel(const float* __restrict__ params, float* __restrict__ packed, PackJobs jobs) {
+    const PackJob J = jobs.j[blockIdx.y];
+    const int64_t total = (int64_t)J.nkg * J.nt * 64;
+    bf16x8* dst = reinterpret_cast<bf16x8*>(packed + J.dst);
+    for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int lane = i & 63;
+        const int nt = (i >> 6) % J.nt;
+        const int kc = (i >> 6) / J.nt;
+        const int n = nt * 32 + (lane & 31);
+        Bf3 w;
+        DH_UNROLL for (int s = 0; s < 8; ++s) {
+            const int k = kc * 16 + 8 * (lane >> 5) + s;
+            const int o = J.rev ? k : n, c = J.rev ? n : k;
+            float x = 0.f;
+            if (o < J.out_valid && c < J.in_valid) {
+                const int row = o + J.row_off;
+                x = J.scale * packed[J.rsoff + row] * params[J.voff + (int64_t)row * J.ldv + J.col_off + c];
+            }
+            __bf16 h1, h2, h3;
+            split_f32(x, h1, h2, h3);
+            w.p[0][s] = h1; w.p[1][s] = h2; w.p[2][s] = h3;
+        }
+        DH_UNROLL for (int p = 0; p < 3; ++p) dst[(((int64_t)kc * J.nt + nt) * 3 + p) * 64 + lane] = w.p[p];
+    }
+}
+
+static PackJobs build_jobs16() {
+    PackJobs J{};
+    int n = 0;
+    auto add = [&](int64_t dst, int64_t voff, int64_t rsoff, int ldv, int nkc, int nt, int rev, int row_off, int col_off,
+                   int out_valid, int in_valid, float scale) {
+        J.j[n++] = PackJob{dst, voff, rsoff, ldv, nkc, nt, rev, row_off, col_off, out_valid, in_valid, scale};
+    };
+    for (int l = 0; l < 8; ++l) {
+        const int64_t rs = PACK.rowscale + (int64_t)l * 260;
+        const int64_t v = sdf_off(l).v;
+        const int in = SDF_DIMS[l].in, out = SDF_DIMS[l].out;
+        if (l == 0) add(PACK16.sdf_fwd_aux[0], v, rs, in, 3, 8, 0, 0, 0, out, EMB, 1.f);
+        else if (l == 4) {
+            add(PACK16.sdf_fwd_main[4], v, rs, in, 14, 8, 0, 0, 0, out, SKIP_OUT, INV_SQRT2);
+            add(PACK16.sdf_fwd_aux[4], v, rs, in, 3, 8, 0, 0, SKIP_OUT, out, EMB, INV_SQRT2);
+        } else add(PACK16.sdf_fwd_main[l], v, rs, in, 16, 8, 0, 0, 0, out, in, 1.f);
+    }
+    J.n = n;
+    return J;
+}
+
 static PackJobs build_jobs() {
     PackJobs J{};
     int n = 0;
@@ -143,6 +191,8 @@ int launch_pack_weights(const float* params, float* packed, hipStream_t stream) 
     hipLaunchKernelGGL(rowscale_kernel, dim3(65, N_SDF + N_COL), dim3(256), 0, stream, params, packed);
     hipLaunchKernelGGL(pack_kernel, dim3(16, jobs.n), dim3(256), 0, stream, params, packed, jobs);
     hipLaunchKernelGGL(pack_small_kernel, dim3(N_SDF + 1 + 4 + 1), dim3(256), 0, stream, params, packed);
+    static const PackJobs jobs16 = build_jobs16();
+    hipLaunchKernelGGL(pack16_kernel, dim3(8, jobs16.n), dim3(256), 0, stream, params, packed, jobs16);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 
