@@ -91,6 +91,42 @@ __global__ __launch_bounds__(256, 1) void sdf_nograd16_kernel(Sdf16Ptrs P, const
     }
 }
 
+// K2a on the split-bf16 core: same outputs and saved native tiles as sdf_fwd_train_kernel
+__global__ __launch_bounds__(256, 1) void sdf_fwd_train16_kernel(Sdf16Ptrs P, const float* __restrict__ pts, int64_t npts,
+                                                                 float* __restrict__ sdf_out, float* __restrict__ feat,
+                                                                 float* __restrict__ act, float* __restrict__ eaux) {
+    __shared__ __attribute__((aligned(16))) __bf16 smain[3 * P_MAIN];
+    __shared__ __attribute__((aligned(16))) __bf16 saux[3 * P_AUX];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int64_t ntiles = (npts + TM - 1) / TM;
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        embed_tile16(pts, tile * TM, npts, saux, tid);
+        __syncthreads();
+        aux_lds16_to_native(saux, eaux + tile * AUXT_F, wave, lane);
+        f32x16 acc[MT][2];
+        for (int l = 0; l < 8; ++l) {
+            acc_zero(acc);
+            if (l > 0) gemm16_rows(acc, smain, P_MAIN, LDB, l == 4 ? 14 : 16, P.main16[l], wave, lane);
+            if (l == 0 || l == 4) gemm16_rows(acc, saux, P_AUX, LDA16, AUX_KC, P.aux16[l], wave, lane);
+            const float b0 = P.bias[l][acc_col(wave, 0, lane)], b1 = P.bias[l][acc_col(wave, 1, lane)];
+            acc_map(acc, [&](int, int t, int, float v) { return softplus100(v + (t ? b1 : b0)); });
+            acc_store_native(acc, act + ((int64_t)l * ntiles + tile) * TILE_F, wave, lane);
+            __syncthreads();
+            acc_to_lds16(acc, smain, wave, lane);
+            __syncthreads();
+        }
+        const float s = row_dot256_16(smain, P.w8row0, tid) + P.b8_0[0];
+        const int64_t gp = tile * TM + tid / TPP;
+        if (tid % TPP == 0 && gp < npts) sdf_out[gp] = s;
+        acc_zero(acc);
+        gemm16_rows(acc, smain, P_MAIN, LDB, 16, P.main16[8], wave, lane);
+        const float b0 = P.bias[8][acc_col(wave, 0, lane)], b1 = P.bias[8][acc_col(wave, 1, lane)];
+        acc_map(acc, [&](int, int t, int, float v) { return v + (t ? b1 : b0); });
+        acc_store_native(acc, feat + tile * TILE_F, wave, lane);
+        __syncthreads();
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // K2a: SDF forward for training: saves the embedding (aux native) and every layer input act[l] (l=1..8,
 // post-softplus, native tiles), writes feat = lin8 rows 1..256 (native) and sdf = lin8 row 0 (VALU dot).
@@ -282,7 +318,9 @@ int launch_sdf_fwd_train(const float* packed, const float* pts, int64_t npts, fl
                          float* eaux, int grid, hipStream_t stream) {
     const int64_t ntiles = (npts + TM - 1) / TM;
     const int g = (int)(ntiles < grid ? ntiles : grid);
-    hipLaunchKernelGGL(sdf_fwd_train_kernel, dim3(g), dim3(256), 0, stream, make_sdf_ptrs(packed), pts, npts, sdf, feat, act, eaux);
+    static const bool f32 = getenv("DH_FWD_F32") != nullptr;           // A/B switch: native fp32-MFMA chain
+    if (f32) hipLaunchKernelGGL(sdf_fwd_train_kernel, dim3(g), dim3(256), 0, stream, make_sdf_ptrs(packed), pts, npts, sdf, feat, act, eaux);
+    else hipLaunchKernelGGL(sdf_fwd_train16_kernel, dim3(g < 256 ? g : 256), dim3(256), 0, stream, make_sdf16_ptrs(packed), pts, npts, sdf, feat, act, eaux);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 int launch_sdf_grad(const float* packed, const float* pts, int64_t npts, const float* act, float* asave, float* normals,

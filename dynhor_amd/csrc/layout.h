@@ -122,11 +122,11 @@ constexpr PackOff PACK = make_pack_off();
 // ---------------------------------------------------------------- split-bf16 packed weights (tile16.h), appended after PACK
 // bf16x8 (16 B = 4 floats) index ((kc*NT + nt)*3 + piece)*64 + lane; offsets below are FLOAT offsets into `packed`.
 struct Pack16Off {
-    int64_t sdf_fwd_main[N_SDF];   // l = 1..7 (l = 4: 14 k-chunks, scaled 1/sqrt2)
+    int64_t sdf_fwd_main[N_SDF];   // l = 1..8 (l = 4: 14 k-chunks, scaled 1/sqrt2; l = 8: rows 1..256)
     int64_t sdf_fwd_aux[N_SDF];    // l = 0, 4 (3 k-chunks: 39 -> 48)
     int64_t total;                 // end of the whole packed buffer
 };
-constexpr int sdf_kc_main(int l) { return (l == 0 || l == 8) ? 0 : (l == 4 ? 14 : 16); }
+constexpr int sdf_kc_main(int l) { return l == 0 ? 0 : (l == 4 ? 14 : 16); }
 constexpr int64_t pack16_floats(int nkc, int nt) { return (int64_t)nkc * nt * 3 * 64 * 4; }
 constexpr Pack16Off make_pack16_off() {
     Pack16Off p{};

@@ -137,6 +137,7 @@ static PackJobs build_jobs16() {
             add(PACK16.sdf_fwd_aux[4], v, rs, in, 3, 8, 0, 0, SKIP_OUT, out, EMB, INV_SQRT2);
         } else add(PACK16.sdf_fwd_main[l], v, rs, in, 16, 8, 0, 0, 0, out, in, 1.f);
     }
+    add(PACK16.sdf_fwd_main[8], sdf_off(8).v, PACK.rowscale + 8 * 260, SDF_DIMS[8].in, 16, 8, 0, 1, 0, 256, 256, 1.f);
     J.n = n;
     return J;
 }

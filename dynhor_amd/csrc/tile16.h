@@ -141,4 +141,21 @@ __device__ __forceinline__ float row_dot256_16(const __bf16* main, const float* 
     return s;
 }
 
+// LDS aux piece planes (cols < 40 valid) -> fp32 aux native tile in HBM (same layout as tile.h aux_lds_to_native)
+__device__ __forceinline__ void aux_lds16_to_native(const __bf16* aux, float* __restrict__ tile, int wave, int lane) {
+    f32x16 a2[AUX_NTW];
+    DH_UNROLL for (int tt = 0; tt < AUX_NTW; ++tt) {
+        const int col = aux_col(wave, tt, lane);
+        DH_UNROLL for (int r = 0; r < 16; ++r) {
+            float v = 0.f;
+            if (col < AUXW) {
+                const __bf16* e = aux + aux_row(wave, r, lane) * LDA16 + col;
+                v = ((float)e[0] + (float)e[P_AUX]) + (float)e[2 * P_AUX];
+            }
+            a2[tt][r] = v;
+        }
+    }
+    aux_store_native(a2, tile, wave, lane);
+}
+
 }  // namespace dh
