@@ -48,6 +48,8 @@ __global__ __launch_bounds__(256, TM == 128 ? 1 : 2) void sdf_nograd_kernel(SdfP
 struct Sdf16Ptrs {
     const bf16x8* main16[N_SDF];
     const bf16x8* aux16[N_SDF];
+    const bf16x8* rev16[N_SDF];
+    const bf16x8* revaux16[N_SDF];
     const float* bias[N_SDF];
     const float* w8row0;
     const float* b8_0;
@@ -57,6 +59,8 @@ static inline Sdf16Ptrs make_sdf16_ptrs(const float* packed) {
     for (int l = 0; l < N_SDF; ++l) {
         P.main16[l] = reinterpret_cast<const bf16x8*>(packed + PACK16.sdf_fwd_main[l]);
         P.aux16[l] = reinterpret_cast<const bf16x8*>(packed + PACK16.sdf_fwd_aux[l]);
+        P.rev16[l] = reinterpret_cast<const bf16x8*>(packed + PACK16.sdf_rev_main[l]);
+        P.revaux16[l] = reinterpret_cast<const bf16x8*>(packed + PACK16.sdf_rev_aux[l]);
         P.bias[l] = packed + PACK.sdf_bias[l];
     }
     P.w8row0 = packed + PACK.sdf_w8row0;
@@ -250,6 +254,81 @@ __global__ __launch_bounds__(256, TM == 128 ? 1 : 2) void sdf_grad_kernel(SdfPtr
     }
 }
 
+// K2b on the split-bf16 core (same saved tiles and outputs as sdf_grad_kernel; the small ge / saux image stays fp32)
+__global__ __launch_bounds__(256, 1) void sdf_grad16_kernel(Sdf16Ptrs P, const float* __restrict__ pts, int64_t npts,
+                                                           const float* __restrict__ act, float* __restrict__ asave,
+                                                           float* __restrict__ normals, int save) {
+    __shared__ __attribute__((aligned(16))) __bf16 smain[3 * P_MAIN];
+    __shared__ __attribute__((aligned(16))) float saux[TM * LDA];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int64_t ntiles = (npts + TM - 1) / TM;
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        f32x16 acc[MT][2];
+        f32x16 ge[AUX_NTW];
+        aux_zero(ge);
+        // a_7 = W8[0,:] * sigma'(z_7)
+        {
+            const float w0 = P.w8row0[acc_col(wave, 0, lane)], w1 = P.w8row0[acc_col(wave, 1, lane)];
+            acc_load_native(acc, act + ((int64_t)7 * ntiles + tile) * TILE_F, wave, lane);
+            acc_map(acc, [&](int, int t, int, float h) { float s, em; softplus_deriv_from_h(h, s, em); return (t ? w1 : w0) * s; });
+            if (save) acc_store_native(acc, asave + ((int64_t)7 * ntiles + tile) * TILE_F, wave, lane);
+            acc_to_lds16(acc, smain, wave, lane);
+            __syncthreads();
+        }
+        for (int l = 7; l >= 1; --l) {
+            acc_zero(acc);
+            gemm16_rows(acc, smain, P_MAIN, LDB, 16, P.rev16[l], wave, lane);        // u_l = a_l W_l
+            if (l == 4) gemm16_auxout(ge, smain, 16, P.revaux16[4], wave, lane);      // skip path -> ge
+            // a_{l-1} = u_l * sigma'(z_{l-1})   (sigma' from act[l-1] == input of layer l)
+            const f32x4* hp = reinterpret_cast<const f32x4*>(act + ((int64_t)(l - 1) * ntiles + tile) * TILE_F) + (size_t)wave * MT * 8 * 64 + lane;
+            DH_UNROLL for (int m = 0; m < MT; ++m) {
+                DH_UNROLL for (int t = 0; t < 2; ++t)
+                    DH_UNROLL for (int r4 = 0; r4 < 4; ++r4) {
+                        const f32x4 h = hp[((m * 2 + t) * 4 + r4) * 64];
+                        DH_UNROLL for (int rr = 0; rr < 4; ++rr) {
+                            float s, em; softplus_deriv_from_h(h[rr], s, em);
+                            acc[m][t][4 * r4 + rr] *= s;
+                        }
+                    }
+                __builtin_amdgcn_sched_barrier(0);     // bound live registers: one m-slab (8 float4) in flight
+            }
+            if (save) acc_store_native(acc, asave + ((int64_t)(l - 1) * ntiles + tile) * TILE_F, wave, lane);
+            __syncthreads();
+            acc_to_lds16(acc, smain, wave, lane);
+            __syncthreads();
+        }
+        gemm16_auxout(ge, smain, 16, P.revaux16[0], wave, lane);                     // ge += a_0 W_0
+        // ge -> LDS aux image
+        DH_UNROLL for (int tt = 0; tt < AUX_NTW; ++tt) {
+            const int col = aux_col(wave, tt, lane);
+            if (col < AUXW) {
+                DH_UNROLL for (int r = 0; r < 16; ++r) saux[aux_row(wave, r, lane) * LDA + col] = ge[tt][r];
+            }
+        }
+        __syncthreads();
+        if (tid < TM) {
+            const int64_t gp = tile * TM + tid;
+            if (gp < npts) {
+                const float* g = saux + tid * LDA;
+                float n[3];
+                DH_UNROLL for (int c = 0; c < 3; ++c) {
+                    const float x = pts[gp * 3 + c];
+                    float v = g[c];
+                    DH_UNROLL for (int k = 0; k < 6; ++k) {
+                        const float f = (float)(1 << k);
+                        float s, co; sincosf(x * f, &s, &co);
+                        v += f * (co * g[3 + 6 * k + c] - s * g[3 + 6 * k + 3 + c]);
+                    }
+                    n[c] = v;
+                }
+                normals[gp * 3 + 0] = n[0]; normals[gp * 3 + 1] = n[1]; normals[gp * 3 + 2] = n[2];
+            }
+        }
+        __syncthreads();
+    }
+}
+
+
 // ------------------------------------------------------------------------------------------------
 // K2c: RenderingNetwork forward (mode idr, App. A.3).  input = [p(3), embed_4(view)(27), n(3) | feat(256)]:
 // the 33 extras live in the aux image, feat in the main image.  Saves caux (aux native), the post-ReLU
@@ -314,6 +393,86 @@ __global__ __launch_bounds__(256, TM == 128 ? 1 : 2) void color_fwd_kernel(ColPt
     }
 }
 
+struct Col16Ptrs {
+    const bf16x8* main16[4];
+    const bf16x8* rev16[4];
+    const bf16x8* aux16;
+    const bf16x8* revaux16;
+    const float* bias[4];
+    const float* w4;
+    const float* b4;
+};
+static inline Col16Ptrs make_col16_ptrs(const float* packed) {
+    Col16Ptrs C;
+    for (int l = 0; l < 4; ++l) {
+        C.main16[l] = reinterpret_cast<const bf16x8*>(packed + PACK16.col_fwd_main[l]);
+        C.rev16[l] = reinterpret_cast<const bf16x8*>(packed + PACK16.col_rev_main[l]);
+        C.bias[l] = packed + PACK.col_bias[l];
+    }
+    C.aux16 = reinterpret_cast<const bf16x8*>(packed + PACK16.col_fwd_aux0);
+    C.revaux16 = reinterpret_cast<const bf16x8*>(packed + PACK16.col_rev_aux0);
+    C.w4 = packed + PACK.col_w4;
+    C.b4 = packed + PACK.col_b4;
+    return C;
+}
+
+// K2c on the split-bf16 core
+__global__ __launch_bounds__(256, 1) void color_fwd16_kernel(Col16Ptrs C, const float* __restrict__ pts, const float* __restrict__ dirs,
+                                                            int n_per_ray, const float* __restrict__ normals,
+                                                            const float* __restrict__ feat, int64_t npts,
+                                                            float* __restrict__ color, float* __restrict__ cact,
+                                                            float* __restrict__ caux, int save) {
+    __shared__ __attribute__((aligned(16))) __bf16 smain[3 * P_MAIN];
+    __shared__ __attribute__((aligned(16))) __bf16 saux[3 * P_AUX];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int64_t ntiles = (npts + TM - 1) / TM;
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        if (tid < TM) {
+            const int64_t gp = tile * TM + tid;
+            __bf16* row = saux + tid * LDA16;
+            if (gp < npts) {
+                const int64_t ray = gp / n_per_ray;
+                DH_UNROLL for (int c = 0; c < 3; ++c) {
+                    const float d = dirs[ray * 3 + c];
+                    aux_put16(row, c, pts[gp * 3 + c]);
+                    aux_put16(row, 3 + c, d);
+                    DH_UNROLL for (int k = 0; k < 4; ++k) {
+                        float s, co; sincosf(d * (float)(1 << k), &s, &co);
+                        aux_put16(row, 6 + 6 * k + c, s);
+                        aux_put16(row, 6 + 6 * k + 3 + c, co);
+                    }
+                    aux_put16(row, 30 + c, normals[gp * 3 + c]);
+                }
+            } else {
+                DH_UNROLL for (int c = 0; c < CAUX; ++c) aux_put16(row, c, 0.f);
+            }
+            DH_UNROLL for (int c = CAUX; c < 48; ++c) aux_put16(row, c, 0.f);
+        }
+        f32x16 acc[MT][2];
+        acc_load_native(acc, feat + tile * TILE_F, wave, lane);
+        acc_to_lds16(acc, smain, wave, lane);
+        __syncthreads();
+        if (save) aux_lds16_to_native(saux, caux + tile * AUXT_F, wave, lane);
+        for (int l = 0; l < 4; ++l) {
+            acc_zero(acc);
+            gemm16_rows(acc, smain, P_MAIN, LDB, 16, C.main16[l], wave, lane);
+            if (l == 0) gemm16_rows(acc, saux, P_AUX, LDA16, AUX_KC, C.aux16, wave, lane);
+            const float b0 = C.bias[l][acc_col(wave, 0, lane)], b1 = C.bias[l][acc_col(wave, 1, lane)];
+            acc_map(acc, [&](int, int t, int, float v) { return fmaxf(v + (t ? b1 : b0), 0.f); });
+            if (save) acc_store_native(acc, cact + ((int64_t)l * ntiles + tile) * TILE_F, wave, lane);
+            __syncthreads();
+            acc_to_lds16(acc, smain, wave, lane);
+            __syncthreads();
+        }
+        const int64_t gp = tile * TM + tid / TPP;
+        DH_UNROLL for (int j = 0; j < 3; ++j) {
+            const float raw = row_dot256_16(smain, C.w4 + j * 256, tid) + C.b4[j];
+            if (tid % TPP == 0 && gp < npts) color[gp * 3 + j] = 1.f / (1.f + __expf(-raw));
+        }
+        __syncthreads();
+    }
+}
+
 int launch_sdf_fwd_train(const float* packed, const float* pts, int64_t npts, float* sdf, float* feat, float* act,
                          float* eaux, int grid, hipStream_t stream) {
     const int64_t ntiles = (npts + TM - 1) / TM;
@@ -327,7 +486,9 @@ int launch_sdf_grad(const float* packed, const float* pts, int64_t npts, const f
                     int save, int grid, hipStream_t stream) {
     const int64_t ntiles = (npts + TM - 1) / TM;
     const int g = (int)(ntiles < grid ? ntiles : grid);
-    hipLaunchKernelGGL(sdf_grad_kernel, dim3(g), dim3(256), 0, stream, make_sdf_ptrs(packed), pts, npts, act, asave, normals, save);
+    static const bool f32 = getenv("DH_GRAD_F32") != nullptr;          // A/B switch: native fp32-MFMA chain
+    if (f32) hipLaunchKernelGGL(sdf_grad_kernel, dim3(g), dim3(256), 0, stream, make_sdf_ptrs(packed), pts, npts, act, asave, normals, save);
+    else hipLaunchKernelGGL(sdf_grad16_kernel, dim3(g < 256 ? g : 256), dim3(256), 0, stream, make_sdf16_ptrs(packed), pts, npts, act, asave, normals, save);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 int launch_color_fwd(const float* packed, const float* pts, const float* dirs, int n_per_ray, const float* normals,
@@ -335,8 +496,11 @@ int launch_color_fwd(const float* packed, const float* pts, const float* dirs, i
                      hipStream_t stream) {
     const int64_t ntiles = (npts + TM - 1) / TM;
     const int g = (int)(ntiles < grid ? ntiles : grid);
-    hipLaunchKernelGGL(color_fwd_kernel, dim3(g), dim3(256), 0, stream, make_col_ptrs(packed), pts, dirs, n_per_ray, normals,
-                       feat, npts, color, cact, caux, save);
+    static const bool f32 = getenv("DH_COLFWD_F32") != nullptr;        // A/B switch: native fp32-MFMA chain
+    if (f32) hipLaunchKernelGGL(color_fwd_kernel, dim3(g), dim3(256), 0, stream, make_col_ptrs(packed), pts, dirs, n_per_ray, normals,
+                                feat, npts, color, cact, caux, save);
+    else hipLaunchKernelGGL(color_fwd16_kernel, dim3(g < 256 ? g : 256), dim3(256), 0, stream, make_col16_ptrs(packed), pts, dirs,
+                            n_per_ray, normals, feat, npts, color, cact, caux, save);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 

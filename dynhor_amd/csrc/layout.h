@@ -124,6 +124,12 @@ constexpr PackOff PACK = make_pack_off();
 struct Pack16Off {
     int64_t sdf_fwd_main[N_SDF];   // l = 1..8 (l = 4: 14 k-chunks, scaled 1/sqrt2; l = 8: rows 1..256)
     int64_t sdf_fwd_aux[N_SDF];    // l = 0, 4 (3 k-chunks: 39 -> 48)
+    int64_t sdf_rev_main[N_SDF];   // l = 1..8 (16 k-chunks, NT = 8): M[k = out][n = in]
+    int64_t sdf_rev_aux[N_SDF];    // l = 0, 4 (16 k-chunks, NT = 2)
+    int64_t col_fwd_main[N_COL];   // l = 0..3
+    int64_t col_fwd_aux0;          // 3 k-chunks (33 -> 48)
+    int64_t col_rev_main[N_COL];   // l = 0..3
+    int64_t col_rev_aux0;          // NT = 2
     int64_t total;                 // end of the whole packed buffer
 };
 constexpr int sdf_kc_main(int l) { return l == 0 ? 0 : (l == 4 ? 14 : 16); }
@@ -134,7 +140,15 @@ constexpr Pack16Off make_pack16_off() {
     for (int l = 0; l < N_SDF; ++l) {
         p.sdf_fwd_main[l] = o; o += pack16_floats(sdf_kc_main(l), 8);
         p.sdf_fwd_aux[l] = o;  o += (l == 0 || l == 4) ? pack16_floats(3, 8) : 0;
+        p.sdf_rev_main[l] = o; o += (l >= 1) ? pack16_floats(16, 8) : 0;
+        p.sdf_rev_aux[l] = o;  o += (l == 0 || l == 4) ? pack16_floats(16, 2) : 0;
     }
+    for (int l = 0; l < N_COL; ++l) {
+        p.col_fwd_main[l] = o; o += (l < 4) ? pack16_floats(16, 8) : 0;
+        p.col_rev_main[l] = o; o += (l < 4) ? pack16_floats(16, 8) : 0;
+    }
+    p.col_fwd_aux0 = o; o += pack16_floats(3, 8);
+    p.col_rev_aux0 = o; o += pack16_floats(16, 2);
     p.total = (o + 3) / 4 * 4;
     return p;
 }

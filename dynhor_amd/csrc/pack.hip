@@ -127,17 +127,40 @@ static PackJobs build_jobs16() {
                    int out_valid, int in_valid, float scale) {
         J.j[n++] = PackJob{dst, voff, rsoff, ldv, nkc, nt, rev, row_off, col_off, out_valid, in_valid, scale};
     };
-    for (int l = 0; l < 8; ++l) {
+    for (int l = 0; l < N_SDF; ++l) {
         const int64_t rs = PACK.rowscale + (int64_t)l * 260;
         const int64_t v = sdf_off(l).v;
         const int in = SDF_DIMS[l].in, out = SDF_DIMS[l].out;
-        if (l == 0) add(PACK16.sdf_fwd_aux[0], v, rs, in, 3, 8, 0, 0, 0, out, EMB, 1.f);
-        else if (l == 4) {
+        if (l == 0) {
+            add(PACK16.sdf_fwd_aux[0], v, rs, in, 3, 8, 0, 0, 0, out, EMB, 1.f);
+            add(PACK16.sdf_rev_aux[0], v, rs, in, 16, 2, 1, 0, 0, out, EMB, 1.f);
+        } else if (l == 4) {
             add(PACK16.sdf_fwd_main[4], v, rs, in, 14, 8, 0, 0, 0, out, SKIP_OUT, INV_SQRT2);
             add(PACK16.sdf_fwd_aux[4], v, rs, in, 3, 8, 0, 0, SKIP_OUT, out, EMB, INV_SQRT2);
-        } else add(PACK16.sdf_fwd_main[l], v, rs, in, 16, 8, 0, 0, 0, out, in, 1.f);
+            add(PACK16.sdf_rev_main[4], v, rs, in, 16, 8, 1, 0, 0, out, SKIP_OUT, INV_SQRT2);
+            add(PACK16.sdf_rev_aux[4], v, rs, in, 16, 2, 1, 0, SKIP_OUT, out, EMB, INV_SQRT2);
+        } else if (l == 8) {
+            add(PACK16.sdf_fwd_main[8], v, rs, in, 16, 8, 0, 1, 0, 256, 256, 1.f);
+            add(PACK16.sdf_rev_main[8], v, rs, in, 16, 8, 1, 1, 0, 256, 256, 1.f);
+        } else {
+            add(PACK16.sdf_fwd_main[l], v, rs, in, 16, 8, 0, 0, 0, out, in, 1.f);
+            add(PACK16.sdf_rev_main[l], v, rs, in, 16, 8, 1, 0, 0, out, in, 1.f);
+        }
     }
-    add(PACK16.sdf_fwd_main[8], sdf_off(8).v, PACK.rowscale + 8 * 260, SDF_DIMS[8].in, 16, 8, 0, 1, 0, 256, 256, 1.f);
+    for (int l = 0; l < 4; ++l) {
+        const int64_t rs = PACK.rowscale + (int64_t)N_SDF * 260 + (int64_t)l * 256;
+        const int64_t v = col_off(l).v;
+        const int in = COL_DIMS[l].in;
+        if (l == 0) {
+            add(PACK16.col_fwd_main[0], v, rs, in, 16, 8, 0, 0, CAUX, 256, 256, 1.f);
+            add(PACK16.col_fwd_aux0, v, rs, in, 3, 8, 0, 0, 0, 256, CAUX, 1.f);
+            add(PACK16.col_rev_main[0], v, rs, in, 16, 8, 1, 0, CAUX, 256, 256, 1.f);
+            add(PACK16.col_rev_aux0, v, rs, in, 16, 2, 1, 0, 0, 256, CAUX, 1.f);
+        } else {
+            add(PACK16.col_fwd_main[l], v, rs, in, 16, 8, 0, 0, 0, 256, 256, 1.f);
+            add(PACK16.col_rev_main[l], v, rs, in, 16, 8, 1, 0, 0, 256, 256, 1.f);
+        }
+    }
     J.n = n;
     return J;
 }

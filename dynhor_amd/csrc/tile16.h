@@ -141,6 +141,39 @@ __device__ __forceinline__ float row_dot256_16(const __bf16* main, const float* 
     return s;
 }
 
+// acc2[.] += X[rows of this wave's m-tile][16 nkc] * M (NT = 2): the 64-wide "aux" output (tile.h gemm_auxout)
+__device__ __forceinline__ void gemm16_auxout(f32x16 (&acc2)[AUX_NTW], const __bf16* xs, const int nkc,
+                                              const bf16x8* __restrict__ wp, const int wave, const int lane) {
+    const __bf16* xrow = xs + (32 * aux_mtile(wave) + (lane & 31)) * LDB + 8 * (lane >> 5);
+    const bf16x8* wl = wp + aux_ntile(wave, 0) * 3 * 64 + lane;
+    auto fetch = [&](Bf3& a, Bf3 (&b)[AUX_NTW], int kc) {
+        DH_UNROLL for (int t = 0; t < AUX_NTW; ++t)
+            DH_UNROLL for (int p = 0; p < 3; ++p) b[t].p[p] = wl[((kc * 2 + t) * 3 + p) * 64];
+        DH_UNROLL for (int p = 0; p < 3; ++p) a.p[p] = *reinterpret_cast<const bf16x8*>(xrow + p * P_MAIN + kc * 16);
+    };
+    Bf3 a0, a1, b0[AUX_NTW], b1[AUX_NTW];
+    fetch(a0, b0, 0);
+    _Pragma("unroll 1") for (int kc = 0; kc < nkc; kc += 2) {
+        fetch(a1, b1, (kc + 1 < nkc) ? kc + 1 : kc);
+        __builtin_amdgcn_sched_barrier(0);
+        DH_UNROLL for (int t = 0; t < AUX_NTW; ++t) acc2[t] = mfma6(a0, b0[t], acc2[t]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (kc + 1 < nkc) {
+            fetch(a0, b0, (kc + 2 < nkc) ? kc + 2 : kc + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            DH_UNROLL for (int t = 0; t < AUX_NTW; ++t) acc2[t] = mfma6(a1, b1[t], acc2[t]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
+// one fp32 value -> the three piece planes of an aux row
+__device__ __forceinline__ void aux_put16(__bf16* row, int c, float v) {
+    __bf16 h1, h2, h3;
+    split_f32(v, h1, h2, h3);
+    row[c] = h1; row[P_AUX + c] = h2; row[2 * P_AUX + c] = h3;
+}
+
 // LDS aux piece planes (cols < 40 valid) -> fp32 aux native tile in HBM (same layout as tile.h aux_lds_to_native)
 __device__ __forceinline__ void aux_lds16_to_native(const __bf16* aux, float* __restrict__ tile, int wave, int lane) {
     f32x16 a2[AUX_NTW];
