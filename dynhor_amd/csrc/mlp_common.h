@@ -1,6 +1,7 @@
 // Helpers shared by the forward and backward MLP chain kernels.
 #pragma once
 #include "tile.h"
+#include "tile16.h"
 
 namespace dh {
 
@@ -93,6 +94,54 @@ static inline ColPtrs make_col_ptrs(const float* packed) {
     }
     C.fwd_aux0 = reinterpret_cast<const f32x4*>(packed + PACK.col_fwd_aux0);
     C.rev_aux0 = reinterpret_cast<const f32x4*>(packed + PACK.col_rev_aux0);
+    C.w4 = packed + PACK.col_w4;
+    C.b4 = packed + PACK.col_b4;
+    return C;
+}
+
+
+// ---- pointers into the split-bf16 packed weights (layout.h PACK16)
+struct Sdf16Ptrs {
+    const bf16x8* main16[N_SDF];
+    const bf16x8* aux16[N_SDF];
+    const bf16x8* rev16[N_SDF];
+    const bf16x8* revaux16[N_SDF];
+    const float* bias[N_SDF];
+    const float* w8row0;
+    const float* b8_0;
+};
+static inline Sdf16Ptrs make_sdf16_ptrs(const float* packed) {
+    Sdf16Ptrs P;
+    for (int l = 0; l < N_SDF; ++l) {
+        P.main16[l] = reinterpret_cast<const bf16x8*>(packed + PACK16.sdf_fwd_main[l]);
+        P.aux16[l] = reinterpret_cast<const bf16x8*>(packed + PACK16.sdf_fwd_aux[l]);
+        P.rev16[l] = reinterpret_cast<const bf16x8*>(packed + PACK16.sdf_rev_main[l]);
+        P.revaux16[l] = reinterpret_cast<const bf16x8*>(packed + PACK16.sdf_rev_aux[l]);
+        P.bias[l] = packed + PACK.sdf_bias[l];
+    }
+    P.w8row0 = packed + PACK.sdf_w8row0;
+    P.b8_0 = packed + PACK.sdf_b8_0;
+    return P;
+}
+
+struct Col16Ptrs {
+    const bf16x8* main16[4];
+    const bf16x8* rev16[4];
+    const bf16x8* aux16;
+    const bf16x8* revaux16;
+    const float* bias[4];
+    const float* w4;
+    const float* b4;
+};
+static inline Col16Ptrs make_col16_ptrs(const float* packed) {
+    Col16Ptrs C;
+    for (int l = 0; l < 4; ++l) {
+        C.main16[l] = reinterpret_cast<const bf16x8*>(packed + PACK16.col_fwd_main[l]);
+        C.rev16[l] = reinterpret_cast<const bf16x8*>(packed + PACK16.col_rev_main[l]);
+        C.bias[l] = packed + PACK.col_bias[l];
+    }
+    C.aux16 = reinterpret_cast<const bf16x8*>(packed + PACK16.col_fwd_aux0);
+    C.revaux16 = reinterpret_cast<const bf16x8*>(packed + PACK16.col_rev_aux0);
     C.w4 = packed + PACK.col_w4;
     C.b4 = packed + PACK.col_b4;
     return C;
