@@ -6,11 +6,17 @@ come from separate --pmc passes (TCC slots)."""
 import json, sys
 src, dst = sys.argv[1], sys.argv[2]
 p = json.load(open(src))
-stage_of = {"dw_lds_kernel": "weight_grads_gemm", "dw_bf16x3_kernel": "weight_grads_gemm", "sdf_fwd_train_kernel": "sdf_forward", "sdf_grad_kernel": "sdf_gradient",
-            "color_fwd_kernel": "color_forward", "color_bwd_kernel": "color_backward", "sdf_tangent_kernel": "sdf_tangent",
-            "sdf_bwd_kernel": "sdf_backward"}
+stage_of = {"dw_lds_kernel": "weight_grads_gemm", "dw_bf16x3_kernel": "weight_grads_gemm",
+            "sdf_fwd_train_kernel": "sdf_forward", "sdf_fwd_train16_kernel": "sdf_forward",
+            "sdf_grad_kernel": "sdf_gradient", "sdf_grad16_kernel": "sdf_gradient",
+            "color_fwd_kernel": "color_forward", "color_fwd16_kernel": "color_forward",
+            "color_bwd_kernel": "color_backward", "color_bwd16_kernel": "color_backward",
+            "sdf_tangent_kernel": "sdf_tangent", "sdf_tangent16_kernel": "sdf_tangent",
+            "sdf_bwd_kernel": "sdf_backward", "sdf_bwd16_kernel": "sdf_backward"}
 out = {}
 for kern, stage in stage_of.items():
+    if kern not in p["prof_pmc2"] or kern not in p["prof_pmc3"]:
+        continue          # the variant that did not run in this profile
     f = p["prof_pmc2"][kern]["FETCH_SIZE"]["mean_per_dispatch"]
     w = p["prof_pmc3"][kern]["WRITE_SIZE"]["mean_per_dispatch"]
     out[stage] = {"kernel": kern, "hbm_bytes_per_launch": f * 1024 * 2 + w * 1024, "fetch_size_kb_raw": f, "write_size_kb_raw": w,
