@@ -72,6 +72,34 @@ __global__ __launch_bounds__(256, 1) void sdf_nograd16_kernel(Sdf16Ptrs P, const
     }
 }
 
+// K1, 8-wave form (tile16.h "8-wave variant"): 512 threads, two waves per SIMD
+__global__ __launch_bounds__(512, 1) void sdf_nograd16w8_kernel(Sdf16Ptrs P, const float* __restrict__ pts, int64_t npts,
+                                                                float* __restrict__ sdf_out) {
+    __shared__ __attribute__((aligned(16))) __bf16 smain[3 * P_MAIN];
+    __shared__ __attribute__((aligned(16))) __bf16 saux[3 * P_AUX];
+    const int tid = threadIdx.x, w8 = tid >> 6, lane = tid & 63;
+    const int64_t ntiles = (npts + TM - 1) / TM;
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        embed_tile16_w8(pts, tile * TM, npts, saux, tid);
+        __syncthreads();
+        f32x16 acc[MT];
+        for (int l = 0; l < 8; ++l) {
+            DH_UNROLL for (int m = 0; m < MT; ++m) DH_UNROLL for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+            if (l > 0) gemm16_rows_w8(acc, smain, P_MAIN, LDB, l == 4 ? 14 : 16, P.main16[l], w8, lane);
+            if (l == 0 || l == 4) gemm16_rows_w8(acc, saux, P_AUX, LDA16, AUX_KC, P.aux16[l], w8, lane);
+            const float b = P.bias[l][32 * w8 + (lane & 31)];
+            DH_UNROLL for (int m = 0; m < MT; ++m) DH_UNROLL for (int r = 0; r < 16; ++r) acc[m][r] = softplus100(acc[m][r] + b);
+            __syncthreads();                 // every wave finished reading smain as the A operand
+            acc_to_lds16_w8(acc, smain, w8, lane);
+            __syncthreads();
+        }
+        const float s = row_dot256_16_w8(smain, P.w8row0, tid) + P.b8_0[0];
+        const int64_t gp = tile * TM + (tid >> 3);
+        if ((tid & 7) == 0 && gp < npts) sdf_out[gp] = s;
+        __syncthreads();                     // smain/saux are rewritten by the next tile
+    }
+}
+
 // K2a on the split-bf16 core: same outputs and saved native tiles as sdf_fwd_train_kernel
 __global__ __launch_bounds__(256, 1) void sdf_fwd_train16_kernel(Sdf16Ptrs P, const float* __restrict__ pts, int64_t npts,
                                                                  float* __restrict__ sdf_out, float* __restrict__ feat,
@@ -464,7 +492,11 @@ int launch_sdf_nograd(const float* packed, const float* pts, int64_t npts, float
     const int g = (int)(ntiles < grid ? ntiles : grid);
     static const bool f32 = getenv("DH_NOGRAD_F32") != nullptr;        // A/B switch: native fp32-MFMA chain
     if (f32) hipLaunchKernelGGL(sdf_nograd_kernel, dim3(g), dim3(256), 0, stream, make_sdf_ptrs(packed), pts, npts, sdf);
-    else hipLaunchKernelGGL(sdf_nograd16_kernel, dim3(g < 256 ? g : 256), dim3(256), 0, stream, make_sdf16_ptrs(packed), pts, npts, sdf);
+    else {
+        static const bool w4 = getenv("DH_NOGRAD_W4") != nullptr;     // A/B switch: 4-wave form of the split-bf16 kernel
+        if (w4) hipLaunchKernelGGL(sdf_nograd16_kernel, dim3(g < 256 ? g : 256), dim3(256), 0, stream, make_sdf16_ptrs(packed), pts, npts, sdf);
+        else hipLaunchKernelGGL(sdf_nograd16w8_kernel, dim3(g < 256 ? g : 256), dim3(512), 0, stream, make_sdf16_ptrs(packed), pts, npts, sdf);
+    }
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 

@@ -191,4 +191,83 @@ __device__ __forceinline__ void aux_lds16_to_native(const __bf16* aux, float* __
     aux_store_native(a2, tile, wave, lane);
 }
 
+// ---------------------------------------------------------------- 8-wave variant (512 threads, two waves per SIMD)
+// Same tile, same LDS image; wave w8 = 0..7 owns the single 32-column tile ct = w8 (native index: wave = ct >> 1,
+// t = ct & 1), so acc is [MT][1] and the B operand per wave halves while every wave still reads the whole A image.
+// The second wave on each SIMD covers the epilogue (activation, split, 16-bit LDS writes) of the first.
+__device__ __forceinline__ void gemm16_rows_w8(f32x16 (&acc)[MT], const __bf16* xs, const int pstride, const int ld,
+                                               const int nkc, const bf16x8* __restrict__ wp, const int w8, const int lane) {
+    const __bf16* xrow = xs + (lane & 31) * ld + 8 * (lane >> 5);
+    const bf16x8* wl = wp + w8 * 3 * 64 + lane;
+    Bf3 a0[MT], b0, a1[MT], b1;
+    auto fetch = [&](Bf3 (&a)[MT], Bf3& b, int kc) {
+        DH_UNROLL for (int p = 0; p < 3; ++p) b.p[p] = wl[(kc * 8 * 3 + p) * 64];
+        DH_UNROLL for (int m = 0; m < MT; ++m)
+            DH_UNROLL for (int p = 0; p < 3; ++p)
+                a[m].p[p] = *reinterpret_cast<const bf16x8*>(xrow + p * pstride + m * 32 * ld + kc * 16);
+    };
+    fetch(a0, b0, 0);
+    _Pragma("unroll 1") for (int kc = 0; kc < nkc; kc += 2) {
+        fetch(a1, b1, (kc + 1 < nkc) ? kc + 1 : kc);
+        __builtin_amdgcn_sched_barrier(0);
+        DH_UNROLL for (int m = 0; m < MT; ++m) acc[m] = mfma6(a0[m], b0, acc[m]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (kc + 1 < nkc) {
+            fetch(a0, b0, (kc + 2 < nkc) ? kc + 2 : kc + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            DH_UNROLL for (int m = 0; m < MT; ++m) acc[m] = mfma6(a1[m], b1, acc[m]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
+__device__ __forceinline__ void acc_to_lds16_w8(const f32x16 (&acc)[MT], __bf16* xs, int w8, int lane) {
+    DH_UNROLL for (int m = 0; m < MT; ++m) {
+        __bf16* base = xs + (m * 32 + 4 * (lane >> 5)) * LDB + 32 * w8 + (lane & 31);
+        DH_UNROLL for (int r = 0; r < 16; ++r) {
+            __bf16 h1, h2, h3;
+            split_f32(acc[m][r], h1, h2, h3);
+            __bf16* e = base + ((r & 3) + 8 * (r >> 2)) * LDB;
+            e[0] = h1; e[P_MAIN] = h2; e[2 * P_MAIN] = h3;
+        }
+    }
+}
+
+// embedding with 512 threads: thread (p = tid & 63, part = tid >> 6): part 0 x, part 1 zero pad, parts 0..5 one frequency each
+__device__ __forceinline__ void embed_tile16_w8(const float* __restrict__ pts, int64_t base, int64_t npts, __bf16* aux, int tid) {
+    static_assert(TM == 64, "8-wave kernels are written for 64-point tiles");
+    const int p = tid & 63, part = tid >> 6;
+    const int64_t gp = base + p;
+    float x[3] = {0.f, 0.f, 0.f};
+    if (gp < npts) { x[0] = pts[gp * 3 + 0]; x[1] = pts[gp * 3 + 1]; x[2] = pts[gp * 3 + 2]; }
+    __bf16* row = aux + p * LDA16;
+    if (part == 6) { aux_put16(row, 0, x[0]); aux_put16(row, 1, x[1]); aux_put16(row, 2, x[2]); }
+    if (part == 7) { for (int c = 39; c < 48; ++c) aux_put16(row, c, 0.f); }
+    if (part < 6) {
+        const float f = (float)(1 << part);
+        DH_UNROLL for (int c = 0; c < 3; ++c) {
+            float s, co;
+            sincosf(x[c] * f, &s, &co);
+            aux_put16(row, 3 + 6 * part + c, s);
+            aux_put16(row, 3 + 6 * part + 3 + c, co);
+        }
+    }
+}
+
+// per-point dot with 8 threads per point (point = tid >> 3)
+__device__ __forceinline__ float row_dot256_16_w8(const __bf16* main, const float* __restrict__ w, int tid) {
+    const int p = tid >> 3, part = tid & 7;
+    const __bf16* xr = main + p * LDB + part * 32;
+    const float* wr = w + part * 32;
+    float s = 0.f;
+    DH_UNROLL for (int i = 0; i < 4; ++i) {
+        const bf16x8 a = *reinterpret_cast<const bf16x8*>(xr + 8 * i);
+        const bf16x8 b = *reinterpret_cast<const bf16x8*>(xr + P_MAIN + 8 * i);
+        const bf16x8 c = *reinterpret_cast<const bf16x8*>(xr + 2 * P_MAIN + 8 * i);
+        DH_UNROLL for (int e = 0; e < 8; ++e) s = fmaf(((float)a[e] + (float)b[e]) + (float)c[e], wr[8 * i + e], s);
+    }
+    DH_UNROLL for (int off = 1; off < 8; off <<= 1) s += __shfl_xor(s, off);
+    return s;
+}
+
 }  // namespace dh
