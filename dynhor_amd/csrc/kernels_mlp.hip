@@ -57,9 +57,9 @@ __global__ __launch_bounds__(256, 1) void sdf_nograd16_kernel(Sdf16Ptrs P, const
         f32x16 acc[MT][2];
         for (int l = 0; l < 8; ++l) {
             acc_zero(acc);
+            const float b0 = P.bias[l][acc_col(wave, 0, lane)], b1 = P.bias[l][acc_col(wave, 1, lane)];     // in flight under the GEMM
             if (l > 0) gemm16_rows(acc, smain, P_MAIN, LDB, l == 4 ? 14 : 16, P.main16[l], wave, lane);
             if (l == 0 || l == 4) gemm16_rows(acc, saux, P_AUX, LDA16, AUX_KC, P.aux16[l], wave, lane);
-            const float b0 = P.bias[l][acc_col(wave, 0, lane)], b1 = P.bias[l][acc_col(wave, 1, lane)];
             acc_map(acc, [&](int, int t, int, float v) { return softplus100(v + (t ? b1 : b0)); });
             __syncthreads();                 // every wave finished reading smain as the A operand
             acc_to_lds16(acc, smain, wave, lane);
@@ -85,9 +85,9 @@ __global__ __launch_bounds__(512, 1) void sdf_nograd16w8_kernel(Sdf16Ptrs P, con
         f32x16 acc[MT];
         for (int l = 0; l < 8; ++l) {
             DH_UNROLL for (int m = 0; m < MT; ++m) DH_UNROLL for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+            const float b = P.bias[l][32 * w8 + (lane & 31)];                 // in flight under the GEMM
             if (l > 0) gemm16_rows_w8(acc, smain, P_MAIN, LDB, l == 4 ? 14 : 16, P.main16[l], w8, lane);
             if (l == 0 || l == 4) gemm16_rows_w8(acc, saux, P_AUX, LDA16, AUX_KC, P.aux16[l], w8, lane);
-            const float b = P.bias[l][32 * w8 + (lane & 31)];
             DH_UNROLL for (int m = 0; m < MT; ++m) DH_UNROLL for (int r = 0; r < 16; ++r) acc[m][r] = softplus100(acc[m][r] + b);
             __syncthreads();                 // every wave finished reading smain as the A operand
             acc_to_lds16_w8(acc, smain, w8, lane);
@@ -115,9 +115,9 @@ __global__ __launch_bounds__(256, 1) void sdf_fwd_train16_kernel(Sdf16Ptrs P, co
         f32x16 acc[MT][2];
         for (int l = 0; l < 8; ++l) {
             acc_zero(acc);
+            const float b0 = P.bias[l][acc_col(wave, 0, lane)], b1 = P.bias[l][acc_col(wave, 1, lane)];     // in flight under the GEMM
             if (l > 0) gemm16_rows(acc, smain, P_MAIN, LDB, l == 4 ? 14 : 16, P.main16[l], wave, lane);
             if (l == 0 || l == 4) gemm16_rows(acc, saux, P_AUX, LDA16, AUX_KC, P.aux16[l], wave, lane);
-            const float b0 = P.bias[l][acc_col(wave, 0, lane)], b1 = P.bias[l][acc_col(wave, 1, lane)];
             acc_map(acc, [&](int, int t, int, float v) { return softplus100(v + (t ? b1 : b0)); });
             acc_store_native(acc, act + ((int64_t)l * ntiles + tile) * TILE_F, wave, lane);
             __syncthreads();
@@ -282,21 +282,18 @@ __global__ __launch_bounds__(256, 1) void sdf_grad16_kernel(Sdf16Ptrs P, const f
         }
         for (int l = 7; l >= 1; --l) {
             acc_zero(acc);
+            TileRegs hreg;                                                              // act[l-1] in flight under the GEMM
+            tile_prefetch(hreg, act + ((int64_t)(l - 1) * ntiles + tile) * TILE_F, wave, lane);
             gemm16_rows(acc, smain, P_MAIN, LDB, 16, P.rev16[l], wave, lane);        // u_l = a_l W_l
             if (l == 4) gemm16_auxout(ge, smain, 16, P.revaux16[4], wave, lane);      // skip path -> ge
             // a_{l-1} = u_l * sigma'(z_{l-1})   (sigma' from act[l-1] == input of layer l)
-            const f32x4* hp = reinterpret_cast<const f32x4*>(act + ((int64_t)(l - 1) * ntiles + tile) * TILE_F) + (size_t)wave * MT * 8 * 64 + lane;
-            DH_UNROLL for (int m = 0; m < MT; ++m) {
+            DH_UNROLL for (int m = 0; m < MT; ++m)
                 DH_UNROLL for (int t = 0; t < 2; ++t)
-                    DH_UNROLL for (int r4 = 0; r4 < 4; ++r4) {
-                        const f32x4 h = hp[((m * 2 + t) * 4 + r4) * 64];
+                    DH_UNROLL for (int r4 = 0; r4 < 4; ++r4)
                         DH_UNROLL for (int rr = 0; rr < 4; ++rr) {
-                            float s, em; softplus_deriv_from_h(h[rr], s, em);
+                            float s, em; softplus_deriv_from_h(hreg.v[m][t][r4][rr], s, em);
                             acc[m][t][4 * r4 + rr] *= s;
                         }
-                    }
-                __builtin_amdgcn_sched_barrier(0);     // bound live registers: one m-slab (8 float4) in flight
-            }
             if (save) acc_store_native(acc, asave + ((int64_t)(l - 1) * ntiles + tile) * TILE_F, wave, lane);
             __syncthreads();
             acc_to_lds16(acc, smain, wave, lane);
@@ -437,9 +434,9 @@ __global__ __launch_bounds__(256, 1) void color_fwd16_kernel(Col16Ptrs C, const 
         if (save) aux_lds16_to_native(saux, caux + tile * AUXT_F, wave, lane);
         for (int l = 0; l < 4; ++l) {
             acc_zero(acc);
+            const float b0 = C.bias[l][acc_col(wave, 0, lane)], b1 = C.bias[l][acc_col(wave, 1, lane)];     // in flight under the GEMM
             gemm16_rows(acc, smain, P_MAIN, LDB, 16, C.main16[l], wave, lane);
             if (l == 0) gemm16_rows(acc, saux, P_AUX, LDA16, AUX_KC, C.aux16, wave, lane);
-            const float b0 = C.bias[l][acc_col(wave, 0, lane)], b1 = C.bias[l][acc_col(wave, 1, lane)];
             acc_map(acc, [&](int, int t, int, float v) { return fmaxf(v + (t ? b1 : b0), 0.f); });
             if (save) acc_store_native(acc, cact + ((int64_t)l * ntiles + tile) * TILE_F, wave, lane);
             __syncthreads();

@@ -176,17 +176,14 @@ __global__ __launch_bounds__(256, 1) void color_bwd16_kernel(Col16Ptrs C, const 
         __syncthreads();
         for (int l = 3; l >= 1; --l) {
             acc_zero(acc);
+            TileRegs hreg;                                                                   // cact[l-1] in flight under the GEMM
+            tile_prefetch(hreg, cact + ((int64_t)(l - 1) * ntiles + tile) * TILE_F, wave, lane);
             gemm16_rows(acc, smain, P_MAIN, LDB, 16, C.rev16[l], wave, lane);             // hbar_l = zbar_l W_l
-            const f32x4* hp = reinterpret_cast<const f32x4*>(cact + ((int64_t)(l - 1) * ntiles + tile) * TILE_F) + (size_t)wave * MT * 8 * 64 + lane;
-            DH_UNROLL for (int m = 0; m < MT; ++m) {
+            DH_UNROLL for (int m = 0; m < MT; ++m)
                 DH_UNROLL for (int t = 0; t < 2; ++t)
-                    DH_UNROLL for (int r4 = 0; r4 < 4; ++r4) {
-                        const f32x4 h = hp[((m * 2 + t) * 4 + r4) * 64];
+                    DH_UNROLL for (int r4 = 0; r4 < 4; ++r4)
                         DH_UNROLL for (int rr = 0; rr < 4; ++rr)
-                            if (!(h[rr] > 0.f)) acc[m][t][4 * r4 + rr] = 0.f;
-                    }
-                __builtin_amdgcn_sched_barrier(0);
-            }
+                            if (!(hreg.v[m][t][r4][rr] > 0.f)) acc[m][t][4 * r4 + rr] = 0.f;
             acc_store_native(acc, czbar + ((int64_t)(l - 1) * ntiles + tile) * TILE_F, wave, lane);
             tile_colsum(acc, tp + (TP_COL_B0 + l - 1) * 256, wave, lane);
             __syncthreads();
@@ -472,6 +469,9 @@ __global__ __launch_bounds__(256, 1) void sdf_bwd16_kernel(Sdf16Ptrs P, const fl
         }
         // hbar_8 = featbar W8[1:,:] + sdfbar (x) W8[0,:]
         acc_zero(acc);
+        TileRegs hreg, rreg;                                     // act[l], rsave[l]: always one GEMM ahead of their use
+        tile_prefetch(hreg, act + ((int64_t)7 * ntiles + tile) * TILE_F, wave, lane);
+        tile_prefetch(rreg, rsave + ((int64_t)7 * ntiles + tile) * TILE_F, wave, lane);
         gemm16_rows(acc, smain, P_MAIN, LDB, 16, P.rev16[8], wave, lane);
         DH_UNROLL for (int m = 0; m < MT; ++m)
             DH_UNROLL for (int r = 0; r < 16; ++r) {
@@ -480,26 +480,19 @@ __global__ __launch_bounds__(256, 1) void sdf_bwd16_kernel(Sdf16Ptrs P, const fl
                 acc[m][1][r] = fmaf(sb, w0c1, acc[m][1][r]);
             }
         for (int l = 7; l >= 0; --l) {
-            const size_t woff = (size_t)wave * MT * 8 * 64 + lane;
-            const f32x4* hp = reinterpret_cast<const f32x4*>(act + ((int64_t)l * ntiles + tile) * TILE_F) + woff;
-            const f32x4* rp = reinterpret_cast<const f32x4*>(rsave + ((int64_t)l * ntiles + tile) * TILE_F) + woff;
             float ws0 = 0.f, ws1 = 0.f;                         // sum_rows sdfbar * h_8 (l == 7 only)
-            DH_UNROLL for (int m = 0; m < MT; ++m) {
+            DH_UNROLL for (int m = 0; m < MT; ++m)
                 DH_UNROLL for (int t = 0; t < 2; ++t)
-                    DH_UNROLL for (int r4 = 0; r4 < 4; ++r4) {
-                        const int idx = ((m * 2 + t) * 4 + r4) * 64;
-                        const f32x4 h = hp[idx], rv = rp[idx];
+                    DH_UNROLL for (int r4 = 0; r4 < 4; ++r4)
                         DH_UNROLL for (int rr = 0; rr < 4; ++rr) {
-                            float s, em; softplus_deriv_from_h(h[rr], s, em);
+                            const float h = hreg.v[m][t][r4][rr];
+                            float s, em; softplus_deriv_from_h(h, s, em);
                             if (l == 7) {
                                 const float sb = saux[acc_row(m, 4 * r4 + rr, lane)];
-                                if (t == 0) ws0 = fmaf(sb, h[rr], ws0); else ws1 = fmaf(sb, h[rr], ws1);
+                                if (t == 0) ws0 = fmaf(sb, h, ws0); else ws1 = fmaf(sb, h, ws1);
                             }
-                            acc[m][t][4 * r4 + rr] = fmaf(acc[m][t][4 * r4 + rr], s, rv[rr]);
+                            acc[m][t][4 * r4 + rr] = fmaf(acc[m][t][4 * r4 + rr], s, rreg.v[m][t][r4][rr]);
                         }
-                    }
-                __builtin_amdgcn_sched_barrier(0);
-            }
             if (l == 7) {
                 ws0 += __shfl_xor(ws0, 32); ws1 += __shfl_xor(ws1, 32);
                 if (lane < 32) {
@@ -514,6 +507,8 @@ __global__ __launch_bounds__(256, 1) void sdf_bwd16_kernel(Sdf16Ptrs P, const fl
                 acc_to_lds16(acc, smain, wave, lane);
                 __syncthreads();
                 acc_zero(acc);
+                tile_prefetch(hreg, act + ((int64_t)(l - 1) * ntiles + tile) * TILE_F, wave, lane);
+                tile_prefetch(rreg, rsave + ((int64_t)(l - 1) * ntiles + tile) * TILE_F, wave, lane);
                 gemm16_rows(acc, smain, P_MAIN, LDB, 16, P.rev16[l], wave, lane);    // hbar_l = zbar_l W_l
             }
         }

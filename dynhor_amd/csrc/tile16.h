@@ -191,6 +191,16 @@ __device__ __forceinline__ void aux_lds16_to_native(const __bf16* aux, float* __
     aux_store_native(a2, tile, wave, lane);
 }
 
+// A saved native tile as registers (same element order as the accumulators): issued BEFORE a GEMM so its HBM latency sits
+// under the MFMAs -- with one workgroup per CU nothing else would hide it.
+struct TileRegs { f32x4 v[MT][2][4]; };
+__device__ __forceinline__ void tile_prefetch(TileRegs& t, const float* __restrict__ tile, int wave, int lane) {
+    const f32x4* p = reinterpret_cast<const f32x4*>(tile) + (size_t)wave * MT * 8 * 64 + lane;
+    DH_UNROLL for (int m = 0; m < MT; ++m)
+        DH_UNROLL for (int tt = 0; tt < 2; ++tt)
+            DH_UNROLL for (int r4 = 0; r4 < 4; ++r4) t.v[m][tt][r4] = p[((m * 2 + tt) * 4 + r4) * 64];
+}
+
 // ---------------------------------------------------------------- 8-wave variant (512 threads, two waves per SIMD)
 // Same tile, same LDS image; wave w8 = 0..7 owns the single 32-column tile ct = w8 (native index: wave = ct >> 1,
 // t = ct & 1), so acc is [MT][1] and the B operand per wave halves while every wave still reads the whole A image.
