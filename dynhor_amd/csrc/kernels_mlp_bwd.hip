@@ -323,28 +323,24 @@ __global__ __launch_bounds__(256, 1) void sdf_tangent16_kernel(Sdf16Ptrs P, cons
         f32x16 acc[MT][2];
         for (int l = 0; l < 8; ++l) {
             acc_zero(acc);
+            TileRegs hreg, areg;                                                     // act[l], asave[l] in flight under the GEMM
+            tile_prefetch(hreg, act + ((int64_t)l * ntiles + tile) * TILE_F, wave, lane);
+            tile_prefetch(areg, asave + ((int64_t)l * ntiles + tile) * TILE_F, wave, lane);
             if (l > 0) gemm16_rows(acc, smain, P_MAIN, LDB, l == 4 ? 14 : 16, P.main16[l], wave, lane);
             if (l == 0 || l == 4) gemm16_rows(acc, saux, P_AUX, LDA16, AUX_KC, P.aux16[l], wave, lane);     // abar_l
-            const size_t woff = (size_t)wave * MT * 8 * 64 + lane;
-            const f32x4* hp = reinterpret_cast<const f32x4*>(act + ((int64_t)l * ntiles + tile) * TILE_F) + woff;
-            const f32x4* ap = reinterpret_cast<const f32x4*>(asave + ((int64_t)l * ntiles + tile) * TILE_F) + woff;
-            f32x4* rp = reinterpret_cast<f32x4*>(rsave + ((int64_t)l * ntiles + tile) * TILE_F) + woff;
-            DH_UNROLL for (int m = 0; m < MT; ++m) {
+            f32x4* rp = reinterpret_cast<f32x4*>(rsave + ((int64_t)l * ntiles + tile) * TILE_F) + (size_t)wave * MT * 8 * 64 + lane;
+            DH_UNROLL for (int m = 0; m < MT; ++m)
                 DH_UNROLL for (int t = 0; t < 2; ++t)
                     DH_UNROLL for (int r4 = 0; r4 < 4; ++r4) {
-                        const int idx = ((m * 2 + t) * 4 + r4) * 64;
-                        const f32x4 h = hp[idx], a = ap[idx];
                         f32x4 rv;
                         DH_UNROLL for (int rr = 0; rr < 4; ++rr) {
-                            float s, em; softplus_deriv_from_h(h[rr], s, em);
+                            float s, em; softplus_deriv_from_h(hreg.v[m][t][r4][rr], s, em);
                             const float ab = acc[m][t][4 * r4 + rr];
-                            rv[rr] = ab * a[rr] * (SOFTPLUS_BETA * em);
+                            rv[rr] = ab * areg.v[m][t][r4][rr] * (SOFTPLUS_BETA * em);
                             acc[m][t][4 * r4 + rr] = s * ab;
                         }
-                        rp[idx] = rv;
+                        rp[((m * 2 + t) * 4 + r4) * 64] = rv;
                     }
-                __builtin_amdgcn_sched_barrier(0);
-            }
             if (l < 7) {
                 acc_store_native(acc, tsave + ((int64_t)l * ntiles + tile) * TILE_F, wave, lane);    // t_{l+1}
                 __syncthreads();
