@@ -159,7 +159,7 @@ def main():
         hip_names = {"weight_grads_gemm": "dw_lds_kernel" if dw_f32 else "dw_bf16x3_kernel", "sdf_forward": "sdf_fwd_train16_kernel",
                      "sdf_gradient": "sdf_grad16_kernel", "color_forward": "color_fwd16_kernel",
                      "color_backward": "color_bwd16_kernel", "sdf_tangent": "sdf_tangent_kernel",
-                     "sdf_backward": "sdf_bwd16_kernel", "sdf_nograd_coarse": "sdf_nograd16_kernel"}
+                     "sdf_backward": "sdf_bwd16_kernel", "sdf_nograd_coarse": "sdf_nograd16w8_kernel"}
         # peak of the dominant kernel's own instruction mix: every GEMM except the tangent chain runs each fp32 product as 6
         # bf16 products (3-way split of both operands, fp32 accumulate: 2^-24 relative) on v_mfma_f32_32x32x16_bf16, so the
         # ceiling in ALGORITHMIC (fp32-product) FLOP/s is the dense bf16 peak / 6; the tangent chain runs
