@@ -12,8 +12,9 @@ namespace dh {
 #ifndef DH_TM
 #define DH_TM 64
 #endif
-constexpr int TM = DH_TM;      // points per tile (= rows of every tile GEMM): 64 -> 2 workgroups/CU (shipping config,
-                               // measured 9 % faster end to end); 128 -> 1 workgroup/CU (kept compiling, parity-green)
+constexpr int TM = DH_TM;      // points per tile (= rows of every tile GEMM): 64 is the shipping (and, since the split-bf16
+                               // kernels of tile16.h, the only building) configuration; 128 was measured 9 % slower
+                               // end to end with the fp32-MFMA kernels
 constexpr int MT = TM / 32;    // 32-row m-tiles per tile
 static_assert(TM == 64 || TM == 128, "tile height");
 constexpr int HID = 256;       // hidden width == main-tile width
