@@ -155,16 +155,23 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tpath):
             traffic = json.load(open(tpath)).get(dom, {}).get("hbm_bytes_per_launch")
-        dw_f32 = os.environ.get("DH_DW_F32") is not None or os.environ.get("DH_DW_REGS") is not None
-        hip_names = {"weight_grads_gemm": "dw_lds_kernel" if dw_f32 else "dw_bf16x3_kernel", "sdf_forward": "sdf_fwd_train16_kernel",
-                     "sdf_gradient": "sdf_grad16_kernel", "color_forward": "color_fwd16_kernel",
-                     "color_backward": "color_bwd16_kernel", "sdf_tangent": "sdf_tangent_kernel",
-                     "sdf_backward": "sdf_bwd16_kernel", "sdf_nograd_coarse": "sdf_nograd16w8_kernel"}
+        all_f32 = os.environ.get("DH_ALL_F32") is not None        # every GEMM on native fp32 MFMA (the A/B twins)
+        dw_f32 = all_f32 or os.environ.get("DH_DW_F32") is not None or os.environ.get("DH_DW_REGS") is not None
+        if all_f32:
+            hip_names = {"weight_grads_gemm": "dw_lds_kernel", "sdf_forward": "sdf_fwd_train_kernel",
+                         "sdf_gradient": "sdf_grad_kernel", "color_forward": "color_fwd_kernel",
+                         "color_backward": "color_bwd_kernel", "sdf_tangent": "sdf_tangent_kernel",
+                         "sdf_backward": "sdf_bwd_kernel", "sdf_nograd_coarse": "sdf_nograd_kernel"}
+        else:
+            hip_names = {"weight_grads_gemm": "dw_lds_kernel" if dw_f32 else "dw_bf16x3_kernel", "sdf_forward": "sdf_fwd_train16_kernel",
+                         "sdf_gradient": "sdf_grad16_kernel", "color_forward": "color_fwd16_kernel",
+                         "color_backward": "color_bwd16_kernel", "sdf_tangent": "sdf_tangent_kernel",
+                         "sdf_backward": "sdf_bwd16_kernel", "sdf_nograd_coarse": "sdf_nograd16w8_kernel"}
         # peak of the dominant kernel's own instruction mix: every GEMM except the tangent chain runs each fp32 product as 6
         # bf16 products (3-way split of both operands, fp32 accumulate: 2^-24 relative) on v_mfma_f32_32x32x16_bf16, so the
         # ceiling in ALGORITHMIC (fp32-product) FLOP/s is the dense bf16 peak / 6; the tangent chain runs
         # v_mfma_f32_32x32x2_f32 (157.3 TFLOP/s)
-        split = not (dom == "sdf_tangent" or (dom == "weight_grads_gemm" and dw_f32))
+        split = not (all_f32 or dom == "sdf_tangent" or (dom == "weight_grads_gemm" and dw_f32))
         peak = BF16_MFMA_PEAK_TFLOPS / 6.0 if split else FP32_MFMA_PEAK_TFLOPS
         roof = {"bound": "mfma", "kernel": hip_names.get(dom, dom), "stage": dom, "achieved": per_kernel[dom]["tflops"],
                 "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(per_kernel[dom]["tflops"] / peak, 4),
@@ -182,8 +189,9 @@ def main():
                                       "NeuS SDF(8x256, skip 4, softplus100) + colour(4x256) MLP, full training iteration",
                           "frames": args.frames, "rays_per_rank": B, "samples_per_ray": n_samples,
                           "parallelism": f"dp{world}", "loss": "rgb L1 + 0.1 eikonal + 0.1 mask BCE + 0.05 mono-normal",
-                          "arithmetic": "fp32 in / fp32 out everywhere; GEMMs as 3-way bf16 split of both operands (6 MFMA "
-                                        "products, fp32 accumulate: 2^-24 relative = fp32 accuracy); tangent chain on fp32 MFMA"},
+                          "arithmetic": ("fp32 everywhere, every GEMM on v_mfma_f32_32x32x2_f32 (DH_ALL_F32)" if all_f32 else
+                                         "fp32 in / fp32 out everywhere; GEMMs as 3-way bf16 split of both operands (6 MFMA "
+                                         "products, fp32 accumulate: 2^-24 relative = fp32 accuracy); tangent chain on fp32 MFMA")},
                "roofline": roof, "kernels": per_kernel,
                "final_stats": {"loss": round(float(stats[0]), 5), "psnr": round(float(stats[5]), 3)}}
         if world == 1 and not args.no_cpu_baseline:

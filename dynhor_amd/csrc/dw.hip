@@ -539,7 +539,7 @@ int launch_weight_grads_gemm(const Workspace& w, float* slabs, int G, hipStream_
     SlabPtrs S{};
     build_dw_jobs(w, slabs + (int64_t)G * gstride, J, S);
     static const bool use_regs = getenv("DH_DW_REGS") != nullptr;     // A/B switch: register-streamed variant
-    static const bool use_f32 = getenv("DH_DW_F32") != nullptr;       // A/B switch: native fp32-MFMA LDS-DMA variant
+    static const bool use_f32 = (getenv("DH_DW_F32") != nullptr || getenv("DH_ALL_F32") != nullptr);       // A/B switch: native fp32-MFMA LDS-DMA variant
     if (use_regs) hipLaunchKernelGGL(dw_kernel, dim3(G), dim3(512), 0, st, J, w.ntiles, slabs, gstride, (int64_t)-1);
     else if (use_f32) hipLaunchKernelGGL(dw_lds_kernel, dim3(G), dim3(512), 0, st, J, w.ntiles, slabs, gstride);
     else hipLaunchKernelGGL(dw_bf16x3_kernel, dim3(G), dim3(512), 0, st, J, w.ntiles, slabs, gstride);

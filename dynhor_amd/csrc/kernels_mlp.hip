@@ -456,7 +456,7 @@ int launch_sdf_fwd_train(const float* packed, const float* pts, int64_t npts, fl
                          float* eaux, int grid, hipStream_t stream) {
     const int64_t ntiles = (npts + TM - 1) / TM;
     const int g = (int)(ntiles < grid ? ntiles : grid);
-    static const bool f32 = getenv("DH_FWD_F32") != nullptr;           // A/B switch: native fp32-MFMA chain
+    static const bool f32 = (getenv("DH_FWD_F32") != nullptr || getenv("DH_ALL_F32") != nullptr);           // A/B switch: native fp32-MFMA chain
     if (f32) hipLaunchKernelGGL(sdf_fwd_train_kernel, dim3(g), dim3(256), 0, stream, make_sdf_ptrs(packed), pts, npts, sdf, feat, act, eaux);
     else hipLaunchKernelGGL(sdf_fwd_train16_kernel, dim3(g < 256 ? g : 256), dim3(256), 0, stream, make_sdf16_ptrs(packed), pts, npts, sdf, feat, act, eaux);
     return hipGetLastError() == hipSuccess ? 0 : -3;
@@ -465,7 +465,7 @@ int launch_sdf_grad(const float* packed, const float* pts, int64_t npts, const f
                     int save, int grid, hipStream_t stream) {
     const int64_t ntiles = (npts + TM - 1) / TM;
     const int g = (int)(ntiles < grid ? ntiles : grid);
-    static const bool f32 = getenv("DH_GRAD_F32") != nullptr;          // A/B switch: native fp32-MFMA chain
+    static const bool f32 = (getenv("DH_GRAD_F32") != nullptr || getenv("DH_ALL_F32") != nullptr);          // A/B switch: native fp32-MFMA chain
     if (f32) hipLaunchKernelGGL(sdf_grad_kernel, dim3(g), dim3(256), 0, stream, make_sdf_ptrs(packed), pts, npts, act, asave, normals, save);
     else hipLaunchKernelGGL(sdf_grad16_kernel, dim3(g < 256 ? g : 256), dim3(256), 0, stream, make_sdf16_ptrs(packed), pts, npts, act, asave, normals, save);
     return hipGetLastError() == hipSuccess ? 0 : -3;
@@ -475,7 +475,7 @@ int launch_color_fwd(const float* packed, const float* pts, const float* dirs, i
                      hipStream_t stream) {
     const int64_t ntiles = (npts + TM - 1) / TM;
     const int g = (int)(ntiles < grid ? ntiles : grid);
-    static const bool f32 = getenv("DH_COLFWD_F32") != nullptr;        // A/B switch: native fp32-MFMA chain
+    static const bool f32 = (getenv("DH_COLFWD_F32") != nullptr || getenv("DH_ALL_F32") != nullptr);        // A/B switch: native fp32-MFMA chain
     if (f32) hipLaunchKernelGGL(color_fwd_kernel, dim3(g), dim3(256), 0, stream, make_col_ptrs(packed), pts, dirs, n_per_ray, normals,
                                 feat, npts, color, cact, caux, save);
     else hipLaunchKernelGGL(color_fwd16_kernel, dim3(g < 256 ? g : 256), dim3(256), 0, stream, make_col16_ptrs(packed), pts, dirs,
@@ -487,7 +487,7 @@ int launch_sdf_nograd(const float* packed, const float* pts, int64_t npts, float
     if (npts <= 0) return 0;
     const int64_t ntiles = (npts + TM - 1) / TM;
     const int g = (int)(ntiles < grid ? ntiles : grid);
-    static const bool f32 = getenv("DH_NOGRAD_F32") != nullptr;        // A/B switch: native fp32-MFMA chain
+    static const bool f32 = (getenv("DH_NOGRAD_F32") != nullptr || getenv("DH_ALL_F32") != nullptr);        // A/B switch: native fp32-MFMA chain
     if (f32) hipLaunchKernelGGL(sdf_nograd_kernel, dim3(g), dim3(256), 0, stream, make_sdf_ptrs(packed), pts, npts, sdf);
     else {
         static const bool w4 = getenv("DH_NOGRAD_W4") != nullptr;     // A/B switch: 4-wave form of the split-bf16 kernel

@@ -514,7 +514,7 @@ __global__ __launch_bounds__(256, 1) void sdf_bwd16_kernel(Sdf16Ptrs P, const fl
 
 static inline int ok() { return hipGetLastError() == hipSuccess ? 0 : -3; }
 // A/B switch: DH_BWD_F32 selects the native fp32-MFMA backward chains
-static inline bool chains_f32() { static const bool v = getenv("DH_BWD_F32") != nullptr; return v; }
+static inline bool chains_f32() { static const bool v = (getenv("DH_BWD_F32") != nullptr || getenv("DH_ALL_F32") != nullptr); return v; }
 static inline int grid_for(int64_t npts, int grid) {
     const int64_t ntiles = (npts + TM - 1) / TM;
     return (int)(ntiles < grid ? ntiles : grid);
