@@ -20,7 +20,8 @@ static_assert(TM == 64 || TM == 128, "tile height");
 constexpr int HID = 256;       // hidden width == main-tile width
 constexpr int AUXW = 40;       // aux tile logical width (39 embedding / 33 colour extras, zero padded)
 constexpr int LDX = 260;       // LDS row stride (floats) of the main tile: 260 % 64 == 4 -> b128 reads conflict free
-constexpr int LDA = 44;        // LDS row stride of the aux tile
+constexpr int LDA = 52;        // LDS row stride of the aux tile: 48 columns readable as three 16-deep k-chunks (39 / 33 valid,
+                               // the rest zero) + 4 pad; 52 % 64 keeps 16 consecutive rows on distinct banks for b128 reads
 constexpr int TILE_F = TM * HID;       // floats per native main tile (32768)
 constexpr int AUXT_F = TM * 64;        // floats per native aux tile (8192)
 

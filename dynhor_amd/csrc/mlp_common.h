@@ -17,7 +17,7 @@ __device__ __forceinline__ void embed_tile(const float* __restrict__ pts, int64_
     if (gp < npts) { x[0] = pts[gp * 3 + 0]; x[1] = pts[gp * 3 + 1]; x[2] = pts[gp * 3 + 2]; }
     float* row = aux + p * LDA;
     if (part == 0) { row[0] = x[0]; row[1] = x[1]; row[2] = x[2]; }
-    if (part == 1) { row[39] = 0.f; row[40] = 0.f; row[41] = 0.f; row[42] = 0.f; row[43] = 0.f; }
+    if (part == 1) { for (int c = 39; c < LDA; ++c) row[c] = 0.f; }
     for (int k = part; k < 6; k += TPP) {
         const float f = (float)(1 << k);
         DH_UNROLL for (int c = 0; c < 3; ++c) {

@@ -201,6 +201,71 @@ __device__ __forceinline__ void tile_prefetch(TileRegs& t, const float* __restri
             DH_UNROLL for (int r4 = 0; r4 < 4; ++r4) t.v[m][tt][r4] = p[((m * 2 + tt) * 4 + r4) * 64];
 }
 
+// ---------------------------------------------------------------- split-on-fetch form (the shipping chain kernels)
+// The LDS activation image stays the fp32 image of tile.h (78 KB with the aux image -> TWO workgroups per CU, whose
+// epilogues and barriers overlap each other's MFMAs); each wave splits its A fragments into bf16 pieces as it fetches
+// them (two ds_read_b128 -> 8 fp32 -> three bf16x8).  The split is redone by each of the four waves, but it sits in the
+// vector-issue shadow of the matrix pipe (an MFMA holds issue for 8 of its 32 cycles): scripts/micro/
+// bf16x3_fp32lds_micro.hip measures 233-247 TFLOP/s fp32-equivalent for this chain WITH softplus and write-back,
+// against 218 for the piece-plane image at one workgroup per CU.  No sched_barrier between the fetch/split block and the
+// MFMA block: interleaving them is exactly what is wanted (micro: 247 vs 233 pinned).
+__device__ __forceinline__ void gemm_rows_s(f32x16 (&acc)[MT][2], const float* xs, const int ldx, const int nkc,
+                                            const bf16x8* __restrict__ wp, const int wave, const int lane) {
+    const float* xrow = xs + (lane & 31) * ldx + 8 * (lane >> 5);
+    const bf16x8* wl = wp + (2 * wave) * 3 * 64 + lane;
+    Bf3 a0[MT], b0[2], a1[MT], b1[2];
+    const int last = nkc - 1;
+    auto fetch = [&](Bf3 (&a)[MT], Bf3 (&b)[2], int kc) {
+        kc = kc < last ? kc : last;
+        DH_UNROLL for (int t = 0; t < 2; ++t)
+            DH_UNROLL for (int p = 0; p < 3; ++p) b[t].p[p] = wl[((kc * 8 + t) * 3 + p) * 64];
+        DH_UNROLL for (int m = 0; m < MT; ++m) {
+            const f32x4 lo = *reinterpret_cast<const f32x4*>(xrow + m * 32 * ldx + kc * 16);
+            const f32x4 hi = *reinterpret_cast<const f32x4*>(xrow + m * 32 * ldx + kc * 16 + 4);
+            a[m] = split3(lo, hi);
+        }
+    };
+    auto mul = [&](const Bf3 (&a)[MT], const Bf3 (&b)[2]) {
+        DH_UNROLL for (int m = 0; m < MT; ++m)
+            DH_UNROLL for (int t = 0; t < 2; ++t) acc[m][t] = mfma6(a[m], b[t], acc[m][t]);
+    };
+    fetch(a0, b0, 0);
+    _Pragma("unroll 1") for (int kc = 0; kc < nkc; kc += 2) {
+        fetch(a1, b1, kc + 1);
+        mul(a0, b0);
+        if (kc + 1 < nkc) {
+            fetch(a0, b0, kc + 2);
+            mul(a1, b1);
+        }
+    }
+}
+
+// 64-wide "aux" output from the fp32 main image (tile.h gemm_auxout), split-on-fetch
+__device__ __forceinline__ void gemm_auxout_s(f32x16 (&acc2)[AUX_NTW], const float* xs, const int nkc,
+                                              const bf16x8* __restrict__ wp, const int wave, const int lane) {
+    const float* xrow = xs + (32 * aux_mtile(wave) + (lane & 31)) * LDX + 8 * (lane >> 5);
+    const bf16x8* wl = wp + aux_ntile(wave, 0) * 3 * 64 + lane;
+    const int last = nkc - 1;
+    auto fetch = [&](Bf3& a, Bf3 (&b)[AUX_NTW], int kc) {
+        kc = kc < last ? kc : last;
+        DH_UNROLL for (int t = 0; t < AUX_NTW; ++t)
+            DH_UNROLL for (int p = 0; p < 3; ++p) b[t].p[p] = wl[((kc * 2 + t) * 3 + p) * 64];
+        const f32x4 lo = *reinterpret_cast<const f32x4*>(xrow + kc * 16);
+        const f32x4 hi = *reinterpret_cast<const f32x4*>(xrow + kc * 16 + 4);
+        a = split3(lo, hi);
+    };
+    Bf3 a0, a1, b0[AUX_NTW], b1[AUX_NTW];
+    fetch(a0, b0, 0);
+    _Pragma("unroll 1") for (int kc = 0; kc < nkc; kc += 2) {
+        fetch(a1, b1, kc + 1);
+        DH_UNROLL for (int t = 0; t < AUX_NTW; ++t) acc2[t] = mfma6(a0, b0[t], acc2[t]);
+        if (kc + 1 < nkc) {
+            fetch(a0, b0, kc + 2);
+            DH_UNROLL for (int t = 0; t < AUX_NTW; ++t) acc2[t] = mfma6(a1, b1[t], acc2[t]);
+        }
+    }
+}
+
 // ---------------------------------------------------------------- 8-wave variant (512 threads, two waves per SIMD)
 // Same tile, same LDS image; wave w8 = 0..7 owns the single 32-column tile ct = w8 (native index: wave = ct >> 1,
 // t = ct & 1), so acc is [MT][1] and the B operand per wave halves while every wave still reads the whole A image.
