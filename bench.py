@@ -163,15 +163,14 @@ def main():
                          "color_backward": "color_bwd_kernel", "sdf_tangent": "sdf_tangent_kernel",
                          "sdf_backward": "sdf_bwd_kernel", "sdf_nograd_coarse": "sdf_nograd_kernel"}
         else:
-            hip_names = {"weight_grads_gemm": "dw_lds_kernel" if dw_f32 else "dw_bf16x3_kernel", "sdf_forward": "sdf_fwd_train16_kernel",
-                         "sdf_gradient": "sdf_grad16_kernel", "color_forward": "color_fwd16_kernel",
-                         "color_backward": "color_bwd16_kernel", "sdf_tangent": "sdf_tangent_kernel",
-                         "sdf_backward": "sdf_bwd16_kernel", "sdf_nograd_coarse": "sdf_nograd16w8_kernel"}
-        # peak of the dominant kernel's own instruction mix: every GEMM except the tangent chain runs each fp32 product as 6
-        # bf16 products (3-way split of both operands, fp32 accumulate: 2^-24 relative) on v_mfma_f32_32x32x16_bf16, so the
-        # ceiling in ALGORITHMIC (fp32-product) FLOP/s is the dense bf16 peak / 6; the tangent chain runs
-        # v_mfma_f32_32x32x2_f32 (157.3 TFLOP/s)
-        split = not (all_f32 or dom == "sdf_tangent" or (dom == "weight_grads_gemm" and dw_f32))
+            hip_names = {"weight_grads_gemm": "dw_lds_kernel" if dw_f32 else "dw_bf16x3_kernel", "sdf_forward": "sdf_fwd_train_s_kernel",
+                         "sdf_gradient": "sdf_grad16_kernel", "color_forward": "color_fwd_s_kernel",
+                         "color_backward": "color_bwd16_kernel", "sdf_tangent": "sdf_tangent_s_kernel",
+                         "sdf_backward": "sdf_bwd_s_kernel", "sdf_nograd_coarse": "sdf_nograd_s_kernel"}
+        # peak of the dominant kernel's own instruction mix: every GEMM runs each fp32 product as 6 bf16 products (3-way
+        # split of both operands, fp32 accumulate: 2^-24 relative) on v_mfma_f32_32x32x16_bf16, so the ceiling in ALGORITHMIC
+        # (fp32-product) FLOP/s is the dense bf16 peak / 6; DH_ALL_F32 runs v_mfma_f32_32x32x2_f32 (157.3 TFLOP/s)
+        split = not (all_f32 or (dom == "weight_grads_gemm" and dw_f32))
         peak = BF16_MFMA_PEAK_TFLOPS / 6.0 if split else FP32_MFMA_PEAK_TFLOPS
         roof = {"bound": "mfma", "kernel": hip_names.get(dom, dom), "stage": dom, "achieved": per_kernel[dom]["tflops"],
                 "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(per_kernel[dom]["tflops"] / peak, 4),
@@ -191,7 +190,7 @@ def main():
                           "parallelism": f"dp{world}", "loss": "rgb L1 + 0.1 eikonal + 0.1 mask BCE + 0.05 mono-normal",
                           "arithmetic": ("fp32 everywhere, every GEMM on v_mfma_f32_32x32x2_f32 (DH_ALL_F32)" if all_f32 else
                                          "fp32 in / fp32 out everywhere; GEMMs as 3-way bf16 split of both operands (6 MFMA "
-                                         "products, fp32 accumulate: 2^-24 relative = fp32 accuracy); tangent chain on fp32 MFMA")},
+                                         "products, fp32 accumulate: 2^-24 relative = fp32 accuracy)")},
                "roofline": roof, "kernels": per_kernel,
                "final_stats": {"loss": round(float(stats[0]), 5), "psnr": round(float(stats[5]), 3)}}
         if world == 1 and not args.no_cpu_baseline:

@@ -12,7 +12,9 @@ stage_of = {"dw_lds_kernel": "weight_grads_gemm", "dw_bf16x3_kernel": "weight_gr
             "color_fwd_kernel": "color_forward", "color_fwd16_kernel": "color_forward",
             "color_bwd_kernel": "color_backward", "color_bwd16_kernel": "color_backward",
             "sdf_tangent_kernel": "sdf_tangent", "sdf_tangent16_kernel": "sdf_tangent",
-            "sdf_bwd_kernel": "sdf_backward", "sdf_bwd16_kernel": "sdf_backward"}
+            "sdf_bwd_kernel": "sdf_backward", "sdf_bwd16_kernel": "sdf_backward",
+            "sdf_fwd_train_s_kernel": "sdf_forward", "sdf_grad_s_kernel": "sdf_gradient", "color_fwd_s_kernel": "color_forward",
+            "color_bwd_s_kernel": "color_backward", "sdf_tangent_s_kernel": "sdf_tangent", "sdf_bwd_s_kernel": "sdf_backward"}
 out = {}
 for kern, stage in stage_of.items():
     if kern not in p["prof_pmc2"] or kern not in p["prof_pmc3"]:
