@@ -11,6 +11,10 @@
  *   - the caller allocates everything (torch tensors); the library never allocates, frees or retains pointers.
  *   - `stream` is a hipStream_t passed as void*; kernels are enqueued on it, no implicit synchronisation.
  *   - return 0 on success or a negative dh_status; never throws, never exits.  Re-entrant, no global state.
+ *   - arithmetic: every buffer that crosses this boundary is fp32.  Inside, the GEMMs form each fp32 product from bf16
+ *     pieces on the bf16 matrix cores (3-way split of both operands, six MFMA products, fp32 accumulation: 2^-24
+ *     relative, i.e. fp32 accuracy -- DESIGN.md section 3).  The environment variable DH_ALL_F32=1 (read once per
+ *     process) selects the native fp32-MFMA twin of every kernel; per-kernel A/B switches are listed in DESIGN.md.
  */
 #ifndef DYNHOR_HIP_H
 #define DYNHOR_HIP_H
