@@ -1,6 +1,8 @@
 #include <cstdlib>
-// Tile-resident MLP chain kernels (SDF no-grad / train forward / input-gradient / colour forward and the
-// backward chains).  See tile.h for the tile GEMM primitives and layouts, DESIGN.md for the math.
+// Tile-resident MLP chain kernels (SDF no-grad / train forward / input-gradient / colour forward).  Each chain exists in three
+// forms: `<name>_s_kernel` (split-bf16 MFMA, A split on fetch from the fp32 LDS image -- tile16.h), `<name>16_kernel`
+// (split-bf16 MFMA on bf16 piece planes in LDS) and `<name>_kernel` (native fp32 MFMA -- tile.h).  The launchers at the end of the
+// file pick the measured-fastest form per kernel; environment switches select the others.
 #include "tile.h"
 #include "kernels.h"
 #include "mlp_common.h"

@@ -5,8 +5,12 @@
 // k-step instead of 8 x 64 for v_mfma_f32_32x32x2_f32.  The accumulator layout of the two instructions is the same
 // 32 x 32 fp32 tile, so epilogues, native saved tiles and the dW kernels are unchanged.
 //
-// LDS activation image: three piece planes [TM x 256] bf16, row stride LDB = 264 (528 B: 16 lanes x 16 B cover all 64
-// banks), plus aux planes [TM x 48] (stride 56).  The split happens ONCE, in the epilogue that writes the image.
+// Two ways of feeding the A operand (both in this file; the faster one per kernel ships):
+//   * split-on-fetch (gemm_rows_s / gemm_auxout_s): the LDS image stays tile.h's fp32 image (two workgroups per CU) and
+//     each wave splits its A fragments as it reads them;
+//   * piece planes (gemm16_rows / gemm16_auxout / acc_to_lds16 ...): three bf16 planes [TM x 256], row stride LDB = 264
+//     (528 B: 16 lanes x 16 B cover all 64 banks), plus aux planes [TM x 48] (stride 56); the split happens once, in the
+//     epilogue that writes the image (122 KB: one workgroup per CU).
 // Packed weights (pack.hip): bf16x8 index ((kc*NT + nt)*3 + piece)*64 + lane holds
 //   M[k = 16 kc + 8 (lane>>5) + s][n = 32 nt + (lane&31)], s = 0..7.
 #pragma once
