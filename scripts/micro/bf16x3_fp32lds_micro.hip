@@ -73,12 +73,30 @@ __global__ __launch_bounds__(256, 2) void k(const bf16x8* __restrict__ wp, float
 #pragma unroll 1
             for (int kc = 0; kc < 16; kc += 2) {
                 fetch(an, bn, kc + 1);
-                if (PIN) __builtin_amdgcn_sched_barrier(0);
+                if (PIN == 1) __builtin_amdgcn_sched_barrier(0);
                 mul(a, b);
+                if (PIN == 2) {
+                    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);      // DS reads of the next A fragments
+                    __builtin_amdgcn_sched_group_barrier(0x020, 6, 0);      // weight pieces
+#pragma unroll
+                    for (int q = 0; q < 24; ++q) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // one MFMA
+                        __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);  // four VALU of the split
+                    }
+                }
                 if (PIN) __builtin_amdgcn_sched_barrier(0);
                 fetch(a, b, kc + 2 < 16 ? kc + 2 : 15);
-                if (PIN) __builtin_amdgcn_sched_barrier(0);
+                if (PIN == 1) __builtin_amdgcn_sched_barrier(0);
                 mul(an, bn);
+                if (PIN == 2) {
+                    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x020, 6, 0);
+#pragma unroll
+                    for (int q = 0; q < 24; ++q) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+                    }
+                }
                 if (PIN) __builtin_amdgcn_sched_barrier(0);
             }
             if (MODE >= 1) {
@@ -129,5 +147,7 @@ int main() {
     run<0, 0>("GEMM loop only, compiler-interleaved", wp, out, grid);
     run<1, 1>("+ softplus + write-back, pinned", wp, out, grid);
     run<1, 0>("+ softplus + write-back, compiler-interleaved", wp, out, grid);
+    run<0, 2>("GEMM loop only, sched_group_barrier 1 MFMA : 4 VALU", wp, out, grid);
+    run<1, 2>("+ softplus + write-back, sched_group_barrier", wp, out, grid);
     return 0;
 }
