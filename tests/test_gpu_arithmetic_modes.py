@@ -33,7 +33,8 @@ torch.save({{"stats": stats.cpu(), "grad": r.store.grad_flat.cpu()}}, {out!r})
 def _run(tmp_path, name, env_extra):
     out = str(tmp_path / (name + ".pt"))
     env = dict(os.environ)
-    env.pop("DH_ALL_F32", None)
+    for k in ("DH_ALL_F32", "DH_CHAIN_PIECES"):
+        env.pop(k, None)
     env.update(env_extra)
     code = SCRIPT.format(root=ROOT, exp=str(tmp_path / name), out=out)
     p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=280)
@@ -44,8 +45,10 @@ def _run(tmp_path, name, env_extra):
 def test_split_bf16_and_fp32_mfma_kernels_agree(tmp_path):
     a = _run(tmp_path, "split", {})
     b = _run(tmp_path, "f32", {"DH_ALL_F32": "1"})
-    ds = (a["stats"][:6] - b["stats"][:6]).abs().max().item()
-    rel = ((a["grad"].double() - b["grad"].double()).norm() / b["grad"].double().norm()).item()
-    print(f"loss/stat max abs diff {ds:.2e}; flat gradient rel diff split-bf16 vs fp32-MFMA {rel:.2e}")
-    assert ds < 5e-6
-    assert rel < 1e-5
+    c = _run(tmp_path, "pieces", {"DH_CHAIN_PIECES": "1"})       # every chain in its piece-plane form
+    for name, other in (("fp32-MFMA", b), ("piece-plane", c)):
+        ds = (a["stats"][:6] - other["stats"][:6]).abs().max().item()
+        rel = ((a["grad"].double() - other["grad"].double()).norm() / other["grad"].double().norm()).item()
+        print(f"shipping kernels vs {name}: loss/stat max abs diff {ds:.2e}; flat gradient rel diff {rel:.2e}")
+        assert ds < 5e-6
+        assert rel < 1e-5
