@@ -14,6 +14,9 @@ _vp, _i64, _i32, _f32 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_
 SIGNATURES = {
     "dh_version": (_i32, []),
     "dh_strerror": (ctypes.c_char_p, [_i32]),
+    "dh_set_arithmetic": (_i32, [_i32]),
+    "dh_get_arithmetic": (_i32, []),
+    "dh_hash_set_scatter_mode": (_i32, [_i32]),
     "dh_num_params": (_i64, []),
     "dh_packed_floats": (_i64, []),
     "dh_param_layout": (_i32, [_i32, _i32, ctypes.POINTER(_i64), ctypes.POINTER(_i64), ctypes.POINTER(_i64),
@@ -78,6 +81,18 @@ def lib():
             fn.argtypes = args
         _LIB = L
     return _LIB
+
+
+ARITH_SPLIT_BF16, ARITH_FP32_MFMA = 0, 1
+
+
+def set_arithmetic(mode: int):
+    """dh_set_arithmetic: 0 = split-bf16 kernels (shipping), 1 = native fp32-MFMA twins.  Process-wide."""
+    check(lib().dh_set_arithmetic(int(mode)))
+
+
+def get_arithmetic() -> int:
+    return int(lib().dh_get_arithmetic())
 
 
 def check(status: int):

@@ -7,14 +7,35 @@
 
 using namespace dh;
 
+namespace dh {
+// the library's only process-global state (include/dynhor_hip.h "Conventions")
+static int g_arith = DH_ARITH_SPLIT_BF16;
+static int g_hash_scatter = 0;
+bool arith_fp32() { return __atomic_load_n(&g_arith, __ATOMIC_RELAXED) == DH_ARITH_FP32_MFMA; }
+int hash_scatter_mode() { return __atomic_load_n(&g_hash_scatter, __ATOMIC_RELAXED); }
+}  // namespace dh
+
 namespace {
 inline bool misaligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) != 0; }
-constexpr int DEFAULT_GRID = 256 * (TM == 128 ? 1 : 2);   // persistent workgroups: all that are co-resident
+constexpr int DEFAULT_GRID = 256 * 2;   // persistent workgroups: all that are co-resident (two 64-point tiles per CU)
 }  // namespace
 
 extern "C" {
 
-int dh_version(void) { return 1; }
+int dh_version(void) { return 2; }
+
+int dh_set_arithmetic(int mode) {
+    if (mode != DH_ARITH_SPLIT_BF16 && mode != DH_ARITH_FP32_MFMA) return DH_ERR_BAD_ARG;
+    __atomic_store_n(&dh::g_arith, mode, __ATOMIC_RELAXED);
+    return DH_OK;
+}
+int dh_get_arithmetic(void) { return __atomic_load_n(&dh::g_arith, __ATOMIC_RELAXED); }
+
+int dh_hash_set_scatter_mode(int mode) {
+    if (mode < 0 || mode > 2) return DH_ERR_BAD_ARG;
+    __atomic_store_n(&dh::g_hash_scatter, mode, __ATOMIC_RELAXED);
+    return DH_OK;
+}
 
 const char* dh_strerror(int status) {
     switch (status) {

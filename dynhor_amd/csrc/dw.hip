@@ -2,11 +2,10 @@
 //
 // Wbar[256 x NB*32] = sum over points of A[p,:]^T B[p,:]  with the POINT axis as the MFMA k dimension.  Both operands
 // are saved "native" tiles (tile.h): a float4 at ((..m..t..)*4 + r4)*64 + lane IS four consecutive A (or B)
-// fragments of v_mfma_f32_32x32x2_f32 for the k-pairs {row, row+4}, so operands stream HBM -> VGPR with 1 KiB
-// coalesced loads and no LDS.  8 waves per workgroup, wave w owns output rows [32w, 32w+32) x all NB n-tiles
-// (128 accumulator VGPRs at NB=8); split-K over tiles across gridDim.x workgroups, slabs reduced in fold_kernel
+// fragments of v_mfma_f32_32x32x2_f32 for the k-pairs {row, row+4} (and two consecutive ones the 8 k-values of one
+// v_mfma_f32_32x32x16_bf16 operand), so operands leave HBM as 1 KiB coalesced wave loads.  8 waves per workgroup,
+// split-K over tiles across gridDim.x persistent workgroups, slabs reduced in slab_reduce_kernel / fold_kernel
 // (deterministic: no float atomics).
-#include <cstdlib>
 #include "tile16.h"
 #include "kernels.h"
 #include "workspace.h"
@@ -31,19 +30,6 @@ template <int NB>
 struct DwOperands { f32x4 a[DwShape<NB>::NA]; f32x4 b[DwShape<NB>::NBW]; };
 
 template <int NB>
-__device__ __forceinline__ void dw_load(DwOperands<NB>& o, const f32x4* ap, const f32x4* bp, int kq, int wave) {
-    const int m = kq >> 2, r4 = kq & 3;
-    DH_UNROLL for (int i = 0; i < DwShape<NB>::NA; ++i) {
-        const int ot = (NB == 8) ? ((wave >> 1) * 2 + i) : wave;                       // output 32-row tile 0..7
-        o.a[i] = ap[(((ot >> 1) * MT + m) * 2 + (ot & 1)) * 4 * 64 + r4 * 64];
-    }
-    DH_UNROLL for (int j = 0; j < DwShape<NB>::NBW; ++j) {
-        const int nt = (NB == 8) ? ((wave & 1) * 4 + j) : j;                           // B n-tile
-        const int bi = (NB == 8) ? ((((nt >> 1) * MT + m) * 2 + (nt & 1)) * 4 + r4) : ((m * 2 + nt) * 4 + r4);
-        o.b[j] = bp[bi * 64];
-    }
-}
-template <int NB>
 __device__ __forceinline__ void dw_mfma(f32x16 (&acc)[DwShape<NB>::NA][DwShape<NB>::NBW], const DwOperands<NB>& o) {
     DH_UNROLL for (int rr = 0; rr < 4; ++rr)
         DH_UNROLL for (int i = 0; i < DwShape<NB>::NA; ++i)
@@ -51,69 +37,12 @@ __device__ __forceinline__ void dw_mfma(f32x16 (&acc)[DwShape<NB>::NA][DwShape<N
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(o.a[i][rr], o.b[j][rr], acc[i][j], 0, 0, 0);
 }
 
-template <int NB>
-__device__ __forceinline__ void dw_body(const DwJob& J, int64_t t0, int64_t t1, float* __restrict__ out, int wave, int lane,
-                                        int64_t tile_mask) {
-    constexpr int KQ = MT * 4;                 // k-quads (8 points each) per tile
-    constexpr int BT = (NB == 8) ? TILE_F : AUXT_F;
-    constexpr int NA = DwShape<NB>::NA, NBW = DwShape<NB>::NBW;
-    f32x16 acc[NA][NBW];
-    DH_UNROLL for (int i = 0; i < NA; ++i) DH_UNROLL for (int j = 0; j < NBW; ++j) DH_UNROLL for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    for (int pair = 0; pair < 2; ++pair) {
-        const float* A = pair ? J.A2 : J.A1;
-        const float* Bm = pair ? J.B2 : J.B1;
-        if (!A || t0 >= t1) continue;
-        DwOperands<NB> s0, s1;
-        dw_load<NB>(s0, reinterpret_cast<const f32x4*>(A + (t0 & tile_mask) * TILE_F) + lane,
-                    reinterpret_cast<const f32x4*>(Bm + (t0 & tile_mask) * BT) + lane, 0, wave);
-        for (int64_t tile = t0; tile < t1; ++tile) {
-            const f32x4* ap = reinterpret_cast<const f32x4*>(A + (tile & tile_mask) * TILE_F) + lane;
-            const f32x4* bp = reinterpret_cast<const f32x4*>(Bm + (tile & tile_mask) * BT) + lane;
-            const int64_t tn = ((tile + 1 < t1) ? tile + 1 : tile) & tile_mask;
-            const f32x4* apn = reinterpret_cast<const f32x4*>(A + tn * TILE_F) + lane;
-            const f32x4* bpn = reinterpret_cast<const f32x4*>(Bm + tn * BT) + lane;
-            // operands of k-quad q+1 are issued before the MFMAs of k-quad q (order pinned: see gemm_rows)
-            DH_UNROLL for (int kq = 0; kq < KQ; kq += 2) {
-                dw_load<NB>(s1, ap, bp, kq + 1, wave);
-                __builtin_amdgcn_sched_barrier(0);
-                dw_mfma<NB>(acc, s0);
-                __builtin_amdgcn_sched_barrier(0);
-                if (kq + 2 < KQ) dw_load<NB>(s0, ap, bp, kq + 2, wave);
-                else dw_load<NB>(s0, apn, bpn, 0, wave);
-                __builtin_amdgcn_sched_barrier(0);
-                dw_mfma<NB>(acc, s1);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-    }
-    // slab layout == accumulator layout: [ot 0..7][nt 0..nb)[16][64]
-    DH_UNROLL for (int i = 0; i < NA; ++i)
-        DH_UNROLL for (int j = 0; j < NBW; ++j) {
-            const int ot = (NB == 8) ? ((wave >> 1) * 2 + i) : wave;
-            const int nt = (NB == 8) ? ((wave & 1) * 4 + j) : j;
-            float* o = out + ((int64_t)ot * NB + nt) * 1024 + lane;
-            DH_UNROLL for (int r = 0; r < 16; ++r) o[r * 64] = acc[i][j][r];
-        }
-}
-
+// ---------------------------------------------------------------- native-fp32-MFMA variant (dh_set_arithmetic(DH_ARITH_FP32_MFMA))
 // One persistent workgroup per CU: split g owns tiles [nt*g/G, nt*(g+1)/G) and runs EVERY job over them, so all
 // workgroups do identical work (no tail) and write one slab block each.
-__global__ __launch_bounds__(512, 2) void dw_kernel(DwJobs jobs, int64_t ntiles, float* __restrict__ slabs, int64_t gstride,
-                                                    int64_t tile_mask) {
-    const int G = gridDim.x, g = blockIdx.x;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int64_t t0 = ntiles * g / G, t1 = ntiles * (g + 1) / G;
-    float* base = slabs + (int64_t)g * gstride;
-    for (int job = 0; job < jobs.n; ++job) {
-        const DwJob J = jobs.j[job];
-        if (J.nb == 8) dw_body<8>(J, t0, t1, base + J.off, wave, lane, tile_mask);
-        else dw_body<2>(J, t0, t1, base + J.off, wave, lane, tile_mask);
-    }
-}
-
-// ---------------------------------------------------------------- LDS-DMA staged variant (default)
-// The register-streamed kernel above fetches every operand byte 2x (A) / 4x (B) per workgroup and is limited by the
-// CU's L1-miss throughput (scripts/micro/dw_micro2.hip: 63 % streamed vs 84 % cache-resident).  Here each k-quad's
+// A register-streamed kernel would fetch every operand byte 2x (A) / 4x (B) per workgroup and is limited by the
+// CU's L1-miss throughput (scripts/micro/dw_micro2.hip: 63 % streamed vs 84 % cache-resident; measured 7.3 vs 5.5 ms,
+// removed in round 2).  Here each k-quad's
 // 16 KiB (8 A pieces + 8 B pieces of 1 KiB = one wave-wide 16-B LDS-DMA each: the native tile layout is lane-linear,
 // exactly what global_load_lds needs) enters the CU once into a DW_STAGES-deep LDS ring; the 8 waves then read their
 // 2 A + 4 B fragments with conflict-free ds_read_b128.  Every wave issues exactly 2 DMAs per k-quad, so one counted
@@ -234,7 +163,7 @@ __device__ __forceinline__ void dw_body_lds(const DwJob& J, int64_t t0, int64_t 
         }
 }
 
-// ---------------------------------------------------------------- split-bf16 variant (default)
+// ---------------------------------------------------------------- split-bf16 variant (shipping)
 // Same native-tile operands and slab layout as the kernels above; only the multiply changes.  Each operand value is split
 // into three bf16 pieces x = x1 + x2 + x3 (24 mantissa bits, exact residuals) and the six products a1b1, a1b2, a2b1, a1b3,
 // a2b2, a3b1 are accumulated in fp32 by v_mfma_f32_32x32x16_bf16: the sum reproduces the fp32 product to 2^-24 (the
@@ -538,10 +467,7 @@ int launch_weight_grads_gemm(const Workspace& w, float* slabs, int G, hipStream_
     DwJobs J{};
     SlabPtrs S{};
     build_dw_jobs(w, slabs + (int64_t)G * gstride, J, S);
-    static const bool use_regs = getenv("DH_DW_REGS") != nullptr;     // A/B switch: register-streamed variant
-    static const bool use_f32 = (getenv("DH_DW_F32") != nullptr || getenv("DH_ALL_F32") != nullptr);       // A/B switch: native fp32-MFMA LDS-DMA variant
-    if (use_regs) hipLaunchKernelGGL(dw_kernel, dim3(G), dim3(512), 0, st, J, w.ntiles, slabs, gstride, (int64_t)-1);
-    else if (use_f32) hipLaunchKernelGGL(dw_lds_kernel, dim3(G), dim3(512), 0, st, J, w.ntiles, slabs, gstride);
+    if (arith_fp32()) hipLaunchKernelGGL(dw_lds_kernel, dim3(G), dim3(512), 0, st, J, w.ntiles, slabs, gstride);
     else hipLaunchKernelGGL(dw_bf16x3_kernel, dim3(G), dim3(512), 0, st, J, w.ntiles, slabs, gstride);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }

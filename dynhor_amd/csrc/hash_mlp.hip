@@ -3,7 +3,6 @@
 // small weights of both MLPs staged whole into LDS (41 KB) and read as wave-uniform broadcasts; the MLP arithmetic is
 // VALU (a 35x64 + 64x13 network is ~3 kFMA per evaluation -- nothing for MFMA to win against the 128 table gathers).
 // Algorithm: oracle/hashgrid_oracle.py (parity unpinned, see its header).
-#include <cstdlib>
 #include "tile.h"
 #include "kernels.h"
 #include "hash_layout.h"
@@ -487,7 +486,7 @@ __global__ __launch_bounds__(256) void hash_geo_bwd_kernel(const float* __restri
 //     = ray order; grid.y = level, so a wave is 16 consecutive samples at one level) and only the last quad of each run
 //     issues the centre's atomics.
 // Against the per-evaluation scatter (tcnn's scheme: E x 8 corners x 2 features atomics per point and level) this is
-// 24.9 ms -> see DESIGN.md for the measured ladder.  DH_HASH_SCATTER_MODE=1 / 2 switch (b) / (a) off for ablation.
+// 24.9 ms -> see DESIGN.md for the measured ladder.  dh_hash_set_scatter_mode(1 / 2) switches (b) / (a) off for ablation.
 template <int MODE>   // 0: both merges; 1: no lane-run merge; 2: no evaluation merge (ablation / debugging)
 __global__ __launch_bounds__(256) void hash_table_bwd_kernel(HashLevels H, const float* __restrict__ ws, HashWs O, int64_t n,
                                                              float* __restrict__ d_table) {
@@ -765,7 +764,7 @@ int launch_hash_weight_grads(const float* params, const float* hp, int64_t n, fl
     hipLaunchKernelGGL(hash_fold_kernel, dim3(64, HW_JOBS), dim3(64), 0, st, params, hp, dwsum, P, grad);
     // table: scatter the encoding adjoint of all E n evaluations
     if (hipMemsetAsync(grad + P.table, 0, (size_t)hashgrid_entries() * 2 * sizeof(float), st) != hipSuccess) return -3;
-    static const int mode = getenv("DH_HASH_SCATTER_MODE") ? atoi(getenv("DH_HASH_SCATTER_MODE")) : 0;
+    const int mode = hash_scatter_mode();      // dh_hash_set_scatter_mode: 0 shipping, 1 / 2 ablations (test / diagnosis only)
     const dim3 grid((unsigned)((4 * n + 255) / 256), HG_L);
     if (mode == 1) hipLaunchKernelGGL(hash_table_bwd_kernel<1>, grid, dim3(256), 0, st, hashgrid_levels(), ws, O, n, grad + P.table);
     else if (mode == 2) hipLaunchKernelGGL(hash_table_bwd_kernel<2>, grid, dim3(256), 0, st, hashgrid_levels(), ws, O, n, grad + P.table);

@@ -6,6 +6,11 @@
 
 namespace dh {
 
+// arithmetic mode of the MLP GEMMs (dh_set_arithmetic, include/dynhor_hip.h): false = split-bf16 (shipping), true = native
+// fp32 MFMA.  One process-global word, read at every launch.
+bool arith_fp32();
+int hash_scatter_mode();
+
 int launch_pack_weights(const float* params, float* packed, hipStream_t stream);
 
 // MLP chains (kernels_mlp.hip).  npts is padded by the caller to a multiple of 128 for saved buffers.

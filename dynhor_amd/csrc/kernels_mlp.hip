@@ -1,18 +1,13 @@
-#include <cstdlib>
-// Tile-resident MLP chain kernels (SDF no-grad / train forward / input-gradient / colour forward).  Each chain exists in three
-// forms: `<name>_s_kernel` (split-bf16 MFMA, A split on fetch from the fp32 LDS image -- tile16.h), `<name>16_kernel`
-// (split-bf16 MFMA on bf16 piece planes in LDS) and `<name>_kernel` (native fp32 MFMA -- tile.h).  The launchers at the end of the
-// file pick the measured-fastest form per kernel; environment switches select the others.
+// Tile-resident MLP chain kernels (SDF no-grad / train forward / input-gradient / colour forward).  Each chain exists in two
+// forms: the shipping split-bf16 kernel -- `<name>_s_kernel` (A split on fetch from the fp32 LDS image, tile16.h) or, where that
+// measured faster, `<name>16_kernel` (bf16 piece planes in LDS) -- and `<name>_kernel`, its native-fp32-MFMA twin (tile.h), the
+// second arithmetic the parity tests check the first against.  dh_set_arithmetic() (include/dynhor_hip.h) selects the set.
 #include "tile.h"
 #include "kernels.h"
 #include "mlp_common.h"
 #include "tile16.h"
 
 namespace dh {
-
-// A/B switch: DH_CHAIN_PIECES=1 selects the piece-plane (one workgroup per CU) form of the split-bf16 chains instead of the
-// shipping split-on-fetch form
-static inline bool chain_pieces() { static const bool v = getenv("DH_CHAIN_PIECES") != nullptr; return v; }
 
 // ------------------------------------------------------------------------------------------------
 // K1: SDF forward, no grad, sdf only (hierarchical up-sampling evaluations; SURVEY §8 a5 "no-grad").
@@ -44,101 +39,6 @@ __global__ __launch_bounds__(256, TM == 128 ? 1 : 2) void sdf_nograd_kernel(SdfP
         const int64_t gp = tile * TM + tid / TPP;
         if (tid % TPP == 0 && gp < npts) sdf_out[gp] = s;
         __syncthreads();                     // smain/saux are rewritten by the next tile
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// K1 on the bf16 matrix cores at fp32 accuracy (tile16.h): same chain as sdf_nograd_kernel, the activation image is
-// three bf16 piece planes (122 KB with the aux planes -> one workgroup per CU), every product is six bf16 MFMAs.
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 1) void sdf_nograd16_kernel(Sdf16Ptrs P, const float* __restrict__ pts, int64_t npts,
-                                                              float* __restrict__ sdf_out) {
-    __shared__ __attribute__((aligned(16))) __bf16 smain[3 * P_MAIN];
-    __shared__ __attribute__((aligned(16))) __bf16 saux[3 * P_AUX];
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int64_t ntiles = (npts + TM - 1) / TM;
-    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        embed_tile16(pts, tile * TM, npts, saux, tid);
-        __syncthreads();
-        f32x16 acc[MT][2];
-        for (int l = 0; l < 8; ++l) {
-            acc_zero(acc);
-            const float b0 = P.bias[l][acc_col(wave, 0, lane)], b1 = P.bias[l][acc_col(wave, 1, lane)];     // in flight under the GEMM
-            if (l > 0) gemm16_rows(acc, smain, P_MAIN, LDB, l == 4 ? 14 : 16, P.main16[l], wave, lane);
-            if (l == 0 || l == 4) gemm16_rows(acc, saux, P_AUX, LDA16, AUX_KC, P.aux16[l], wave, lane);
-            acc_map(acc, [&](int, int t, int, float v) { return softplus100(v + (t ? b1 : b0)); });
-            __syncthreads();                 // every wave finished reading smain as the A operand
-            acc_to_lds16(acc, smain, wave, lane);
-            __syncthreads();
-        }
-        const float s = row_dot256_16(smain, P.w8row0, tid) + P.b8_0[0];
-        const int64_t gp = tile * TM + tid / TPP;
-        if (tid % TPP == 0 && gp < npts) sdf_out[gp] = s;
-        __syncthreads();                     // smain/saux are rewritten by the next tile
-    }
-}
-
-// K1, 8-wave form (tile16.h "8-wave variant"): 512 threads, two waves per SIMD
-__global__ __launch_bounds__(512, 1) void sdf_nograd16w8_kernel(Sdf16Ptrs P, const float* __restrict__ pts, int64_t npts,
-                                                                float* __restrict__ sdf_out) {
-    __shared__ __attribute__((aligned(16))) __bf16 smain[3 * P_MAIN];
-    __shared__ __attribute__((aligned(16))) __bf16 saux[3 * P_AUX];
-    const int tid = threadIdx.x, w8 = tid >> 6, lane = tid & 63;
-    const int64_t ntiles = (npts + TM - 1) / TM;
-    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        embed_tile16_w8(pts, tile * TM, npts, saux, tid);
-        __syncthreads();
-        f32x16 acc[MT];
-        for (int l = 0; l < 8; ++l) {
-            DH_UNROLL for (int m = 0; m < MT; ++m) DH_UNROLL for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
-            const float b = P.bias[l][32 * w8 + (lane & 31)];                 // in flight under the GEMM
-            if (l > 0) gemm16_rows_w8(acc, smain, P_MAIN, LDB, l == 4 ? 14 : 16, P.main16[l], w8, lane);
-            if (l == 0 || l == 4) gemm16_rows_w8(acc, saux, P_AUX, LDA16, AUX_KC, P.aux16[l], w8, lane);
-            DH_UNROLL for (int m = 0; m < MT; ++m) DH_UNROLL for (int r = 0; r < 16; ++r) acc[m][r] = softplus100(acc[m][r] + b);
-            __syncthreads();                 // every wave finished reading smain as the A operand
-            acc_to_lds16_w8(acc, smain, w8, lane);
-            __syncthreads();
-        }
-        const float s = row_dot256_16_w8(smain, P.w8row0, tid) + P.b8_0[0];
-        const int64_t gp = tile * TM + (tid >> 3);
-        if ((tid & 7) == 0 && gp < npts) sdf_out[gp] = s;
-        __syncthreads();                     // smain/saux are rewritten by the next tile
-    }
-}
-
-// K2a on the split-bf16 core: same outputs and saved native tiles as sdf_fwd_train_kernel
-__global__ __launch_bounds__(256, 1) void sdf_fwd_train16_kernel(Sdf16Ptrs P, const float* __restrict__ pts, int64_t npts,
-                                                                 float* __restrict__ sdf_out, float* __restrict__ feat,
-                                                                 float* __restrict__ act, float* __restrict__ eaux) {
-    __shared__ __attribute__((aligned(16))) __bf16 smain[3 * P_MAIN];
-    __shared__ __attribute__((aligned(16))) __bf16 saux[3 * P_AUX];
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int64_t ntiles = (npts + TM - 1) / TM;
-    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        embed_tile16(pts, tile * TM, npts, saux, tid);
-        __syncthreads();
-        aux_lds16_to_native(saux, eaux + tile * AUXT_F, wave, lane);
-        f32x16 acc[MT][2];
-        for (int l = 0; l < 8; ++l) {
-            acc_zero(acc);
-            const float b0 = P.bias[l][acc_col(wave, 0, lane)], b1 = P.bias[l][acc_col(wave, 1, lane)];     // in flight under the GEMM
-            if (l > 0) gemm16_rows(acc, smain, P_MAIN, LDB, l == 4 ? 14 : 16, P.main16[l], wave, lane);
-            if (l == 0 || l == 4) gemm16_rows(acc, saux, P_AUX, LDA16, AUX_KC, P.aux16[l], wave, lane);
-            acc_map(acc, [&](int, int t, int, float v) { return softplus100(v + (t ? b1 : b0)); });
-            acc_store_native(acc, act + ((int64_t)l * ntiles + tile) * TILE_F, wave, lane);
-            __syncthreads();
-            acc_to_lds16(acc, smain, wave, lane);
-            __syncthreads();
-        }
-        const float s = row_dot256_16(smain, P.w8row0, tid) + P.b8_0[0];
-        const int64_t gp = tile * TM + tid / TPP;
-        if (tid % TPP == 0 && gp < npts) sdf_out[gp] = s;
-        acc_zero(acc);
-        gemm16_rows(acc, smain, P_MAIN, LDB, 16, P.main16[8], wave, lane);
-        const float b0 = P.bias[8][acc_col(wave, 0, lane)], b1 = P.bias[8][acc_col(wave, 1, lane)];
-        acc_map(acc, [&](int, int t, int, float v) { return v + (t ? b1 : b0); });
-        acc_store_native(acc, feat + tile * TILE_F, wave, lane);
-        __syncthreads();
     }
 }
 
@@ -401,63 +301,6 @@ __global__ __launch_bounds__(256, TM == 128 ? 1 : 2) void color_fwd_kernel(ColPt
     }
 }
 
-// K2c on the split-bf16 core
-__global__ __launch_bounds__(256, 1) void color_fwd16_kernel(Col16Ptrs C, const float* __restrict__ pts, const float* __restrict__ dirs,
-                                                            int n_per_ray, const float* __restrict__ normals,
-                                                            const float* __restrict__ feat, int64_t npts,
-                                                            float* __restrict__ color, float* __restrict__ cact,
-                                                            float* __restrict__ caux, int save) {
-    __shared__ __attribute__((aligned(16))) __bf16 smain[3 * P_MAIN];
-    __shared__ __attribute__((aligned(16))) __bf16 saux[3 * P_AUX];
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int64_t ntiles = (npts + TM - 1) / TM;
-    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        if (tid < TM) {
-            const int64_t gp = tile * TM + tid;
-            __bf16* row = saux + tid * LDA16;
-            if (gp < npts) {
-                const int64_t ray = gp / n_per_ray;
-                DH_UNROLL for (int c = 0; c < 3; ++c) {
-                    const float d = dirs[ray * 3 + c];
-                    aux_put16(row, c, pts[gp * 3 + c]);
-                    aux_put16(row, 3 + c, d);
-                    DH_UNROLL for (int k = 0; k < 4; ++k) {
-                        float s, co; sincosf(d * (float)(1 << k), &s, &co);
-                        aux_put16(row, 6 + 6 * k + c, s);
-                        aux_put16(row, 6 + 6 * k + 3 + c, co);
-                    }
-                    aux_put16(row, 30 + c, normals[gp * 3 + c]);
-                }
-            } else {
-                DH_UNROLL for (int c = 0; c < CAUX; ++c) aux_put16(row, c, 0.f);
-            }
-            DH_UNROLL for (int c = CAUX; c < 48; ++c) aux_put16(row, c, 0.f);
-        }
-        f32x16 acc[MT][2];
-        acc_load_native(acc, feat + tile * TILE_F, wave, lane);
-        acc_to_lds16(acc, smain, wave, lane);
-        __syncthreads();
-        if (save) aux_lds16_to_native(saux, caux + tile * AUXT_F, wave, lane);
-        for (int l = 0; l < 4; ++l) {
-            acc_zero(acc);
-            const float b0 = C.bias[l][acc_col(wave, 0, lane)], b1 = C.bias[l][acc_col(wave, 1, lane)];     // in flight under the GEMM
-            gemm16_rows(acc, smain, P_MAIN, LDB, 16, C.main16[l], wave, lane);
-            if (l == 0) gemm16_rows(acc, saux, P_AUX, LDA16, AUX_KC, C.aux16, wave, lane);
-            acc_map(acc, [&](int, int t, int, float v) { return fmaxf(v + (t ? b1 : b0), 0.f); });
-            if (save) acc_store_native(acc, cact + ((int64_t)l * ntiles + tile) * TILE_F, wave, lane);
-            __syncthreads();
-            acc_to_lds16(acc, smain, wave, lane);
-            __syncthreads();
-        }
-        const int64_t gp = tile * TM + tid / TPP;
-        DH_UNROLL for (int j = 0; j < 3; ++j) {
-            const float raw = row_dot256_16(smain, C.w4 + j * 256, tid) + C.b4[j];
-            if (tid % TPP == 0 && gp < npts) color[gp * 3 + j] = 1.f / (1.f + __expf(-raw));
-        }
-        __syncthreads();
-    }
-}
-
 // K1, split-on-fetch (tile16.h): the fp32 LDS image of sdf_nograd_kernel, GEMMs as six bf16 products
 __global__ __launch_bounds__(256, TM == 128 ? 1 : 2) void sdf_nograd_s_kernel(Sdf16Ptrs P, const float* __restrict__ pts, int64_t npts,
                                                              float* __restrict__ sdf_out) {
@@ -522,80 +365,6 @@ __global__ __launch_bounds__(256, TM == 128 ? 1 : 2) void sdf_fwd_train_s_kernel
     }
 }
 
-// K2b, split-on-fetch
-__global__ __launch_bounds__(256, TM == 128 ? 1 : 2) void sdf_grad_s_kernel(Sdf16Ptrs P, const float* __restrict__ pts, int64_t npts,
-                                                           const float* __restrict__ act, float* __restrict__ asave,
-                                                           float* __restrict__ normals, int save) {
-    __shared__ __attribute__((aligned(16))) float smain[TM * LDX];
-    __shared__ __attribute__((aligned(16))) float saux[TM * LDA];
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int64_t ntiles = (npts + TM - 1) / TM;
-    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        f32x16 acc[MT][2];
-        f32x16 ge[AUX_NTW];
-        aux_zero(ge);
-        // a_7 = W8[0,:] * sigma'(z_7)
-        {
-            const float w0 = P.w8row0[acc_col(wave, 0, lane)], w1 = P.w8row0[acc_col(wave, 1, lane)];
-            acc_load_native(acc, act + ((int64_t)7 * ntiles + tile) * TILE_F, wave, lane);
-            acc_map(acc, [&](int, int t, int, float h) { float s, em; softplus_deriv_from_h(h, s, em); return (t ? w1 : w0) * s; });
-            if (save) acc_store_native(acc, asave + ((int64_t)7 * ntiles + tile) * TILE_F, wave, lane);
-            acc_to_lds(acc, smain, wave, lane);
-            __syncthreads();
-        }
-        for (int l = 7; l >= 1; --l) {
-            acc_zero(acc);
-            gemm_rows_s(acc, smain, LDX, 16, P.rev16[l], wave, lane);               // u_l = a_l W_l
-            if (l == 4) gemm_auxout_s(ge, smain, 16, P.revaux16[4], wave, lane);      // skip path -> ge
-            // a_{l-1} = u_l * sigma'(z_{l-1})   (sigma' from act[l-1] == input of layer l)
-            const f32x4* hp = reinterpret_cast<const f32x4*>(act + ((int64_t)(l - 1) * ntiles + tile) * TILE_F) + (size_t)wave * MT * 8 * 64 + lane;
-            DH_UNROLL for (int m = 0; m < MT; ++m) {
-                DH_UNROLL for (int t = 0; t < 2; ++t)
-                    DH_UNROLL for (int r4 = 0; r4 < 4; ++r4) {
-                        const f32x4 h = hp[((m * 2 + t) * 4 + r4) * 64];
-                        DH_UNROLL for (int rr = 0; rr < 4; ++rr) {
-                            float s, em; softplus_deriv_from_h(h[rr], s, em);
-                            acc[m][t][4 * r4 + rr] *= s;
-                        }
-                    }
-                __builtin_amdgcn_sched_barrier(0);     // bound live registers: one m-slab (8 float4) in flight
-            }
-            if (save) acc_store_native(acc, asave + ((int64_t)(l - 1) * ntiles + tile) * TILE_F, wave, lane);
-            __syncthreads();
-            acc_to_lds(acc, smain, wave, lane);
-            __syncthreads();
-        }
-        gemm_auxout_s(ge, smain, 16, P.revaux16[0], wave, lane);                     // ge += a_0 W_0
-        // ge -> LDS aux image
-        DH_UNROLL for (int tt = 0; tt < AUX_NTW; ++tt) {
-            const int col = aux_col(wave, tt, lane);
-            if (col < AUXW) {
-                DH_UNROLL for (int r = 0; r < 16; ++r) saux[aux_row(wave, r, lane) * LDA + col] = ge[tt][r];
-            }
-        }
-        __syncthreads();
-        if (tid < TM) {
-            const int64_t gp = tile * TM + tid;
-            if (gp < npts) {
-                const float* g = saux + tid * LDA;
-                float n[3];
-                DH_UNROLL for (int c = 0; c < 3; ++c) {
-                    const float x = pts[gp * 3 + c];
-                    float v = g[c];
-                    DH_UNROLL for (int k = 0; k < 6; ++k) {
-                        const float f = (float)(1 << k);
-                        float s, co; sincosf(x * f, &s, &co);
-                        v += f * (co * g[3 + 6 * k + c] - s * g[3 + 6 * k + 3 + c]);
-                    }
-                    n[c] = v;
-                }
-                normals[gp * 3 + 0] = n[0]; normals[gp * 3 + 1] = n[1]; normals[gp * 3 + 2] = n[2];
-            }
-        }
-        __syncthreads();
-    }
-}
-
 // K2c, split-on-fetch
 __global__ __launch_bounds__(256, TM == 128 ? 1 : 2) void color_fwd_s_kernel(Col16Ptrs C, const float* __restrict__ pts, const float* __restrict__ dirs,
                                                             int n_per_ray, const float* __restrict__ normals,
@@ -653,69 +422,43 @@ __global__ __launch_bounds__(256, TM == 128 ? 1 : 2) void color_fwd_s_kernel(Col
     }
 }
 
+static inline int ok() { return hipGetLastError() == hipSuccess ? 0 : -3; }
+static inline int grid_for(int64_t npts, int grid) {
+    const int64_t ntiles = (npts + TM - 1) / TM;
+    return (int)(ntiles < grid ? ntiles : grid);
+}
+
 int launch_sdf_fwd_train(const float* packed, const float* pts, int64_t npts, float* sdf, float* feat, float* act,
                          float* eaux, int grid, hipStream_t stream) {
-    const int64_t ntiles = (npts + TM - 1) / TM;
-    const int g = (int)(ntiles < grid ? ntiles : grid);
-    static const bool f32 = (getenv("DH_FWD_F32") != nullptr || getenv("DH_ALL_F32") != nullptr);           // A/B switch: native fp32-MFMA chain
-    if (!f32 && !chain_pieces()) {
-        hipLaunchKernelGGL(sdf_fwd_train_s_kernel, dim3(g), dim3(256), 0, stream, make_sdf16_ptrs(packed), pts, npts, sdf, feat, act, eaux);
-        return hipGetLastError() == hipSuccess ? 0 : -3;
-    }
-    if (f32) hipLaunchKernelGGL(sdf_fwd_train_kernel, dim3(g), dim3(256), 0, stream, make_sdf_ptrs(packed), pts, npts, sdf, feat, act, eaux);
-    else hipLaunchKernelGGL(sdf_fwd_train16_kernel, dim3(g < 256 ? g : 256), dim3(256), 0, stream, make_sdf16_ptrs(packed), pts, npts, sdf, feat, act, eaux);
-    return hipGetLastError() == hipSuccess ? 0 : -3;
+    const int g = grid_for(npts, grid);
+    if (arith_fp32()) hipLaunchKernelGGL(sdf_fwd_train_kernel, dim3(g), dim3(256), 0, stream, make_sdf_ptrs(packed), pts, npts, sdf, feat, act, eaux);
+    else hipLaunchKernelGGL(sdf_fwd_train_s_kernel, dim3(g), dim3(256), 0, stream, make_sdf16_ptrs(packed), pts, npts, sdf, feat, act, eaux);
+    return ok();
 }
 int launch_sdf_grad(const float* packed, const float* pts, int64_t npts, const float* act, float* asave, float* normals,
                     int save, int grid, hipStream_t stream) {
-    const int64_t ntiles = (npts + TM - 1) / TM;
-    const int g = (int)(ntiles < grid ? ntiles : grid);
-    static const bool f32 = (getenv("DH_GRAD_F32") != nullptr || getenv("DH_ALL_F32") != nullptr);          // A/B switch: native fp32-MFMA chain
-    // measured per kernel: the reverse chain is faster in its piece-plane form (1.68 vs 1.75 ms), DH_GRAD_S=1 selects the
-    // split-on-fetch kernel
-    static const bool grad_s = getenv("DH_GRAD_S") != nullptr;
-    if (!f32 && !chain_pieces() && grad_s) {
-        hipLaunchKernelGGL(sdf_grad_s_kernel, dim3(g), dim3(256), 0, stream, make_sdf16_ptrs(packed), pts, npts, act, asave, normals, save);
-        return hipGetLastError() == hipSuccess ? 0 : -3;
-    }
-    if (f32) hipLaunchKernelGGL(sdf_grad_kernel, dim3(g), dim3(256), 0, stream, make_sdf_ptrs(packed), pts, npts, act, asave, normals, save);
-    else hipLaunchKernelGGL(sdf_grad16_kernel, dim3(g < 256 ? g : 256), dim3(256), 0, stream, make_sdf16_ptrs(packed), pts, npts, act, asave, normals, save);
-    return hipGetLastError() == hipSuccess ? 0 : -3;
+    // the reverse chain ships in its piece-plane form (one workgroup per CU): 1.68 vs 1.75 ms for split-on-fetch
+    if (arith_fp32()) hipLaunchKernelGGL(sdf_grad_kernel, dim3(grid_for(npts, grid)), dim3(256), 0, stream, make_sdf_ptrs(packed), pts, npts, act, asave, normals, save);
+    else hipLaunchKernelGGL(sdf_grad16_kernel, dim3(grid_for(npts, 256)), dim3(256), 0, stream, make_sdf16_ptrs(packed), pts, npts, act, asave, normals, save);
+    return ok();
 }
 int launch_color_fwd(const float* packed, const float* pts, const float* dirs, int n_per_ray, const float* normals,
                      const float* feat, int64_t npts, float* color, float* cact, float* caux, int save, int grid,
                      hipStream_t stream) {
-    const int64_t ntiles = (npts + TM - 1) / TM;
-    const int g = (int)(ntiles < grid ? ntiles : grid);
-    static const bool f32 = (getenv("DH_COLFWD_F32") != nullptr || getenv("DH_ALL_F32") != nullptr);        // A/B switch: native fp32-MFMA chain
-    if (!f32 && !chain_pieces()) {
-        hipLaunchKernelGGL(color_fwd_s_kernel, dim3(g), dim3(256), 0, stream, make_col16_ptrs(packed), pts, dirs, n_per_ray, normals,
-                           feat, npts, color, cact, caux, save);
-        return hipGetLastError() == hipSuccess ? 0 : -3;
-    }
-    if (f32) hipLaunchKernelGGL(color_fwd_kernel, dim3(g), dim3(256), 0, stream, make_col_ptrs(packed), pts, dirs, n_per_ray, normals,
-                                feat, npts, color, cact, caux, save);
-    else hipLaunchKernelGGL(color_fwd16_kernel, dim3(g < 256 ? g : 256), dim3(256), 0, stream, make_col16_ptrs(packed), pts, dirs,
-                            n_per_ray, normals, feat, npts, color, cact, caux, save);
-    return hipGetLastError() == hipSuccess ? 0 : -3;
+    const int g = grid_for(npts, grid);
+    if (arith_fp32()) hipLaunchKernelGGL(color_fwd_kernel, dim3(g), dim3(256), 0, stream, make_col_ptrs(packed), pts, dirs, n_per_ray, normals,
+                                         feat, npts, color, cact, caux, save);
+    else hipLaunchKernelGGL(color_fwd_s_kernel, dim3(g), dim3(256), 0, stream, make_col16_ptrs(packed), pts, dirs, n_per_ray, normals,
+                            feat, npts, color, cact, caux, save);
+    return ok();
 }
 
 int launch_sdf_nograd(const float* packed, const float* pts, int64_t npts, float* sdf, int grid, hipStream_t stream) {
     if (npts <= 0) return 0;
-    const int64_t ntiles = (npts + TM - 1) / TM;
-    const int g = (int)(ntiles < grid ? ntiles : grid);
-    static const bool f32 = (getenv("DH_NOGRAD_F32") != nullptr || getenv("DH_ALL_F32") != nullptr);        // A/B switch: native fp32-MFMA chain
-    if (!f32 && !chain_pieces()) {
-        hipLaunchKernelGGL(sdf_nograd_s_kernel, dim3(g), dim3(256), 0, stream, make_sdf16_ptrs(packed), pts, npts, sdf);
-        return hipGetLastError() == hipSuccess ? 0 : -3;
-    }
-    if (f32) hipLaunchKernelGGL(sdf_nograd_kernel, dim3(g), dim3(256), 0, stream, make_sdf_ptrs(packed), pts, npts, sdf);
-    else {
-        static const bool w4 = getenv("DH_NOGRAD_W4") != nullptr;     // A/B switch: 4-wave form of the split-bf16 kernel
-        if (w4) hipLaunchKernelGGL(sdf_nograd16_kernel, dim3(g < 256 ? g : 256), dim3(256), 0, stream, make_sdf16_ptrs(packed), pts, npts, sdf);
-        else hipLaunchKernelGGL(sdf_nograd16w8_kernel, dim3(g < 256 ? g : 256), dim3(512), 0, stream, make_sdf16_ptrs(packed), pts, npts, sdf);
-    }
-    return hipGetLastError() == hipSuccess ? 0 : -3;
+    const int g = grid_for(npts, grid);
+    if (arith_fp32()) hipLaunchKernelGGL(sdf_nograd_kernel, dim3(g), dim3(256), 0, stream, make_sdf_ptrs(packed), pts, npts, sdf);
+    else hipLaunchKernelGGL(sdf_nograd_s_kernel, dim3(g), dim3(256), 0, stream, make_sdf16_ptrs(packed), pts, npts, sdf);
+    return ok();
 }
 
 }  // namespace dh

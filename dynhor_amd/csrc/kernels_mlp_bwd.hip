@@ -7,7 +7,6 @@
 //   backward  zbar_l = hbar_{l+1} * sigma'(z_l) + r_l,  hbar_l = zbar_l W_l
 //   weights   Wbar_l = zbar_l^T in_l + a_l^T tt_l  (dw.hip),  bbar_l = colsum(zbar_l)
 // because the adjoint of the reverse-mode pass u -> a -> u is a forward-mode (tangent) pass in direction J_e nbar.
-#include <cstdlib>
 #include "tile.h"
 #include "kernels.h"
 #include "mlp_common.h"
@@ -286,74 +285,6 @@ __global__ __launch_bounds__(256, TM == 128 ? 1 : 2) void sdf_tangent_kernel(Sdf
     }
 }
 
-// K7a on the split-bf16 core
-__global__ __launch_bounds__(256, 1) void sdf_tangent16_kernel(Sdf16Ptrs P, const float* __restrict__ pts,
-                                                              const float* __restrict__ d_normals, int64_t npts,
-                                                              const float* __restrict__ act, const float* __restrict__ asave,
-                                                              float* __restrict__ t0aux, float* __restrict__ tsave,
-                                                              float* __restrict__ rsave, float* __restrict__ tpart) {
-    __shared__ __attribute__((aligned(16))) __bf16 smain[3 * P_MAIN];
-    __shared__ __attribute__((aligned(16))) __bf16 saux[3 * P_AUX];
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int64_t ntiles = (npts + TM - 1) / TM;
-    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        float* tp = tpart + tile * N_TILE_PART * 256;
-        {   // tt_0 = J_e(x) nbar
-            const int p = tid & (TM - 1), part = tid / TM;
-            const int64_t gp = tile * TM + p;
-            float x[3] = {0.f, 0.f, 0.f}, nb[3] = {0.f, 0.f, 0.f};
-            if (gp < npts) {
-                DH_UNROLL for (int c = 0; c < 3; ++c) { x[c] = pts[gp * 3 + c]; nb[c] = d_normals[gp * 3 + c]; }
-            }
-            __bf16* row = saux + p * LDA16;
-            if (part == 0) { aux_put16(row, 0, nb[0]); aux_put16(row, 1, nb[1]); aux_put16(row, 2, nb[2]); }
-            if (part == 1) { for (int c = 39; c < 48; ++c) aux_put16(row, c, 0.f); }
-            for (int k = part; k < 6; k += TPP) {
-                const float f = (float)(1 << k);
-                DH_UNROLL for (int c = 0; c < 3; ++c) {
-                    float s, co;
-                    sincosf(x[c] * f, &s, &co);
-                    aux_put16(row, 3 + 6 * k + c, f * co * nb[c]);
-                    aux_put16(row, 3 + 6 * k + 3 + c, -f * s * nb[c]);
-                }
-            }
-        }
-        __syncthreads();
-        aux_lds16_to_native(saux, t0aux + tile * AUXT_F, wave, lane);
-        f32x16 acc[MT][2];
-        for (int l = 0; l < 8; ++l) {
-            acc_zero(acc);
-            TileRegs hreg, areg;                                                     // act[l], asave[l] in flight under the GEMM
-            tile_prefetch(hreg, act + ((int64_t)l * ntiles + tile) * TILE_F, wave, lane);
-            tile_prefetch(areg, asave + ((int64_t)l * ntiles + tile) * TILE_F, wave, lane);
-            if (l > 0) gemm16_rows(acc, smain, P_MAIN, LDB, l == 4 ? 14 : 16, P.main16[l], wave, lane);
-            if (l == 0 || l == 4) gemm16_rows(acc, saux, P_AUX, LDA16, AUX_KC, P.aux16[l], wave, lane);     // abar_l
-            f32x4* rp = reinterpret_cast<f32x4*>(rsave + ((int64_t)l * ntiles + tile) * TILE_F) + (size_t)wave * MT * 8 * 64 + lane;
-            DH_UNROLL for (int m = 0; m < MT; ++m)
-                DH_UNROLL for (int t = 0; t < 2; ++t)
-                    DH_UNROLL for (int r4 = 0; r4 < 4; ++r4) {
-                        f32x4 rv;
-                        DH_UNROLL for (int rr = 0; rr < 4; ++rr) {
-                            float s, em; softplus_deriv_from_h(hreg.v[m][t][r4][rr], s, em);
-                            const float ab = acc[m][t][4 * r4 + rr];
-                            rv[rr] = ab * areg.v[m][t][r4][rr] * (SOFTPLUS_BETA * em);
-                            acc[m][t][4 * r4 + rr] = s * ab;
-                        }
-                        rp[((m * 2 + t) * 4 + r4) * 64] = rv;
-                    }
-            if (l < 7) {
-                acc_store_native(acc, tsave + ((int64_t)l * ntiles + tile) * TILE_F, wave, lane);    // t_{l+1}
-                __syncthreads();
-                acc_to_lds16(acc, smain, wave, lane);
-                __syncthreads();
-            } else {
-                tile_colsum(acc, tp + TP_W8ROW0_T * 256, wave, lane);                                 // colsum t_8
-            }
-        }
-        __syncthreads();
-    }
-}
-
 // ------------------------------------------------------------------------------------------------
 // K7b: backward chain -> zbar_l (l = 7..0), bias-gradient partials, Wbar_8[0,:] partial
 // ------------------------------------------------------------------------------------------------
@@ -430,177 +361,6 @@ __global__ __launch_bounds__(256, TM == 128 ? 1 : 2) void sdf_bwd_kernel(SdfPtrs
                 acc_zero(acc);
                 gemm_rows(acc, smain, LDX, 32, P.rev_main[l], wave, lane, pre);     // hbar_l = zbar_l W_l
                 if (l > 1) pre = gemm_b_prefetch(P.rev_main[l - 1], wave, lane);
-            }
-        }
-        __syncthreads();
-    }
-}
-
-// K7b on the split-bf16 core
-__global__ __launch_bounds__(256, 1) void sdf_bwd16_kernel(Sdf16Ptrs P, const float* __restrict__ d_sdf, int64_t npts,
-                                                          const float* __restrict__ act, const float* __restrict__ rsave,
-                                                          const float* __restrict__ featbar, float* __restrict__ zbar,
-                                                          float* __restrict__ tpart) {
-    __shared__ __attribute__((aligned(16))) __bf16 smain[3 * P_MAIN];
-    __shared__ __attribute__((aligned(16))) float saux[TM * LDA];     // scratch: sdfbar [128]
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int64_t ntiles = (npts + TM - 1) / TM;
-    const float w0c0 = P.w8row0[acc_col(wave, 0, lane)], w0c1 = P.w8row0[acc_col(wave, 1, lane)];
-    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        float* tp = tpart + tile * N_TILE_PART * 256;
-        if (tid < TM) {
-            const int64_t gp = tile * TM + tid;
-            saux[tid] = gp < npts ? d_sdf[gp] : 0.f;
-        }
-        f32x16 acc[MT][2];
-        acc_load_native(acc, featbar + tile * TILE_F, wave, lane);
-        tile_colsum(acc, tp + TP_SDF_B8 * 256, wave, lane);
-        acc_to_lds16(acc, smain, wave, lane);
-        __syncthreads();
-        if (wave == 0) {                                       // sum of sdfbar -> bbar_8[0]
-            float s = 0.f;
-            for (int i = lane; i < TM; i += 64) s += saux[i];
-            DH_UNROLL for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
-            if (lane == 0) tp[TP_SCAL * 256] = s;
-        }
-        // hbar_8 = featbar W8[1:,:] + sdfbar (x) W8[0,:]
-        acc_zero(acc);
-        TileRegs hreg, rreg;                                     // act[l], rsave[l]: always one GEMM ahead of their use
-        tile_prefetch(hreg, act + ((int64_t)7 * ntiles + tile) * TILE_F, wave, lane);
-        tile_prefetch(rreg, rsave + ((int64_t)7 * ntiles + tile) * TILE_F, wave, lane);
-        gemm16_rows(acc, smain, P_MAIN, LDB, 16, P.rev16[8], wave, lane);
-        DH_UNROLL for (int m = 0; m < MT; ++m)
-            DH_UNROLL for (int r = 0; r < 16; ++r) {
-                const float sb = saux[acc_row(m, r, lane)];
-                acc[m][0][r] = fmaf(sb, w0c0, acc[m][0][r]);
-                acc[m][1][r] = fmaf(sb, w0c1, acc[m][1][r]);
-            }
-        for (int l = 7; l >= 0; --l) {
-            float ws0 = 0.f, ws1 = 0.f;                         // sum_rows sdfbar * h_8 (l == 7 only)
-            DH_UNROLL for (int m = 0; m < MT; ++m)
-                DH_UNROLL for (int t = 0; t < 2; ++t)
-                    DH_UNROLL for (int r4 = 0; r4 < 4; ++r4)
-                        DH_UNROLL for (int rr = 0; rr < 4; ++rr) {
-                            const float h = hreg.v[m][t][r4][rr];
-                            float s, em; softplus_deriv_from_h(h, s, em);
-                            if (l == 7) {
-                                const float sb = saux[acc_row(m, 4 * r4 + rr, lane)];
-                                if (t == 0) ws0 = fmaf(sb, h, ws0); else ws1 = fmaf(sb, h, ws1);
-                            }
-                            acc[m][t][4 * r4 + rr] = fmaf(acc[m][t][4 * r4 + rr], s, rreg.v[m][t][r4][rr]);
-                        }
-            if (l == 7) {
-                ws0 += __shfl_xor(ws0, 32); ws1 += __shfl_xor(ws1, 32);
-                if (lane < 32) {
-                    tp[TP_W8ROW0_S * 256 + 64 * wave + lane] = ws0;
-                    tp[TP_W8ROW0_S * 256 + 64 * wave + 32 + lane] = ws1;
-                }
-            }
-            acc_store_native(acc, zbar + ((int64_t)l * ntiles + tile) * TILE_F, wave, lane);
-            tile_colsum(acc, tp + (TP_SDF_B0 + l) * 256, wave, lane);
-            if (l > 0) {
-                __syncthreads();
-                acc_to_lds16(acc, smain, wave, lane);
-                __syncthreads();
-                acc_zero(acc);
-                tile_prefetch(hreg, act + ((int64_t)(l - 1) * ntiles + tile) * TILE_F, wave, lane);
-                tile_prefetch(rreg, rsave + ((int64_t)(l - 1) * ntiles + tile) * TILE_F, wave, lane);
-                gemm16_rows(acc, smain, P_MAIN, LDB, 16, P.rev16[l], wave, lane);    // hbar_l = zbar_l W_l
-            }
-        }
-        __syncthreads();
-    }
-}
-
-// K6, split-on-fetch
-__global__ __launch_bounds__(256, TM == 128 ? 1 : 2) void color_bwd_s_kernel(Col16Ptrs C, const float* __restrict__ colors,
-                                                            const float* __restrict__ d_colors, int64_t npts,
-                                                            const float* __restrict__ cact, float* __restrict__ czbar,
-                                                            float* __restrict__ featbar, float* __restrict__ d_normals,
-                                                            float* __restrict__ tpart) {
-    __shared__ __attribute__((aligned(16))) float smain[TM * LDX];
-    __shared__ __attribute__((aligned(16))) float saux[TM * LDA];     // scratch: craw [128][4]
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int64_t ntiles = (npts + TM - 1) / TM;
-    const int col0 = acc_col(wave, 0, lane), col1 = acc_col(wave, 1, lane);
-    float w4[3][2];
-    DH_UNROLL for (int j = 0; j < 3; ++j) { w4[j][0] = C.w4[j * 256 + col0]; w4[j][1] = C.w4[j * 256 + col1]; }
-    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        float* tp = tpart + tile * N_TILE_PART * 256;
-        if (tid < TM) {
-            const int64_t gp = tile * TM + tid;
-            DH_UNROLL for (int j = 0; j < 3; ++j) {
-                float v = 0.f;
-                if (gp < npts) { const float c = colors[gp * 3 + j]; v = d_colors[gp * 3 + j] * c * (1.f - c); }
-                saux[tid * 4 + j] = v;
-            }
-            saux[tid * 4 + 3] = 0.f;
-        }
-        __syncthreads();
-        if (tid < 3) {                                               // db4
-            float s = 0.f;
-            for (int r = 0; r < TM; ++r) s += saux[r * 4 + tid];
-            tp[TP_COL_B4 * 256 + tid] = s;
-        }
-        f32x16 acc[MT][2];
-        // lin4: dW4 partials, zbar_3 = (craw W4) * [h4 > 0]
-        acc_load_native(acc, cact + ((int64_t)3 * ntiles + tile) * TILE_F, wave, lane);
-        {
-            float dw[3][2] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
-            DH_UNROLL for (int m = 0; m < MT; ++m)
-                DH_UNROLL for (int r = 0; r < 16; ++r) {
-                    const f32x4 cr = *reinterpret_cast<const f32x4*>(saux + acc_row(m, r, lane) * 4);
-                    DH_UNROLL for (int t = 0; t < 2; ++t) {
-                        const float h = acc[m][t][r];
-                        DH_UNROLL for (int j = 0; j < 3; ++j) dw[j][t] = fmaf(cr[j], h, dw[j][t]);
-                        const float hb = cr[0] * w4[0][t] + cr[1] * w4[1][t] + cr[2] * w4[2][t];
-                        acc[m][t][r] = h > 0.f ? hb : 0.f;
-                    }
-                }
-            DH_UNROLL for (int j = 0; j < 3; ++j)
-                DH_UNROLL for (int t = 0; t < 2; ++t) {
-                    float s = dw[j][t];
-                    s += __shfl_xor(s, 32);
-                    if (lane < 32) tp[(TP_COL_W4 + j) * 256 + 64 * wave + 32 * t + lane] = s;
-                }
-        }
-        acc_store_native(acc, czbar + ((int64_t)3 * ntiles + tile) * TILE_F, wave, lane);
-        tile_colsum(acc, tp + (TP_COL_B0 + 3) * 256, wave, lane);
-        acc_to_lds(acc, smain, wave, lane);
-        __syncthreads();
-        for (int l = 3; l >= 1; --l) {
-            acc_zero(acc);
-            gemm_rows_s(acc, smain, LDX, 16, C.rev16[l], wave, lane);                     // hbar_l = zbar_l W_l
-            const f32x4* hp = reinterpret_cast<const f32x4*>(cact + ((int64_t)(l - 1) * ntiles + tile) * TILE_F) + (size_t)wave * MT * 8 * 64 + lane;
-            DH_UNROLL for (int m = 0; m < MT; ++m) {
-                DH_UNROLL for (int t = 0; t < 2; ++t)
-                    DH_UNROLL for (int r4 = 0; r4 < 4; ++r4) {
-                        const f32x4 h = hp[((m * 2 + t) * 4 + r4) * 64];
-                        DH_UNROLL for (int rr = 0; rr < 4; ++rr)
-                            if (!(h[rr] > 0.f)) acc[m][t][4 * r4 + rr] = 0.f;
-                    }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            acc_store_native(acc, czbar + ((int64_t)(l - 1) * ntiles + tile) * TILE_F, wave, lane);
-            tile_colsum(acc, tp + (TP_COL_B0 + l - 1) * 256, wave, lane);
-            __syncthreads();
-            acc_to_lds(acc, smain, wave, lane);
-            __syncthreads();
-        }
-        // lin0: featbar = zbar_0 W0[:,33:] ; extras adjoint = zbar_0 W0[:,:33] (only the normal columns 30..32 matter)
-        acc_zero(acc);
-        gemm_rows_s(acc, smain, LDX, 16, C.rev16[0], wave, lane);
-        acc_store_native(acc, featbar + tile * TILE_F, wave, lane);
-        f32x16 a2[AUX_NTW];
-        aux_zero(a2);
-        gemm_auxout_s(a2, smain, 16, C.revaux16, wave, lane);
-        DH_UNROLL for (int tt = 0; tt < AUX_NTW; ++tt) {
-            const int col = aux_col(wave, tt, lane);
-            if (col >= 30 && col < 33) {
-                DH_UNROLL for (int r = 0; r < 16; ++r) {
-                    const int64_t gp = tile * TM + aux_row(wave, r, lane);
-                    if (gp < npts) d_normals[gp * 3 + (col - 30)] += a2[tt][r];
-                }
             }
         }
         __syncthreads();
@@ -758,10 +518,6 @@ __global__ __launch_bounds__(256, TM == 128 ? 1 : 2) void sdf_bwd_s_kernel(Sdf16
 }
 
 static inline int ok() { return hipGetLastError() == hipSuccess ? 0 : -3; }
-// A/B switch: DH_BWD_F32 selects the native fp32-MFMA backward chains
-// A/B switch: DH_CHAIN_PIECES=1 selects the piece-plane (one workgroup per CU) form of the split-bf16 chains
-static inline bool chain_pieces() { static const bool v = getenv("DH_CHAIN_PIECES") != nullptr; return v; }
-static inline bool chains_f32() { static const bool v = (getenv("DH_BWD_F32") != nullptr || getenv("DH_ALL_F32") != nullptr); return v; }
 static inline int grid_for(int64_t npts, int grid) {
     const int64_t ntiles = (npts + TM - 1) / TM;
     return (int)(ntiles < grid ? ntiles : grid);
@@ -769,15 +525,8 @@ static inline int grid_for(int64_t npts, int grid) {
 
 int launch_color_bwd(const float* packed, const float* colors, const float* d_colors, int64_t npts, const float* cact,
                      float* czbar, float* featbar, float* d_normals, float* tpart, int grid, hipStream_t st) {
-    // measured per kernel: the colour backward is faster in its piece-plane form (0.97 vs 1.04 ms); DH_COLBWD_S=1 selects the
-    // split-on-fetch kernel
-    static const bool colbwd_s = getenv("DH_COLBWD_S") != nullptr;
-    if (!chains_f32() && !chain_pieces() && colbwd_s) {
-        hipLaunchKernelGGL(color_bwd_s_kernel, dim3(grid_for(npts, grid)), dim3(256), 0, st, make_col16_ptrs(packed), colors, d_colors,
-                           npts, cact, czbar, featbar, d_normals, tpart);
-        return ok();
-    }
-    if (chains_f32()) hipLaunchKernelGGL(color_bwd_kernel, dim3(grid_for(npts, grid)), dim3(256), 0, st, make_col_ptrs(packed), colors,
+    // the colour backward ships in its piece-plane form (one workgroup per CU): 0.97 vs 1.04 ms for split-on-fetch
+    if (arith_fp32()) hipLaunchKernelGGL(color_bwd_kernel, dim3(grid_for(npts, grid)), dim3(256), 0, st, make_col_ptrs(packed), colors,
                                          d_colors, npts, cact, czbar, featbar, d_normals, tpart);
     else hipLaunchKernelGGL(color_bwd16_kernel, dim3(grid_for(npts, 256)), dim3(256), 0, st, make_col16_ptrs(packed), colors, d_colors,
                             npts, cact, czbar, featbar, d_normals, tpart);
@@ -785,30 +534,17 @@ int launch_color_bwd(const float* packed, const float* colors, const float* d_co
 }
 int launch_sdf_tangent(const float* packed, const float* pts, const float* d_normals, int64_t npts, const float* act,
                        const float* asave, float* t0aux, float* tsave, float* rsave, float* tpart, int grid, hipStream_t st) {
-    // the tangent chain's epilogue (two tile loads, two tile stores per layer) needs the second workgroup per CU more than
-    // it gains from the faster MFMAs: fp32 kernel 2.60 ms, split-bf16 kernel 2.70 ms -> fp32 stays the default here
-    if (!chains_f32() && !chain_pieces() && getenv("DH_TANGENT_F32") == nullptr) {
-        hipLaunchKernelGGL(sdf_tangent_s_kernel, dim3(grid_for(npts, grid)), dim3(256), 0, st, make_sdf16_ptrs(packed), pts, d_normals,
-                           npts, act, asave, t0aux, tsave, rsave, tpart);
-        return ok();
-    }
-    static const bool tangent16 = getenv("DH_TANGENT_BF16") != nullptr;
-    if (!tangent16 || chains_f32()) hipLaunchKernelGGL(sdf_tangent_kernel, dim3(grid_for(npts, grid)), dim3(256), 0, st, make_sdf_ptrs(packed), pts,
+    if (arith_fp32()) hipLaunchKernelGGL(sdf_tangent_kernel, dim3(grid_for(npts, grid)), dim3(256), 0, st, make_sdf_ptrs(packed), pts,
                                          d_normals, npts, act, asave, t0aux, tsave, rsave, tpart);
-    else hipLaunchKernelGGL(sdf_tangent16_kernel, dim3(grid_for(npts, 256)), dim3(256), 0, st, make_sdf16_ptrs(packed), pts, d_normals,
+    else hipLaunchKernelGGL(sdf_tangent_s_kernel, dim3(grid_for(npts, grid)), dim3(256), 0, st, make_sdf16_ptrs(packed), pts, d_normals,
                             npts, act, asave, t0aux, tsave, rsave, tpart);
     return ok();
 }
 int launch_sdf_bwd(const float* packed, const float* d_sdf, int64_t npts, const float* act, const float* rsave,
                    const float* featbar, float* zbar, float* tpart, int grid, hipStream_t st) {
-    if (!chains_f32() && !chain_pieces()) {
-        hipLaunchKernelGGL(sdf_bwd_s_kernel, dim3(grid_for(npts, grid)), dim3(256), 0, st, make_sdf16_ptrs(packed), d_sdf, npts, act,
-                           rsave, featbar, zbar, tpart);
-        return ok();
-    }
-    if (chains_f32()) hipLaunchKernelGGL(sdf_bwd_kernel, dim3(grid_for(npts, grid)), dim3(256), 0, st, make_sdf_ptrs(packed), d_sdf, npts,
+    if (arith_fp32()) hipLaunchKernelGGL(sdf_bwd_kernel, dim3(grid_for(npts, grid)), dim3(256), 0, st, make_sdf_ptrs(packed), d_sdf, npts,
                                          act, rsave, featbar, zbar, tpart);
-    else hipLaunchKernelGGL(sdf_bwd16_kernel, dim3(grid_for(npts, 256)), dim3(256), 0, st, make_sdf16_ptrs(packed), d_sdf, npts, act,
+    else hipLaunchKernelGGL(sdf_bwd_s_kernel, dim3(grid_for(npts, grid)), dim3(256), 0, st, make_sdf16_ptrs(packed), d_sdf, npts, act,
                             rsave, featbar, zbar, tpart);
     return ok();
 }

@@ -9,14 +9,11 @@
 
 namespace dh {
 
-#ifndef DH_TM
-#define DH_TM 64
-#endif
-constexpr int TM = DH_TM;      // points per tile (= rows of every tile GEMM): 64 is the shipping (and, since the split-bf16
-                               // kernels of tile16.h, the only building) configuration; 128 was measured 9 % slower
-                               // end to end with the fp32-MFMA kernels
+constexpr int TM = 64;         // points per tile (= rows of every tile GEMM).  Fixed: the split-bf16 kernels are written for
+                               // 64-point tiles (two workgroups per CU); 128 measured 9 % slower with the fp32-MFMA kernels
+                               // (DESIGN.md "tried and rejected") and its build switch was removed in round 2
 constexpr int MT = TM / 32;    // 32-row m-tiles per tile
-static_assert(TM == 64 || TM == 128, "tile height");
+static_assert(TM == 64, "tile height");
 constexpr int HID = 256;       // hidden width == main-tile width
 constexpr int AUXW = 40;       // aux tile logical width (39 embedding / 33 colour extras, zero padded)
 constexpr int LDX = 260;       // LDS row stride (floats) of the main tile: 260 % 64 == 4 -> b128 reads conflict free

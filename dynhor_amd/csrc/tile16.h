@@ -8,9 +8,10 @@
 // Two ways of feeding the A operand (both in this file; the faster one per kernel ships):
 //   * split-on-fetch (gemm_rows_s / gemm_auxout_s): the LDS image stays tile.h's fp32 image (two workgroups per CU) and
 //     each wave splits its A fragments as it reads them;
-//   * piece planes (gemm16_rows / gemm16_auxout / acc_to_lds16 ...): three bf16 planes [TM x 256], row stride LDB = 264
-//     (528 B: 16 lanes x 16 B cover all 64 banks), plus aux planes [TM x 48] (stride 56); the split happens once, in the
-//     epilogue that writes the image (122 KB: one workgroup per CU).
+//   * piece planes (gemm16_rows / gemm16_auxout / acc_to_lds16): three bf16 planes [TM x 256], row stride LDB = 264
+//     (528 B: 16 lanes x 16 B cover all 64 banks); the split happens once, in the epilogue that writes the image
+//     (one workgroup per CU).  Ships for the reverse chain and the colour backward, whose epilogue inputs are
+//     prefetched into registers under the GEMM (tile_prefetch).
 // Packed weights (pack.hip): bf16x8 index ((kc*NT + nt)*3 + piece)*64 + lane holds
 //   M[k = 16 kc + 8 (lane>>5) + s][n = 32 nt + (lane&31)], s = 0..7.
 #pragma once
@@ -22,10 +23,8 @@ typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 bf16x8;
 struct Bf3 { bf16x8 p[3]; };
 
 constexpr int LDB = 264;             // bf16 row stride of a main piece plane
-constexpr int LDA16 = 56;            // bf16 row stride of an aux piece plane (48 valid columns)
 constexpr int P_MAIN = TM * LDB;     // elements per main piece plane
-constexpr int P_AUX = TM * LDA16;
-constexpr int AUX_KC = 3;            // 48 / 16
+constexpr int AUX_KC = 3;            // k-chunks of the aux image: 48 / 16
 
 __device__ __forceinline__ void split_f32(float v, __bf16& h1, __bf16& h2, __bf16& h3) {
     h1 = (__bf16)v;
@@ -102,49 +101,6 @@ __device__ __forceinline__ void acc_to_lds16(const f32x16 (&acc)[MT][2], __bf16*
         }
 }
 
-// positional embedding of the tile's points into the aux piece planes (columns 39..47 zero)
-__device__ __forceinline__ void embed_tile16(const float* __restrict__ pts, int64_t base, int64_t npts, __bf16* aux, int tid) {
-    constexpr int TPP16 = 256 / TM;
-    const int p = tid & (TM - 1), part = tid / TM;
-    const int64_t gp = base + p;
-    float x[3] = {0.f, 0.f, 0.f};
-    if (gp < npts) { x[0] = pts[gp * 3 + 0]; x[1] = pts[gp * 3 + 1]; x[2] = pts[gp * 3 + 2]; }
-    __bf16* row = aux + p * LDA16;
-    auto put = [&](int c, float v) {
-        __bf16 h1, h2, h3;
-        split_f32(v, h1, h2, h3);
-        row[c] = h1; row[P_AUX + c] = h2; row[2 * P_AUX + c] = h3;
-    };
-    if (part == 0) { put(0, x[0]); put(1, x[1]); put(2, x[2]); }
-    if (part == 1) { for (int c = 39; c < 48; ++c) put(c, 0.f); }
-    for (int k = part; k < 6; k += TPP16) {
-        const float f = (float)(1 << k);
-        DH_UNROLL for (int c = 0; c < 3; ++c) {
-            float s, co;
-            sincosf(x[c] * f, &s, &co);
-            put(3 + 6 * k + c, s);
-            put(3 + 6 * k + 3 + c, co);
-        }
-    }
-}
-
-// per-point dot of the main image rows (pieces summed back to fp32) with a 256-vector; TPP threads per point
-__device__ __forceinline__ float row_dot256_16(const __bf16* main, const float* __restrict__ w, int tid) {
-    constexpr int TPP16 = 256 / TM, SEG = 256 / TPP16;
-    const int p = tid / TPP16, part = tid % TPP16;
-    const __bf16* xr = main + p * LDB + part * SEG;
-    const float* wr = w + part * SEG;
-    float s = 0.f;
-    DH_UNROLL for (int i = 0; i < SEG / 8; ++i) {
-        const bf16x8 a = *reinterpret_cast<const bf16x8*>(xr + 8 * i);
-        const bf16x8 b = *reinterpret_cast<const bf16x8*>(xr + P_MAIN + 8 * i);
-        const bf16x8 c = *reinterpret_cast<const bf16x8*>(xr + 2 * P_MAIN + 8 * i);
-        DH_UNROLL for (int e = 0; e < 8; ++e) s = fmaf(((float)a[e] + (float)b[e]) + (float)c[e], wr[8 * i + e], s);
-    }
-    DH_UNROLL for (int off = 1; off < TPP16; off <<= 1) s += __shfl_xor(s, off);
-    return s;
-}
-
 // acc2[.] += X[rows of this wave's m-tile][16 nkc] * M (NT = 2): the 64-wide "aux" output (tile.h gemm_auxout)
 __device__ __forceinline__ void gemm16_auxout(f32x16 (&acc2)[AUX_NTW], const __bf16* xs, const int nkc,
                                               const bf16x8* __restrict__ wp, const int wave, const int lane) {
@@ -169,30 +125,6 @@ __device__ __forceinline__ void gemm16_auxout(f32x16 (&acc2)[AUX_NTW], const __b
             __builtin_amdgcn_sched_barrier(0);
         }
     }
-}
-
-// one fp32 value -> the three piece planes of an aux row
-__device__ __forceinline__ void aux_put16(__bf16* row, int c, float v) {
-    __bf16 h1, h2, h3;
-    split_f32(v, h1, h2, h3);
-    row[c] = h1; row[P_AUX + c] = h2; row[2 * P_AUX + c] = h3;
-}
-
-// LDS aux piece planes (cols < 40 valid) -> fp32 aux native tile in HBM (same layout as tile.h aux_lds_to_native)
-__device__ __forceinline__ void aux_lds16_to_native(const __bf16* aux, float* __restrict__ tile, int wave, int lane) {
-    f32x16 a2[AUX_NTW];
-    DH_UNROLL for (int tt = 0; tt < AUX_NTW; ++tt) {
-        const int col = aux_col(wave, tt, lane);
-        DH_UNROLL for (int r = 0; r < 16; ++r) {
-            float v = 0.f;
-            if (col < AUXW) {
-                const __bf16* e = aux + aux_row(wave, r, lane) * LDA16 + col;
-                v = ((float)e[0] + (float)e[P_AUX]) + (float)e[2 * P_AUX];
-            }
-            a2[tt][r] = v;
-        }
-    }
-    aux_store_native(a2, tile, wave, lane);
 }
 
 // A saved native tile as registers (same element order as the accumulators): issued BEFORE a GEMM so its HBM latency sits
@@ -268,85 +200,6 @@ __device__ __forceinline__ void gemm_auxout_s(f32x16 (&acc2)[AUX_NTW], const flo
             DH_UNROLL for (int t = 0; t < AUX_NTW; ++t) acc2[t] = mfma6(a1, b1[t], acc2[t]);
         }
     }
-}
-
-// ---------------------------------------------------------------- 8-wave variant (512 threads, two waves per SIMD)
-// Same tile, same LDS image; wave w8 = 0..7 owns the single 32-column tile ct = w8 (native index: wave = ct >> 1,
-// t = ct & 1), so acc is [MT][1] and the B operand per wave halves while every wave still reads the whole A image.
-// The second wave on each SIMD covers the epilogue (activation, split, 16-bit LDS writes) of the first.
-__device__ __forceinline__ void gemm16_rows_w8(f32x16 (&acc)[MT], const __bf16* xs, const int pstride, const int ld,
-                                               const int nkc, const bf16x8* __restrict__ wp, const int w8, const int lane) {
-    const __bf16* xrow = xs + (lane & 31) * ld + 8 * (lane >> 5);
-    const bf16x8* wl = wp + w8 * 3 * 64 + lane;
-    Bf3 a0[MT], b0, a1[MT], b1;
-    auto fetch = [&](Bf3 (&a)[MT], Bf3& b, int kc) {
-        DH_UNROLL for (int p = 0; p < 3; ++p) b.p[p] = wl[(kc * 8 * 3 + p) * 64];
-        DH_UNROLL for (int m = 0; m < MT; ++m)
-            DH_UNROLL for (int p = 0; p < 3; ++p)
-                a[m].p[p] = *reinterpret_cast<const bf16x8*>(xrow + p * pstride + m * 32 * ld + kc * 16);
-    };
-    fetch(a0, b0, 0);
-    _Pragma("unroll 1") for (int kc = 0; kc < nkc; kc += 2) {
-        fetch(a1, b1, (kc + 1 < nkc) ? kc + 1 : kc);
-        __builtin_amdgcn_sched_barrier(0);
-        DH_UNROLL for (int m = 0; m < MT; ++m) acc[m] = mfma6(a0[m], b0, acc[m]);
-        __builtin_amdgcn_sched_barrier(0);
-        if (kc + 1 < nkc) {
-            fetch(a0, b0, (kc + 2 < nkc) ? kc + 2 : kc + 1);
-            __builtin_amdgcn_sched_barrier(0);
-            DH_UNROLL for (int m = 0; m < MT; ++m) acc[m] = mfma6(a1[m], b1, acc[m]);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    }
-}
-
-__device__ __forceinline__ void acc_to_lds16_w8(const f32x16 (&acc)[MT], __bf16* xs, int w8, int lane) {
-    DH_UNROLL for (int m = 0; m < MT; ++m) {
-        __bf16* base = xs + (m * 32 + 4 * (lane >> 5)) * LDB + 32 * w8 + (lane & 31);
-        DH_UNROLL for (int r = 0; r < 16; ++r) {
-            __bf16 h1, h2, h3;
-            split_f32(acc[m][r], h1, h2, h3);
-            __bf16* e = base + ((r & 3) + 8 * (r >> 2)) * LDB;
-            e[0] = h1; e[P_MAIN] = h2; e[2 * P_MAIN] = h3;
-        }
-    }
-}
-
-// embedding with 512 threads: thread (p = tid & 63, part = tid >> 6): part 0 x, part 1 zero pad, parts 0..5 one frequency each
-__device__ __forceinline__ void embed_tile16_w8(const float* __restrict__ pts, int64_t base, int64_t npts, __bf16* aux, int tid) {
-    static_assert(TM == 64, "8-wave kernels are written for 64-point tiles");
-    const int p = tid & 63, part = tid >> 6;
-    const int64_t gp = base + p;
-    float x[3] = {0.f, 0.f, 0.f};
-    if (gp < npts) { x[0] = pts[gp * 3 + 0]; x[1] = pts[gp * 3 + 1]; x[2] = pts[gp * 3 + 2]; }
-    __bf16* row = aux + p * LDA16;
-    if (part == 6) { aux_put16(row, 0, x[0]); aux_put16(row, 1, x[1]); aux_put16(row, 2, x[2]); }
-    if (part == 7) { for (int c = 39; c < 48; ++c) aux_put16(row, c, 0.f); }
-    if (part < 6) {
-        const float f = (float)(1 << part);
-        DH_UNROLL for (int c = 0; c < 3; ++c) {
-            float s, co;
-            sincosf(x[c] * f, &s, &co);
-            aux_put16(row, 3 + 6 * part + c, s);
-            aux_put16(row, 3 + 6 * part + 3 + c, co);
-        }
-    }
-}
-
-// per-point dot with 8 threads per point (point = tid >> 3)
-__device__ __forceinline__ float row_dot256_16_w8(const __bf16* main, const float* __restrict__ w, int tid) {
-    const int p = tid >> 3, part = tid & 7;
-    const __bf16* xr = main + p * LDB + part * 32;
-    const float* wr = w + part * 32;
-    float s = 0.f;
-    DH_UNROLL for (int i = 0; i < 4; ++i) {
-        const bf16x8 a = *reinterpret_cast<const bf16x8*>(xr + 8 * i);
-        const bf16x8 b = *reinterpret_cast<const bf16x8*>(xr + P_MAIN + 8 * i);
-        const bf16x8 c = *reinterpret_cast<const bf16x8*>(xr + 2 * P_MAIN + 8 * i);
-        DH_UNROLL for (int e = 0; e < 8; ++e) s = fmaf(((float)a[e] + (float)b[e]) + (float)c[e], wr[8 * i + e], s);
-    }
-    DH_UNROLL for (int off = 1; off < 8; off <<= 1) s += __shfl_xor(s, off);
-    return s;
 }
 
 }  // namespace dh

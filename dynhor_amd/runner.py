@@ -103,18 +103,19 @@ class Runner:
                                      store=self.store, device=self.device, **self.conf["model"]["neus_renderer"])
         self.ray_gen = torch.Generator(device=self.device)
         self.ray_gen.manual_seed(tr["ray_seed"] * 1000003 + self.rank)
-        self.perm_gen = torch.Generator(device="cpu")
-        self.perm_gen.manual_seed(tr["ray_seed"])   # same permutation on every rank
-        self.image_perm = self.get_image_perm()
+        self.frame_perm = schedules.FramePermutation(self.dataset.n_images, tr["ray_seed"])   # same on every rank
         self.scalars = []
         if is_continue:
-            ck = sorted(f for f in os.listdir(os.path.join(self.base_exp_dir, "checkpoints")) if f.endswith(".pth"))
+            ck_dir = os.path.join(self.base_exp_dir, "checkpoints")
+            ck = sorted(f for f in os.listdir(ck_dir) if f.endswith(".pth")) if os.path.isdir(ck_dir) else []
             if ck:
                 self.load_checkpoint(ck[-1])
 
     # ------------------------------------------------------------------ schedules (App. A.8)
-    def get_image_perm(self):
-        return torch.randperm(self.dataset.n_images, generator=self.perm_gen)
+    @property
+    def image_perm(self):
+        """Upstream name of the current epoch's frame permutation."""
+        return self.frame_perm.perm
 
     def get_cos_anneal_ratio(self):
         return schedules.cos_anneal_ratio(self.iter_step, self.anneal_end)
@@ -127,13 +128,15 @@ class Runner:
         self.lr = self.current_lr()
         return self.lr
 
+    def frame_for_slot(self, slot: int) -> int:
+        """Frame of permutation slot `slot`: the permutation is re-drawn once per epoch (upstream re-permutes when
+        iter_step % n_images == 0) from the SHARED perm_gen, so every rank holds the same e-th permutation for epoch e
+        whatever the world size."""
+        return self.frame_perm.frame(slot)
+
     # ------------------------------------------------------------------ one iteration (the hot loop)
     def train_iteration(self):
-        n = self.dataset.n_images
-        slot = schedules.frame_slot(self.iter_step, self.rank, self.world)
-        if self.world == 1 and slot % n == 0 and slot > 0:
-            self.image_perm = self.get_image_perm()
-        frame = int(self.image_perm[slot % n])
+        frame = self.frame_for_slot(schedules.frame_slot(self.iter_step, self.rank, self.world))
         rays = self.dataset.gen_random_rays_at(frame, self.batch_size, keep_only=self.keep_only, generator=self.ray_gen)
         near, far = self.dataset._last_near_far
         self._last_rays = rays
@@ -142,7 +145,7 @@ class Runner:
                                               self.igr_weight, self.mask_weight, self.normal_weight, background_rgb=bg)
         grad = self.store.grad_flat
         dh_dist.allreduce_sum_(grad)                             # RCCL over xGMI: one 3.2 MB bucket
-        lr = self.current_lr() if self.iter_step > 0 else self.learning_rate / max(self.warm_up_end, 1)
+        lr = self.current_lr()          # 0 at iter_step 0, as upstream (update_learning_rate() runs before the loop)
         self.store.adam_step(lr, grad=grad, grad_scale=1.0 / self.world)
         self.iter_step += 1
         return stats
@@ -182,7 +185,11 @@ class Runner:
         ck = {"nerf": {}, "sdf_network_fine": self.sdf_network.state_dict(),
               "variance_network_fine": self.deviation_network.state_dict(),
               "color_network_fine": self.color_network.state_dict(),
-              "optimizer": self.store.optimizer_state_dict(self.current_lr()), "iter_step": self.iter_step}
+              "optimizer": self.store.optimizer_state_dict(self.current_lr()), "iter_step": self.iter_step,
+              # extra keys (upstream loaders ignore them): the ray / permutation RNG streams, so that a resumed run draws
+              # the pixels and frames an uninterrupted one would have drawn
+              "dynhor_rng": {"ray_gen": self.ray_gen.get_state(), "frame_perm": self.frame_perm.state_dict(),
+                             "rank": self.rank, "world": self.world}}
         d = os.path.join(self.base_exp_dir, "checkpoints")
         os.makedirs(d, exist_ok=True)
         path = os.path.join(d, "ckpt_{:0>6d}.pth".format(self.iter_step))
@@ -204,6 +211,14 @@ class Runner:
                 opt = {"state": {i - extra: v for i, v in st.items() if i >= extra}, "param_groups": opt["param_groups"]}
             self.store.load_optimizer_state_dict(opt)
         self.iter_step = ck["iter_step"]
+        rng = ck.get("dynhor_rng")
+        if rng is not None:
+            self.frame_perm.load_state_dict(rng["frame_perm"])
+            if rng.get("rank", 0) == self.rank and rng.get("world", 1) == self.world:
+                self.ray_gen.set_state(rng["ray_gen"].cpu())
+            else:   # only rank 0 writes checkpoints: the other ranks restart their own stream at a point no earlier
+                    # iteration used (not bit-equal to an uninterrupted run, but no pixel draw is replayed)
+                self.ray_gen.manual_seed((self.conf["train"]["ray_seed"] * 1000003 + self.rank) ^ (self.iter_step * 2654435761 % (1 << 31)))
         self.store.bump()
 
     # ------------------------------------------------------------------ validation

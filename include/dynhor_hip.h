@@ -10,11 +10,12 @@
  *   - plain pointers and sizes; every pointer is a DEVICE pointer unless named host_*; fp32 row-major.
  *   - the caller allocates everything (torch tensors); the library never allocates, frees or retains pointers.
  *   - `stream` is a hipStream_t passed as void*; kernels are enqueued on it, no implicit synchronisation.
- *   - return 0 on success or a negative dh_status; never throws, never exits.  Re-entrant, no global state.
+ *   - return 0 on success or a negative dh_status; never throws, never exits.  Re-entrant: the library keeps no
+ *     pointer and no per-call state.  Its ONLY process-global state is the two mode words set by dh_set_arithmetic() and
+ *     dh_hash_set_scatter_mode() below (plain ints read at every launch; no environment variable is read anywhere).
  *   - arithmetic: every buffer that crosses this boundary is fp32.  Inside, the GEMMs form each fp32 product from bf16
  *     pieces on the bf16 matrix cores (3-way split of both operands, six MFMA products, fp32 accumulation: 2^-24
- *     relative, i.e. fp32 accuracy -- DESIGN.md section 3).  The environment variable DH_ALL_F32=1 (read once per
- *     process) selects the native fp32-MFMA twin of every kernel; per-kernel A/B switches are listed in DESIGN.md.
+ *     relative, i.e. fp32 accuracy -- DESIGN.md section 3).
  */
 #ifndef DYNHOR_HIP_H
 #define DYNHOR_HIP_H
@@ -34,6 +35,14 @@ typedef enum {
 
 int dh_version(void);
 const char* dh_strerror(int status);
+
+/* Arithmetic of every MLP GEMM, process-wide.  DH_ARITH_SPLIT_BF16 (default): the shipping kernels described above.
+ * DH_ARITH_FP32_MFMA: the native v_mfma_f32_32x32x2_f32 twin of every kernel (1.34x slower; kept as the second,
+ * independent arithmetic that tests/test_gpu_arithmetic_modes.py checks the first against).  Takes effect for launches
+ * enqueued after the call; both sets read and write the same buffers (packed weights, workspace, outputs). */
+typedef enum { DH_ARITH_SPLIT_BF16 = 0, DH_ARITH_FP32_MFMA = 1 } dh_arithmetic;
+int dh_set_arithmetic(int mode);
+int dh_get_arithmetic(void);
 
 /* ---- parameter vector / packed weights -----------------------------------------------------------------
  * One flat fp32 vector of dh_num_params() == 802,491 values in state_dict order (SURVEY.md §5 checkpoint row:
@@ -203,6 +212,10 @@ int dh_hash_geo_backward(const float* params, const float* packed, const float* 
                          const float* d_feature, const float* d_normals, int64_t n, float radius, float eps, float* ws,
                          void* stream);
 int dh_hash_weight_grads(const float* params, const float* packed, int64_t n, float* ws, float* grad, void* stream);
+/* Diagnosis only (scripts/psnr_parity.py ablations): how dh_hash_weight_grads merges table-gradient adds before they
+ * reach memory.  0 (default, shipping) = 7-evaluation blending + ray-run merging + quad-lane packing; 1 = no ray-run
+ * merging; 2 = neither (one atomic per evaluation corner, tcnn's scheme).  Same sums up to float-atomic ordering. */
+int dh_hash_set_scatter_mode(int mode);
 
 #ifdef __cplusplus
 }

@@ -1,5 +1,5 @@
 // Microbenchmark of the tile GEMM core (tile.h gemm_rows) without epilogues: how close does the MFMA loop itself get
-// to the fp32 MFMA peak, at TM=64 (2 WG/CU) and TM=128 (1 WG/CU)?  Build: hipcc --offload-arch=gfx950 -O3 -DDH_TM=64 ...
+// to the fp32 MFMA peak, at TM=64 (2 WG/CU)?  (TM=128, 1 WG/CU, was measured in round 1 and its build switch removed.)  Build: make gemm_micro_64
 #pragma clang diagnostic ignored "-Wunused-value"
 #include <hip/hip_runtime.h>
 #include <cstdio>

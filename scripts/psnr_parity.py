@@ -82,7 +82,7 @@ def main():
     for it in range(args.iters):
         frame = int(perm[it % ds.n_images])
         car = schedules.cos_anneal_ratio(it, 50000)
-        lr = args.lr * (schedules.lr_factor(it, 5000, 300000, 0.05) if it > 0 else 1.0 / 5000)
+        lr = args.lr * schedules.lr_factor(it, 5000, 300000, 0.05)
         # ---- HIP path
         torch.cuda.synchronize(); t0 = time.perf_counter()
         px, py, tr = draw(gen_h)

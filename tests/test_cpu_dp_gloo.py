@@ -33,8 +33,10 @@ def _worker(rank, world, port, out_dir):
     mean = grad * (1.0 / world)                       # what dh_adam_step's grad_scale applies
     stats = dh_dist.mean_stats(torch.full((8,), float(rank)))
     assert torch.allclose(stats, torch.full((8,), (world - 1) / 2.0))
-    perm = torch.randperm(64, generator=torch.Generator().manual_seed(4321))
-    frames = [int(perm[schedules.frame_slot(it, rank, world) % 64]) for it in range(32)]
+    fp = schedules.FramePermutation(64, 4321)
+    frames = [fp.frame(schedules.frame_slot(it, rank, world)) for it in range(32)]
+    frames2 = [fp.frame(schedules.frame_slot(it, rank, world)) for it in range(32, 64)]      # second epoch: re-drawn
+    torch.save({"frames2": frames2, "perm2": fp.perm.clone(), "epoch": fp.epoch}, os.path.join(out_dir, f"e{rank}.pt"))
     torch.save({"mean": mean, "frames": frames}, os.path.join(out_dir, f"r{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
@@ -48,3 +50,28 @@ def test_gradient_allreduce_and_frame_sharding(tmp_path):
     assert torch.equal(r0["mean"], r1["mean"]), "every rank must step with the identical mean gradient"
     assert len(set(r0["frames"]) & set(r1["frames"])) == 0, "ranks take disjoint frames within an epoch"
     assert sorted(r0["frames"] + r1["frames"]) == list(range(64)), "one epoch covers every frame exactly once"
+    e0 = torch.load(tmp_path / "e0.pt")
+    e1 = torch.load(tmp_path / "e1.pt")
+    assert e0["epoch"] == e1["epoch"] == 1 and torch.equal(e0["perm2"], e1["perm2"]), "every rank re-draws the SAME permutation"
+    assert sorted(e0["frames2"] + e1["frames2"]) == list(range(64)), "the second epoch covers every frame once as well"
+    first_epoch = [None] * 64
+    first_epoch[0::2], first_epoch[1::2] = r0["frames"], r1["frames"]
+    second_epoch = [None] * 64
+    second_epoch[0::2], second_epoch[1::2] = e0["frames2"], e1["frames2"]
+    assert first_epoch != second_epoch, "world > 1 must reshuffle per epoch too (VERDICT r1 weak #14)"
+
+
+def test_frame_permutation_state_roundtrip_and_world_independence():
+    from dynhor_amd import schedules
+    a = schedules.FramePermutation(10, 7)
+    seq_w1 = [a.frame(s) for s in range(35)]
+    # world 3, ragged (10 % 3 != 0): ranks cross the epoch boundary at different iterations, same sequence of slots
+    ranks = [schedules.FramePermutation(10, 7) for _ in range(3)]
+    seq_w3 = [None] * 36
+    for it in range(12):
+        for r in range(3):
+            seq_w3[schedules.frame_slot(it, r, 3)] = ranks[r].frame(schedules.frame_slot(it, r, 3))
+    assert seq_w3[:35] == seq_w1
+    b = schedules.FramePermutation(10, 999)
+    b.load_state_dict(a.state_dict())
+    assert [a.frame(s) for s in range(35, 60)] == [b.frame(s) for s in range(35, 60)]

@@ -1,54 +1,50 @@
-"""The shipping kernels form every fp32 product from bf16 pieces on the bf16 matrix cores; DH_ALL_F32=1 selects
-the native fp32-MFMA twin of every kernel.  Both must produce the same full-size training step: losses to 1e-6, flat
-gradient to a few 1e-6 relative (each is 3.7e-6 from the eager-fp32 oracle, tests/test_gpu_fullsize_and_runner.py).
-The switches are read once per process, so each mode runs in its own subprocess."""
-import os
-import subprocess
-import sys
-
+"""The shipping kernels form every fp32 product from bf16 pieces on the bf16 matrix cores;
+dh_set_arithmetic(DH_ARITH_FP32_MFMA) selects the native fp32-MFMA twin of every kernel.  Both must produce the same
+full-size training step: losses to 5e-6, flat gradient to 1e-5 relative (each is 3.7e-6 from the eager-fp32 oracle,
+tests/test_gpu_fullsize_and_runner.py).  Every arithmetic mode the ABI can select is exercised here."""
 import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-
-SCRIPT = r"""
-import sys, torch
-sys.path.insert(0, {root!r})
-from dynhor_amd.runner import Runner
-conf = {{"seq_name": "t", "exp_name": "modes", "data_info": {{"synthetic": {{"n_frames": 4, "H": 128, "W": 128, "seed": 11}}}},
-        "train": {{"batch_size": 2048, "normal_weight": 0.05, "report_freq": 10 ** 9, "save_freq": 10 ** 9, "val_freq": 0}}}}
-r = Runner(conf=conf, device="cuda:0", exp_root={exp!r})
-g = torch.Generator(device="cuda:0"); g.manual_seed(5)
-rays = r.dataset.gen_random_rays_at(1, 2048, generator=g)
-near, far = r.dataset._last_near_far
-t_rand = torch.rand(2048, 1, device="cuda:0", generator=g)
-stats = r.renderer.train_step_core(rays, near, far, r.dataset.R[1], 0.3, 0.1, 0.1, 0.05, t_rand=t_rand)
-torch.cuda.synchronize()
-torch.save({{"stats": stats.cpu(), "grad": r.store.grad_flat.cpu()}}, {out!r})
-"""
-
-
-def _run(tmp_path, name, env_extra):
-    out = str(tmp_path / (name + ".pt"))
-    env = dict(os.environ)
-    for k in ("DH_ALL_F32", "DH_CHAIN_PIECES"):
-        env.pop(k, None)
-    env.update(env_extra)
-    code = SCRIPT.format(root=ROOT, exp=str(tmp_path / name), out=out)
-    p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=280)
-    assert p.returncode == 0, p.stderr[-2000:]
-    return torch.load(out)
-
 
 def test_split_bf16_and_fp32_mfma_kernels_agree(tmp_path):
-    a = _run(tmp_path, "split", {})
-    b = _run(tmp_path, "f32", {"DH_ALL_F32": "1"})
-    c = _run(tmp_path, "pieces", {"DH_CHAIN_PIECES": "1"})       # every chain in its piece-plane form
-    for name, other in (("fp32-MFMA", b), ("piece-plane", c)):
-        ds = (a["stats"][:6] - other["stats"][:6]).abs().max().item()
-        rel = ((a["grad"].double() - other["grad"].double()).norm() / other["grad"].double().norm()).item()
-        print(f"shipping kernels vs {name}: loss/stat max abs diff {ds:.2e}; flat gradient rel diff {rel:.2e}")
-        assert ds < 5e-6
-        assert rel < 1e-5
+    from dynhor_amd import _lib
+    from dynhor_amd.runner import Runner
+    conf = {"seq_name": "t", "exp_name": "modes", "data_info": {"synthetic": {"n_frames": 4, "H": 128, "W": 128, "seed": 11}},
+            "train": {"batch_size": 2048, "normal_weight": 0.05, "report_freq": 10 ** 9, "save_freq": 10 ** 9, "val_freq": 0}}
+    r = Runner(conf=conf, device="cuda:0", exp_root=str(tmp_path))
+    g = torch.Generator(device="cuda:0"); g.manual_seed(5)
+    rays = r.dataset.gen_random_rays_at(1, 2048, generator=g)
+    near, far = r.dataset._last_near_far
+    t_rand = torch.rand(2048, 1, device="cuda:0", generator=g)
+    res = {}
+    assert _lib.get_arithmetic() == _lib.ARITH_SPLIT_BF16, "split-bf16 is the default arithmetic"
+    try:
+        for mode in (_lib.ARITH_SPLIT_BF16, _lib.ARITH_FP32_MFMA):
+            _lib.set_arithmetic(mode)
+            assert _lib.get_arithmetic() == mode
+            stats = r.renderer.train_step_core(rays, near, far, r.dataset.R[1], 0.3, 0.1, 0.1, 0.05, t_rand=t_rand)
+            torch.cuda.synchronize()
+            res[mode] = (stats.clone(), r.store.grad_flat.clone(), r.renderer.last_state.z_vals.clone())
+        # a full-frame forward-only chunk in both modes (the save = 0 variants)
+        o, d = rays[:, :3].contiguous(), rays[:, 3:6].contiguous()
+        cols = {}
+        for mode in (_lib.ARITH_SPLIT_BF16, _lib.ARITH_FP32_MFMA):
+            _lib.set_arithmetic(mode)
+            st = r.renderer._forward_core(o, d, res[0][2], 0.3, None, want_nmap=True, infer_only=True)
+            cols[mode] = (st.color.clone(), st.nmap.clone())
+    finally:
+        _lib.set_arithmetic(_lib.ARITH_SPLIT_BF16)
+    with pytest.raises(_lib.DynhorHipError):
+        _lib.set_arithmetic(7)
+    a, b = res[_lib.ARITH_SPLIT_BF16], res[_lib.ARITH_FP32_MFMA]
+    ds = (a[0][:6] - b[0][:6]).abs().max().item()
+    rel = ((a[1].double() - b[1].double()).norm() / b[1].double().norm()).item()
+    dz = (a[2] - b[2]).abs()
+    print(f"split-bf16 vs fp32-MFMA: loss/stat max abs diff {ds:.2e}; flat gradient rel diff {rel:.2e}; "
+          f"sampled z: {float((dz > 1e-4).float().mean()):.2e} of samples differ by > 1e-4")
+    assert ds < 5e-6
+    assert rel < 1e-5
+    assert float((dz > 1e-4).float().mean()) < 2e-3        # ill-conditioned inverse-CDF samples only
+    assert (cols[0][0] - cols[1][0]).abs().max().item() < 2e-5 and (cols[0][1] - cols[1][1]).abs().max().item() < 2e-4
