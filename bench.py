@@ -1,9 +1,14 @@
 """bench.py -- training rays/s of the NeuS reconstruction hot path on N MI355X (contract in the task brief).
 
 One "step" = one full training iteration on 2048 rays x (64 coarse + 64 importance) samples of a synthetic 512x512
-sequence (BASELINE.json configs[1], SURVEY.md §8 cfg2): HIP ray gather -> hierarchical up-sampling -> SDF/colour MLPs
+sequence (BASELINE.json configs[1], SURVEY.md section 8 cfg2): HIP ray gather -> hierarchical up-sampling -> SDF/colour MLPs
 -> volume rendering -> losses -> backward -> (N>1: RCCL all-reduce of the flat gradient) -> fused Adam.  Frames shard
 data-parallel over ranks (weak scaling: 2048 rays per rank).  Prints ONE JSON line on rank 0.
+
+    python bench.py                          # cfg2, N = 1 (the driver's default run)
+    python bench.py --family hash            # BASELINE.json configs[3]: hash-grid encoding + shallow MLPs, same batch
+    python bench.py --arithmetic fp32_mfma   # every GEMM on native fp32 MFMA (the second arithmetic, 1.34x slower)
+    python bench.py --psnr --psnr-seeds 2    # adds "psnr_at_2k": HIP vs oracle at equal iterations (minutes per seed)
 """
 import argparse
 import json
@@ -25,37 +30,63 @@ MACS = {
 }
 FP32_MFMA_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md, Chip-level parameters
 BF16_MFMA_PEAK_TFLOPS = 2500.0     # same table: bf16 dense
-FLOP_PER_RAY_TRAIN = 1081270272    # SURVEY.md §8(d)
+HBM_PEAK_GBPS = 8000.0             # same table: HBM3E spec
+FLOP_PER_RAY_TRAIN = 1081270272    # SURVEY.md section 8(d)
 
 
-def cpu_baseline(n_rays, n_samples, n_importance):
-    """The oracle (PyTorch restatement, oracle/) timed on the host cores: 1 warm-up + 2 timed training iterations on a
-    bounded sample of the same workload (n_rays rays x 128 samples)."""
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(rays, R, n_samples, n_importance, normal_weight):
+    """The oracle (PyTorch restatement, oracle/ -- the CHECKER, timed here as the reported CPU baseline only) on the host
+    cores: one warm-up + two timed full training iterations on the SAME rays the GPU path trains on (one 2048-ray batch of
+    the synthetic sequence).  The thread count is chosen by a short calibration (the GPU boxes advertise far more logical
+    CPUs than an eager-PyTorch run of this size can use: 256 threads ran >100x slower than 8)."""
     from oracle import neus_oracle as O
-    # the GPU box advertises far more logical CPUs than a PyTorch-CPU run of this size can use (256 threads ran
-    # >100x slower than 8); use the cores this process may run on, capped at 8
     try:
         ncpu = len(os.sched_getaffinity(0))
     except AttributeError:
-        ncpu = os.cpu_count()
-    torch.set_num_threads(max(1, min(8, ncpu)))
-    sdf, col, var = O.build_models(seed=1234, device="cpu")
-    r = O.NeuSRenderer(None, sdf, var, col, n_samples, n_importance, 0, 4, 1.0)
-    opt = torch.optim.Adam(list(sdf.parameters()) + list(var.parameters()) + list(col.parameters()), lr=5e-4)
+        ncpu = os.cpu_count() or 1
+    rays, R = rays.detach().cpu(), R.detach().cpu()
     g = torch.Generator().manual_seed(0)
-    o = torch.nn.functional.normalize(torch.randn(n_rays, 3, generator=g), dim=-1) * 2.3
-    d = torch.nn.functional.normalize((torch.rand(n_rays, 3, generator=g) - 0.5) * 0.8 - o, dim=-1)
-    rays = torch.cat([o, d, torch.rand(n_rays, 3, generator=g), (torch.rand(n_rays, 1, generator=g) > 0.5).float(),
-                      torch.ones(n_rays, 1), torch.nn.functional.normalize(torch.randn(n_rays, 3, generator=g), dim=-1)], -1)
-    times = []
-    for it in range(3):
+    t_rand = torch.rand(rays.shape[0], 1, generator=g)
+
+    def build():
+        sdf, col, var = O.build_models(seed=1234, device="cpu")
+        r = O.NeuSRenderer(None, sdf, var, col, n_samples, n_importance, 0, 4, 1.0)
+        opt = torch.optim.Adam(list(sdf.parameters()) + list(var.parameters()) + list(col.parameters()), lr=5e-4)
+        return r, opt
+
+    calib = {}
+    for nt in sorted({t for t in (4, 8, 16, 32, 64) if t <= ncpu} or {1}):
+        torch.set_num_threads(nt)
+        r, opt = build()
+        O.train_step(r, opt, rays[:64], 0.5, 0.1, 0.1, normal_weight, R=R, t_rand=t_rand[:64])
         t0 = time.perf_counter()
-        O.train_step(r, opt, rays, 0.5)
+        O.train_step(r, opt, rays[:128], 0.5, 0.1, 0.1, normal_weight, R=R, t_rand=t_rand[:128])
+        calib[nt] = time.perf_counter() - t0
+    best = min(calib, key=calib.get)
+    torch.set_num_threads(best)
+    r, opt = build()
+    times = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        O.train_step(r, opt, rays, 0.5, 0.1, 0.1, normal_weight, R=R, t_rand=t_rand)
         times.append(time.perf_counter() - t0)
     dt = sum(times[1:]) / 2
-    return {"value": n_rays / dt, "unit": "rays/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{n_rays} rays x {n_samples}+{n_importance} samples, full training iteration (render, losses, "
-                      f"backward, Adam), 1 warm-up + 2 timed, fp32, {dt:.2f} s/iter"}
+    n = rays.shape[0]
+    return {"value": n / dt, "unit": "rays/s", "cores": torch.get_num_threads(), "kind": "port",
+            "host": {"os_cpu_count": os.cpu_count(), "affinity": ncpu, "model": _cpu_model(),
+                     "thread_calibration_s_per_128_rays": {str(k): round(v, 3) for k, v in calib.items()}},
+            "sample": f"{n} rays x {n_samples}+{n_importance} samples of one synthetic frame (the GPU path's own batch), full "
+                      f"training iteration (render, losses, backward, Adam), 1 warm-up + 2 timed, fp32, {dt:.2f} s/iter"}
 
 
 def main():
@@ -64,10 +95,16 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--frames", type=int, default=64)
+    ap.add_argument("--family", choices=["neus", "hash"], default="neus",
+                    help="neus = BASELINE.json configs[1] (the headline); hash = configs[3] (hash-grid encoding + shallow MLPs)")
+    ap.add_argument("--arithmetic", choices=["split_bf16", "fp32_mfma"], default="split_bf16")
     ap.add_argument("--rays-per-rank", type=int, default=2048,
                     help="2048 = throughput mode (weak scaling, the headline); 2048/N = fixed global batch (PSNR-parity mode)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-rays", type=int, default=512)
+    ap.add_argument("--cpu-rays", type=int, default=2048)
+    ap.add_argument("--psnr", action="store_true", help="add psnr_at_2k: HIP path vs oracle at equal iterations (scripts/psnr_parity.py)")
+    ap.add_argument("--psnr-seeds", type=int, default=2)
+    ap.add_argument("--psnr-iters", type=int, default=2000)
     ap.add_argument("--backend", type=str, default="nccl", help="torch.distributed backend (nccl == RCCL; gloo for tests)")
     ap.add_argument("--share-gpu", action="store_true", help="TEST ONLY: every rank uses cuda:0 (with --backend gloo)")
     ap.add_argument("--check-sync", action="store_true", help="verify all ranks hold identical parameters at the end")
@@ -91,11 +128,16 @@ def main():
     device = torch.device(f"cuda:{local_rank}")
     torch.cuda.set_device(device)
 
+    from dynhor_amd import _lib
     from dynhor_amd.runner import Runner
+    arith = _lib.ARITH_FP32_MFMA if args.arithmetic == "fp32_mfma" else _lib.ARITH_SPLIT_BF16
+    _lib.set_arithmetic(arith)
+    hash_family = args.family == "hash"
     conf = {"seq_name": "bench_synth", "exp_name": f"r{rank}",
             "data_info": {"synthetic": {"n_frames": args.frames, "H": 512, "W": 512, "seed": 4321}},
             "train": {"batch_size": args.rays_per_rank, "normal_weight": 0.05, "report_freq": 10 ** 9, "save_freq": 10 ** 9,
-                      "val_freq": 0}}
+                      "val_freq": 0},
+            "model": {"family": args.family}}
     runner = Runner(conf=conf, device=device, exp_root=os.path.join("/tmp", "dynhor_bench_exps"))
     B = runner.batch_size
     n_samples = runner.renderer.n_samples + runner.renderer.n_importance
@@ -122,6 +164,33 @@ def main():
         dt = float(t.item())
     runner.renderer.timer.enabled = False
     kern = runner.renderer.timer.summary()
+
+    comm = None
+    if use_dist:
+        # self-diagnosis for the first real multi-GPU run: what the process group reports, and the cost of the one collective
+        # on this path in isolation (the flat gradient bucket; 20 back-to-back all-reduces, HIP events)
+        g = runner.store.grad_flat.clone()
+        for _ in range(3):
+            dist.all_reduce(g)
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(20):
+            dist.all_reduce(g)
+        b.record()
+        torch.cuda.synchronize()
+        ar_ms = a.elapsed_time(b) / 20
+        t = torch.tensor([ar_ms], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        nccl_ver = None
+        try:
+            nccl_ver = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception:
+            pass
+        comm = {"backend": dist.get_backend(), "nranks": dist.get_world_size(), "rccl_version": nccl_ver,
+                "bucket_bytes": g.numel() * 4, "allreduce_only_ms": round(float(t.item()), 4),
+                "allreduce_frac_of_step": round(float(t.item()) / (dt / args.steps * 1e3), 4),
+                "collectives_per_step": 1}
     if args.check_sync and world > 1:
         ref = runner.store.flat.clone()
         dist.broadcast(ref, src=0)
@@ -143,58 +212,98 @@ def main():
                "sdf_nograd_fine": B * (runner.renderer.n_importance // max(runner.renderer.up_sample_steps, 1))}
         per_kernel = {}
         for k, (mean_ms, cnt) in kern.items():
-            if k not in MACS:
-                per_kernel[k] = {"ms": round(mean_ms, 4), "launches_per_step": cnt / args.steps}
-                continue
-            npts = pts.get(k, P)
-            tf = 2.0 * MACS[k] * npts / (mean_ms * 1e-3) / 1e12
-            per_kernel[k] = {"ms": round(mean_ms, 4), "launches_per_step": cnt / args.steps, "tflops": round(tf, 2)}
-        dom = max((k for k in per_kernel if per_kernel[k]["launches_per_step"] <= 1.01 and "tflops" in per_kernel[k]),
-                  key=lambda k: per_kernel[k]["ms"])
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tpath):
-            traffic = json.load(open(tpath)).get(dom, {}).get("hbm_bytes_per_launch")
-        all_f32 = os.environ.get("DH_ALL_F32") is not None        # every GEMM on native fp32 MFMA (the A/B twins)
-        dw_f32 = all_f32 or os.environ.get("DH_DW_F32") is not None or os.environ.get("DH_DW_REGS") is not None
-        if all_f32:
-            hip_names = {"weight_grads_gemm": "dw_lds_kernel", "sdf_forward": "sdf_fwd_train_kernel",
-                         "sdf_gradient": "sdf_grad_kernel", "color_forward": "color_fwd_kernel",
-                         "color_backward": "color_bwd_kernel", "sdf_tangent": "sdf_tangent_kernel",
-                         "sdf_backward": "sdf_bwd_kernel", "sdf_nograd_coarse": "sdf_nograd_kernel"}
+            per_kernel[k] = {"ms": round(mean_ms, 4), "launches_per_step": cnt / args.steps}
+            if k in MACS and not hash_family:
+                npts = pts.get(k, P)
+                per_kernel[k]["tflops"] = round(2.0 * MACS[k] * npts / (mean_ms * 1e-3) / 1e12, 2)
+        traffic_path = os.path.join(ROOT, "profiles", "pmc_traffic_hash.json" if hash_family else "pmc_traffic.json")
+        traffic_table = json.load(open(traffic_path)) if os.path.exists(traffic_path) else {}
+
+        def offline_traffic(stage, kernel):
+            """HBM bytes per launch from the committed rocprofv3 PMC passes -- only if they were taken on THIS kernel."""
+            e = traffic_table.get(stage)
+            if e and e.get("kernel") == kernel:
+                return e.get("hbm_bytes_per_launch"), f"profiles/{os.path.basename(traffic_path)} (offline rocprofv3 PMC passes: FETCH_SIZE x2 + WRITE_SIZE)"
+            return None, None
+
+        if hash_family:
+            # dominant stage of this family: dh_hash_weight_grads (table-gradient scatter + the five small dW reductions), HBM /
+            # memory-side-atomic bound.  Algorithmic bytes per launch = every add the per-evaluation scatter defines (7
+            # evaluations x 16 levels x 8 corners x 2 features x 4 B per sample) + one read of the dW operands.
+            dom = "hash_weight_grads"
+            add_bytes = 7 * P * 16 * 8 * 2 * 4
+            dw_bytes = 7 * P * (64 + 36 + 13 + 64) * 4 + P * (64 + 32 + 64 + 64 + 3 + 64) * 4
+            tsec = per_kernel[dom]["ms"] * 1e-3
+            kernel = _lib.HASH_STAGE_KERNELS[dom]
+            traffic, tsrc = offline_traffic(dom, kernel)
+            roof = {"bound": "hbm", "kernel": kernel + " (+ small_dw_kernel, reductions: one C-ABI stage)", "stage": dom,
+                    "achieved": round((add_bytes + dw_bytes) / tsec / 1e9, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                    "frac": round((add_bytes + dw_bytes) / tsec / 1e9 / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": tsrc,
+                    "avg_launch_ms": per_kernel[dom]["ms"],
+                    "algorithmic_bytes": {"scatter_adds": add_bytes, "dw_operands": dw_bytes},
+                    "memory_side_float_atomic_peak_GBps": 1300.0}
+            workload = (f"instant-nsr-pl-shaped hash-grid family (BASELINE.json configs[3]): 16-level x 2-feature hash grid (T = 2^19) + "
+                        f"1x64 geometry MLP with finite-difference normals + SH-4 2x64 colour MLP, custom_shoes-shaped synthetic seq, "
+                        f"512x512, {B} rays x (64+64) samples per rank, full training iteration")
+            arithmetic = "fp32 everywhere (VALU / fp32 MFMA for the small dW GEMMs); table gradient by float atomics"
         else:
-            hip_names = {"weight_grads_gemm": "dw_lds_kernel" if dw_f32 else "dw_bf16x3_kernel", "sdf_forward": "sdf_fwd_train_s_kernel",
-                         "sdf_gradient": "sdf_grad16_kernel", "color_forward": "color_fwd_s_kernel",
-                         "color_backward": "color_bwd16_kernel", "sdf_tangent": "sdf_tangent_s_kernel",
-                         "sdf_backward": "sdf_bwd_s_kernel", "sdf_nograd_coarse": "sdf_nograd_s_kernel"}
-        # peak of the dominant kernel's own instruction mix: every GEMM runs each fp32 product as 6 bf16 products (3-way
-        # split of both operands, fp32 accumulate: 2^-24 relative) on v_mfma_f32_32x32x16_bf16, so the ceiling in ALGORITHMIC
-        # (fp32-product) FLOP/s is the dense bf16 peak / 6; DH_ALL_F32 runs v_mfma_f32_32x32x2_f32 (157.3 TFLOP/s)
-        split = not (all_f32 or (dom == "weight_grads_gemm" and dw_f32))
-        peak = BF16_MFMA_PEAK_TFLOPS / 6.0 if split else FP32_MFMA_PEAK_TFLOPS
-        roof = {"bound": "mfma", "kernel": hip_names.get(dom, dom), "stage": dom, "achieved": per_kernel[dom]["tflops"],
-                "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(per_kernel[dom]["tflops"] / peak, 4),
-                "peak_basis": ("bf16 dense MFMA 2500 TFLOP/s / 6 split products per fp32 product" if split
-                               else "fp32 MFMA v_mfma_f32_32x32x2_f32"),
-                "frac_of_fp32_mfma_peak": round(per_kernel[dom]["tflops"] / FP32_MFMA_PEAK_TFLOPS, 4),
-                "traffic": traffic, "avg_launch_ms": per_kernel[dom]["ms"],
-                "whole_step_tflops": round(value / world * FLOP_PER_RAY_TRAIN / 1e12, 2),
-                "whole_step_frac_of_split_bf16_peak": round(value / world * FLOP_PER_RAY_TRAIN / 1e12 / (BF16_MFMA_PEAK_TFLOPS / 6.0), 4),
-                "whole_step_frac_of_fp32_mfma_peak": round(value / world * FLOP_PER_RAY_TRAIN / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4)}
+            names = _lib.STAGE_KERNELS[arith]
+            dom = max((k for k in per_kernel if per_kernel[k]["launches_per_step"] <= 1.01 and "tflops" in per_kernel[k]),
+                      key=lambda k: per_kernel[k]["ms"])
+            # peak of the dominant kernel's own instruction mix: every GEMM runs each fp32 product as 6 bf16 products (3-way
+            # split of both operands, fp32 accumulate: 2^-24 relative) on v_mfma_f32_32x32x16_bf16, so the ceiling in
+            # ALGORITHMIC (fp32-product) FLOP/s is the dense bf16 peak / 6; fp32_mfma runs v_mfma_f32_32x32x2_f32 (157.3 TFLOP/s)
+            split = arith == _lib.ARITH_SPLIT_BF16
+            peak = BF16_MFMA_PEAK_TFLOPS / 6.0 if split else FP32_MFMA_PEAK_TFLOPS
+            traffic, tsrc = offline_traffic(dom, names[dom])
+            roof = {"bound": "mfma", "kernel": names[dom], "stage": dom, "achieved": per_kernel[dom]["tflops"],
+                    "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(per_kernel[dom]["tflops"] / peak, 4),
+                    "peak_basis": ("bf16 dense MFMA 2500 TFLOP/s / 6 split products per fp32 product" if split
+                                   else "fp32 MFMA v_mfma_f32_32x32x2_f32"),
+                    "frac_of_fp32_mfma_peak": round(per_kernel[dom]["tflops"] / FP32_MFMA_PEAK_TFLOPS, 4),
+                    "traffic": traffic, "traffic_source": tsrc, "avg_launch_ms": per_kernel[dom]["ms"],
+                    "whole_step_tflops": round(value / world * FLOP_PER_RAY_TRAIN / 1e12, 2),
+                    "whole_step_frac_of_split_bf16_peak": round(value / world * FLOP_PER_RAY_TRAIN / 1e12 / (BF16_MFMA_PEAK_TFLOPS / 6.0), 4),
+                    "whole_step_frac_of_fp32_mfma_peak": round(value / world * FLOP_PER_RAY_TRAIN / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4)}
+            for k, v in per_kernel.items():
+                if "tflops" in v:
+                    v["kernel"] = names.get(k)
+                    v["frac_of_peak"] = round(v["tflops"] / peak, 4)
+            workload = (f"custom_shoes-shaped synthetic seq, 512x512, {B} rays x (64+64) samples per rank, "
+                        "NeuS SDF(8x256, skip 4, softplus100) + colour(4x256) MLP, full training iteration")
+            arithmetic = ("fp32 everywhere, every GEMM on v_mfma_f32_32x32x2_f32 (--arithmetic fp32_mfma)" if not split else
+                          "fp32 in / fp32 out everywhere; GEMMs as 3-way bf16 split of both operands (6 MFMA "
+                          "products, fp32 accumulate: 2^-24 relative = fp32 accuracy)")
         out = {"metric": "training rays/sec", "value": round(value, 1), "unit": "rays/s", "n_gpus": world,
                "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
                "scaling": "weak" if args.rays_per_rank == 2048 else "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-               "config": {"workload": "custom_shoes-shaped synthetic seq, 512x512, 2048 rays x (64+64) samples per rank, "
-                                      "NeuS SDF(8x256, skip 4, softplus100) + colour(4x256) MLP, full training iteration",
-                          "frames": args.frames, "rays_per_rank": B, "samples_per_ray": n_samples,
-                          "parallelism": f"dp{world}", "loss": "rgb L1 + 0.1 eikonal + 0.1 mask BCE + 0.05 mono-normal",
-                          "arithmetic": ("fp32 everywhere, every GEMM on v_mfma_f32_32x32x2_f32 (DH_ALL_F32)" if all_f32 else
-                                         "fp32 in / fp32 out everywhere; GEMMs as 3-way bf16 split of both operands (6 MFMA "
-                                         "products, fp32 accumulate: 2^-24 relative = fp32 accuracy)")},
+               "config": {"workload": workload, "family": args.family, "frames": args.frames, "rays_per_rank": B,
+                          "samples_per_ray": n_samples, "parallelism": f"dp{world}",
+                          "loss": "rgb L1 + 0.1 eikonal + 0.1 mask BCE + 0.05 mono-normal", "arithmetic": arithmetic},
                "roofline": roof, "kernels": per_kernel,
                "final_stats": {"loss": round(float(stats[0]), 5), "psnr": round(float(stats[5]), 3)}}
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.cpu_rays, runner.renderer.n_samples, runner.renderer.n_importance)
+        if comm is not None:
+            out["comm"] = comm
+        if world == 1 and not args.no_cpu_baseline and not hash_family:
+            frame = int(runner.image_perm[0])
+            g = torch.Generator(device=device); g.manual_seed(99)
+            rays = runner.dataset.gen_random_rays_at(frame, args.cpu_rays, generator=g)
+            out["cpu_baseline"] = cpu_baseline(rays, runner.dataset.R[frame], runner.renderer.n_samples,
+                                               runner.renderer.n_importance, runner.normal_weight)
+        if args.psnr and world == 1:
+            # the oracle is the checker here (never the thing measured): PSNR of both arms on all frames at equal iterations
+            sys.path.insert(0, os.path.join(ROOT, "scripts"))
+            import psnr_parity
+            psnr_parity.LOG = sys.stderr          # this program prints ONE JSON line on stdout
+            seeds = ",".join(str(11 * (i + 1)) for i in range(args.psnr_seeds))
+            res = psnr_parity.run_parity(["--mode", "hip_vs_oracle", "--family", args.family, "--seeds", seeds,
+                                          "--iters", str(args.psnr_iters)])
+            w = res["window_delta"]
+            out["psnr_at_2k"] = {"hip": round(res["window_mean_a"], 3), "oracle": round(res["window_mean_b"], 3),
+                                 "delta": round(w["mean_db"], 4), "se": None if w["n"] < 2 else round(w["se_db"], 4),
+                                 "seeds": w["n"], "per_seed_delta": [round(x, 4) for x in w["per_seed"]],
+                                 "iters": res["iters"], "protocol": res["protocol"],
+                                 "committed_runs": "profiles/psnr_parity_r02*.json (8 seeds per family + noise floors)"}
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.barrier()

@@ -85,6 +85,23 @@ def lib():
 
 ARITH_SPLIT_BF16, ARITH_FP32_MFMA = 0, 1
 
+# stage (StageTimer / bench.py name) -> HIP kernel that runs it, per arithmetic mode.  bench.py's roofline block and
+# scripts/make_traffic_json.py (rocprofv3 PMC -> HBM bytes per launch) both read THIS table, so a renamed or removed kernel
+# cannot leave a stale entry behind.
+STAGE_KERNELS = {
+    ARITH_SPLIT_BF16: {"weight_grads_gemm": "dw_bf16x3_kernel", "sdf_forward": "sdf_fwd_train_s_kernel",
+                       "sdf_gradient": "sdf_grad16_kernel", "color_forward": "color_fwd_s_kernel",
+                       "color_backward": "color_bwd16_kernel", "sdf_tangent": "sdf_tangent_s_kernel",
+                       "sdf_backward": "sdf_bwd_s_kernel", "sdf_nograd_coarse": "sdf_nograd_s_kernel",
+                       "sdf_nograd_fine": "sdf_nograd_s_kernel"},
+    ARITH_FP32_MFMA: {"weight_grads_gemm": "dw_lds_kernel", "sdf_forward": "sdf_fwd_train_kernel",
+                      "sdf_gradient": "sdf_grad_kernel", "color_forward": "color_fwd_kernel",
+                      "color_backward": "color_bwd_kernel", "sdf_tangent": "sdf_tangent_kernel",
+                      "sdf_backward": "sdf_bwd_kernel", "sdf_nograd_coarse": "sdf_nograd_kernel",
+                      "sdf_nograd_fine": "sdf_nograd_kernel"},
+}
+HASH_STAGE_KERNELS = {"hash_weight_grads": "hash_table_bwd_kernel"}
+
 
 def set_arithmetic(mode: int):
     """dh_set_arithmetic: 0 = split-bf16 kernels (shipping), 1 = native fp32-MFMA twins.  Process-wide."""

@@ -6,6 +6,9 @@
 #include "kernels.h"
 #include "mlp_common.h"
 #include "tile16.h"
+#include "stamps.h"
+
+DH_STAMP_READER(dh_dev_read_stamps_fwd)
 
 namespace dh {
 
@@ -329,38 +332,66 @@ __global__ __launch_bounds__(256, TM == 128 ? 1 : 2) void sdf_nograd_s_kernel(Sd
     }
 }
 
-// K2a, split-on-fetch
-__global__ __launch_bounds__(256, TM == 128 ? 1 : 2) void sdf_fwd_train_s_kernel(Sdf16Ptrs P, const float* __restrict__ pts, int64_t npts,
+// K2a, split-on-fetch.  TEAMS = 1: one 64-point tile per 4-wave workgroup, two workgroups per CU (independent phases).
+// TEAMS = 2: one 8-wave workgroup per CU whose two 4-wave teams run the same layer on two tiles in lockstep, so each B
+// fragment is fetched from L2 once per CU (the second team's load hits L1).  TRICKLE = 1: the activation tile is saved from
+// the LDS image under the NEXT layer's MFMAs (TileTrickle) instead of as a 16-store burst after the epilogue.
+template <int TEAMS, int TRICKLE>
+__global__ __launch_bounds__(256 * TEAMS, 2) void sdf_fwd_train_s_kernel(Sdf16Ptrs P, const float* __restrict__ pts, int64_t npts,
                                                                 float* __restrict__ sdf_out, float* __restrict__ feat,
                                                                 float* __restrict__ act, float* __restrict__ eaux) {
-    __shared__ __attribute__((aligned(16))) float smain[TM * LDX];
-    __shared__ __attribute__((aligned(16))) float saux[TM * LDA];
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    __shared__ __attribute__((aligned(16))) float smain_all[TEAMS * TM * LDX];
+    __shared__ __attribute__((aligned(16))) float saux_all[TEAMS * TM * LDA];
+    const int team = threadIdx.x >> 8, tid = threadIdx.x & 255, wave = tid >> 6, lane = tid & 63;
+    float* smain = smain_all + team * TM * LDX;
+    float* saux = saux_all + team * TM * LDA;
     const int64_t ntiles = (npts + TM - 1) / TM;
-    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    int it = 0;
+    for (int64_t tile0 = (int64_t)blockIdx.x * TEAMS; tile0 < ntiles; tile0 += (int64_t)gridDim.x * TEAMS, ++it) {
+        const int64_t tile = tile0 + team;
+        const bool tv = tile < ntiles;                      // an odd tile count leaves the last workgroup's second team idle
         embed_tile(pts, tile * TM, npts, saux, tid);
         __syncthreads();
-        aux_lds_to_native(saux, eaux + tile * AUXT_F, wave, lane);
+        if (tv) aux_lds_to_native(saux, eaux + tile * AUXT_F, wave, lane);
         f32x16 acc[MT][2];
+        const size_t woff = (size_t)wave * MT * 8 * 64 + lane;
         for (int l = 0; l < 8; ++l) {
+            DH_STAMP(it, l, 0);
             acc_zero(acc);
-            if (l > 0) gemm_rows_s(acc, smain, LDX, l == 4 ? 14 : 16, P.main16[l], wave, lane);
-            if (l == 0 || l == 4) gemm_rows_s(acc, saux, LDA, AUX_KC, P.aux16[l], wave, lane);
+            if (TRICKLE && l > 0 && tv) {
+                TileTrickle tr{smain, reinterpret_cast<f32x4*>(act + ((int64_t)(l - 1) * ntiles + tile) * TILE_F) + woff, wave, lane, 0};
+                gemm_rows_s(acc, smain, LDX, l == 4 ? 14 : 16, P.main16[l], wave, lane, tr);
+                if (l == 4) { tr.j0 = 14; gemm_rows_s(acc, saux, LDA, AUX_KC, P.aux16[l], wave, lane, tr); }
+            } else {
+                if (l > 0) gemm_rows_s(acc, smain, LDX, l == 4 ? 14 : 16, P.main16[l], wave, lane);
+                if (l == 0 || l == 4) gemm_rows_s(acc, saux, LDA, AUX_KC, P.aux16[l], wave, lane);
+            }
+            DH_STAMP(it, l, 1);
             const float b0 = P.bias[l][acc_col(wave, 0, lane)], b1 = P.bias[l][acc_col(wave, 1, lane)];
             acc_map(acc, [&](int, int t, int, float v) { return softplus100(v + (t ? b1 : b0)); });
-            acc_store_native(acc, act + ((int64_t)l * ntiles + tile) * TILE_F, wave, lane);
+            DH_STAMP(it, l, 2);
+            if (!TRICKLE && tv) acc_store_native(acc, act + ((int64_t)l * ntiles + tile) * TILE_F, wave, lane);
+            DH_STAMP(it, l, 3);
             __syncthreads();
+            DH_STAMP(it, l, 4);
             acc_to_lds(acc, smain, wave, lane);
+            DH_STAMP(it, l, 5);
             __syncthreads();
+            DH_STAMP(it, l, 6);
         }
         const float s = row_dot256(smain, P.w8row0, tid) + P.b8_0[0];
         const int64_t gp = tile * TM + tid / TPP;
         if (tid % TPP == 0 && gp < npts) sdf_out[gp] = s;
         acc_zero(acc);
-        gemm_rows_s(acc, smain, LDX, 16, P.main16[8], wave, lane);
+        if (TRICKLE && tv) {
+            TileTrickle tr{smain, reinterpret_cast<f32x4*>(act + ((int64_t)7 * ntiles + tile) * TILE_F) + woff, wave, lane, 0};
+            gemm_rows_s(acc, smain, LDX, 16, P.main16[8], wave, lane, tr);
+        } else {
+            gemm_rows_s(acc, smain, LDX, 16, P.main16[8], wave, lane);
+        }
         const float b0 = P.bias[8][acc_col(wave, 0, lane)], b1 = P.bias[8][acc_col(wave, 1, lane)];
         acc_map(acc, [&](int, int t, int, float v) { return v + (t ? b1 : b0); });
-        acc_store_native(acc, feat + tile * TILE_F, wave, lane);
+        if (tv) acc_store_native(acc, feat + tile * TILE_F, wave, lane);
         __syncthreads();
     }
 }
@@ -432,7 +463,17 @@ int launch_sdf_fwd_train(const float* packed, const float* pts, int64_t npts, fl
                          float* eaux, int grid, hipStream_t stream) {
     const int g = grid_for(npts, grid);
     if (arith_fp32()) hipLaunchKernelGGL(sdf_fwd_train_kernel, dim3(g), dim3(256), 0, stream, make_sdf_ptrs(packed), pts, npts, sdf, feat, act, eaux);
-    else hipLaunchKernelGGL(sdf_fwd_train_s_kernel, dim3(g), dim3(256), 0, stream, make_sdf16_ptrs(packed), pts, npts, sdf, feat, act, eaux);
+    else {
+        const int64_t ntiles = (npts + TM - 1) / TM;
+        const int g2 = (int)(((ntiles + 1) / 2) < 256 ? ((ntiles + 1) / 2) : 256);
+        const Sdf16Ptrs P = make_sdf16_ptrs(packed);
+        switch (dev_variant(1)) {       // A/B (scripts/ab_stage.py): 0 shipping
+            case 1: hipLaunchKernelGGL((sdf_fwd_train_s_kernel<1, 1>), dim3(g), dim3(256), 0, stream, P, pts, npts, sdf, feat, act, eaux); break;
+            case 2: hipLaunchKernelGGL((sdf_fwd_train_s_kernel<2, 0>), dim3(g2), dim3(512), 0, stream, P, pts, npts, sdf, feat, act, eaux); break;
+            case 3: hipLaunchKernelGGL((sdf_fwd_train_s_kernel<2, 1>), dim3(g2), dim3(512), 0, stream, P, pts, npts, sdf, feat, act, eaux); break;
+            default: hipLaunchKernelGGL((sdf_fwd_train_s_kernel<1, 0>), dim3(g), dim3(256), 0, stream, P, pts, npts, sdf, feat, act, eaux); break;
+        }
+    }
     return ok();
 }
 int launch_sdf_grad(const float* packed, const float* pts, int64_t npts, const float* act, float* asave, float* normals,

@@ -11,6 +11,9 @@
 #include "kernels.h"
 #include "mlp_common.h"
 #include "workspace.h"
+#include "stamps.h"
+
+DH_STAMP_READER(dh_dev_read_stamps_bwd)
 
 namespace dh {
 
@@ -377,7 +380,8 @@ __global__ __launch_bounds__(256, TM == 128 ? 1 : 2) void sdf_tangent_s_kernel(S
     __shared__ __attribute__((aligned(16))) float saux[TM * LDA];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int64_t ntiles = (npts + TM - 1) / TM;
-    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    int it = 0;
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x, ++it) {
         float* tp = tpart + tile * N_TILE_PART * 256;
         {   // tt_0 = J_e(x) nbar
             const int p = tid & (TM - 1), part = tid / TM;
@@ -403,9 +407,11 @@ __global__ __launch_bounds__(256, TM == 128 ? 1 : 2) void sdf_tangent_s_kernel(S
         aux_lds_to_native(saux, t0aux + tile * AUXT_F, wave, lane);
         f32x16 acc[MT][2];
         for (int l = 0; l < 8; ++l) {
+            DH_STAMP(it, l, 0);
             acc_zero(acc);
             if (l > 0) gemm_rows_s(acc, smain, LDX, l == 4 ? 14 : 16, P.main16[l], wave, lane);
             if (l == 0 || l == 4) gemm_rows_s(acc, saux, LDA, AUX_KC, P.aux16[l], wave, lane);     // abar_l
+            DH_STAMP(it, l, 1);
             const size_t woff = (size_t)wave * MT * 8 * 64 + lane;
             const f32x4* hp = reinterpret_cast<const f32x4*>(act + ((int64_t)l * ntiles + tile) * TILE_F) + woff;
             const f32x4* ap = reinterpret_cast<const f32x4*>(asave + ((int64_t)l * ntiles + tile) * TILE_F) + woff;
@@ -426,11 +432,16 @@ __global__ __launch_bounds__(256, TM == 128 ? 1 : 2) void sdf_tangent_s_kernel(S
                     }
                 __builtin_amdgcn_sched_barrier(0);
             }
+            DH_STAMP(it, l, 2);
             if (l < 7) {
                 acc_store_native(acc, tsave + ((int64_t)l * ntiles + tile) * TILE_F, wave, lane);    // t_{l+1}
+                DH_STAMP(it, l, 3);
                 __syncthreads();
+                DH_STAMP(it, l, 4);
                 acc_to_lds(acc, smain, wave, lane);
+                DH_STAMP(it, l, 5);
                 __syncthreads();
+                DH_STAMP(it, l, 6);
             } else {
                 tile_colsum(acc, tp + TP_W8ROW0_T * 256, wave, lane);                                 // colsum t_8
             }

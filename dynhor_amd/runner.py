@@ -141,8 +141,11 @@ class Runner:
         near, far = self.dataset._last_near_far
         self._last_rays = rays
         bg = torch.ones(3, device=self.device) if self.use_white_bkgd else None
+        # the per-ray perturbation of the coarse samples comes from the SAME checkpointed stream as the pixels
+        t_rand = torch.rand([rays.shape[0], 1], device=self.device, generator=self.ray_gen) if self.renderer.perturb > 0 else None
         stats = self.renderer.train_step_core(rays, near, far, self.dataset.R[frame], self.get_cos_anneal_ratio(),
-                                              self.igr_weight, self.mask_weight, self.normal_weight, background_rgb=bg)
+                                              self.igr_weight, self.mask_weight, self.normal_weight, background_rgb=bg,
+                                              t_rand=t_rand)
         grad = self.store.grad_flat
         dh_dist.allreduce_sum_(grad)                             # RCCL over xGMI: one 3.2 MB bucket
         lr = self.current_lr()          # 0 at iter_step 0, as upstream (update_learning_rate() runs before the loop)

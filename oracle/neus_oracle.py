@@ -396,6 +396,61 @@ def neus_losses(render_out, true_rgb, obj_mask, keep_mask, igr_weight=0.1, mask_
 
 
 # ----------------------------------------------------------------------------------------------
+# Dense-correspondence reprojection loss (BASELINE.json configs[4] "DKM correspondence")
+# ----------------------------------------------------------------------------------------------
+# The reference names only the input folder (README.md:43 "correspondence_infos # dense correspondence obtained using DKM
+# for reconstruction and outlier-voting"); neither file format nor loss is released, so -- like the monocular-normal term --
+# the form below is this build's specification, parity unpinned:
+#   a match says pixel p of frame i (the ray) and pixel q = (u, v) of frame j see the same surface point, certainty c.
+#   expected ray depth   t^ = sum_k w_k m_k        (w: compositing weights, m: mid-point depths of render_core, detached)
+#   surface estimate     x  = o + t^ d              (object frame)
+#   reprojection         y  = R_j x + T_j ;  pi = (fx y0/y2 + cx, fy y1/y2 + cy)          (x_cam = R x_obj + T, run.py:166)
+#   residual             s  = || pi - q || / fx                                            (focal-normalised pixels)
+#   robust cost          rho(s) = s^2 / (2 delta) if s <= delta else s - delta/2,  delta = delta_px / fx      (Huber)
+#   L_corr = sum_r c_r v_r rho(s_r) / (sum_r c_r v_r + 1e-5),   v_r = [y2 > 1e-3]  (point in front of camera j)
+# "outlier voting" is a data-side step (vote_correspondences below): it only edits the certainties c.
+def correspondence_loss(weights, z_vals, sample_dist, rays_o, rays_d, corr, R_all, T_all, K, delta_px=4.0):
+    """corr [B,4] = (u_j, v_j, certainty, frame_j); certainty 0 marks a ray without a match.  Returns dict(loss, residual_px
+    [B] (detached), depth [B])."""
+    dists = torch.cat([z_vals[:, 1:] - z_vals[:, :-1], torch.full_like(z_vals[:, :1], sample_dist)], -1)
+    mid = (z_vals + 0.5 * dists).detach()
+    depth = (weights * mid).sum(-1)
+    x = rays_o + depth[:, None] * rays_d
+    j = corr[:, 3].long()
+    y = torch.einsum("bij,bj->bi", R_all[j], x) + T_all[j].reshape(-1, 3)
+    fx, fy, cx, cy = K[0, 0], K[1, 1], K[0, 2], K[1, 2]
+    valid = (y[:, 2] > 1e-3).to(weights.dtype)
+    y2 = torch.where(y[:, 2] > 1e-3, y[:, 2], torch.ones_like(y[:, 2]))
+    pu = fx * y[:, 0] / y2 + cx
+    pv = fy * y[:, 1] / y2 + cy
+    e2 = (pu - corr[:, 0]) ** 2 + (pv - corr[:, 1]) ** 2
+    s = torch.sqrt(e2 + 1e-24) / fx
+    delta = delta_px / fx
+    rho = torch.where(s <= delta, s * s / (2.0 * delta), s - 0.5 * delta)
+    c = corr[:, 2] * valid
+    loss = (c * rho).sum() / (c.sum() + 1e-5)
+    return {"loss": loss, "residual_px": (s * fx).detach(), "depth": depth, "valid": valid}
+
+
+def vote_correspondences(residual_px, corr, pair_id, tau_px=8.0, min_pair_inlier_ratio=0.5):
+    """Outlier voting on the certainties (returns a new certainty vector): a match votes `inlier` if its reprojection
+    residual under the current geometry is below tau_px; a frame PAIR whose inlier ratio is below min_pair_inlier_ratio is
+    voted out as a whole (wrong pose or matcher failure), and inside kept pairs the outlier matches are dropped."""
+    conf = corr[:, 2].clone()
+    has = conf > 0
+    inl = (residual_px < tau_px) & has
+    out = conf.clone()
+    for pid in torch.unique(pair_id[has]).tolist():
+        sel = has & (pair_id == pid)
+        ratio = inl[sel].float().mean()
+        if ratio < min_pair_inlier_ratio:
+            out[sel] = 0.0
+        else:
+            out[sel & ~inl] = 0.0
+    return out
+
+
+# ----------------------------------------------------------------------------------------------
 # Schedules (App. A.8)
 # ----------------------------------------------------------------------------------------------
 def lr_factor(iter_step, warm_up_end, end_iter, alpha):
@@ -422,13 +477,19 @@ def build_models(seed=1234, device="cpu", dtype=torch.float32):
 
 
 def train_step(renderer: NeuSRenderer, optimizer, rays, cos_anneal, igr_weight=0.1, mask_weight=0.1,
-               normal_weight=0.0, R=None, t_rand=None):
+               normal_weight=0.0, R=None, t_rand=None, corr_weight=0.0, corr=None, R_all=None, T_all=None, K=None,
+               corr_delta_px=4.0):
     """One full training iteration (render -> losses -> backward -> Adam); the cpu_baseline unit of work."""
     rays_o, rays_d, true_rgb = rays[:, :3], rays[:, 3:6], rays[:, 6:9]
     obj, keep, mono = rays[:, 9:10], rays[:, 10:11], rays[:, 11:14]
     near, far = near_far_from_sphere(rays_o, rays_d)
     out = renderer.render(rays_o, rays_d, near, far, cos_anneal_ratio=cos_anneal, t_rand=t_rand)
     losses = neus_losses(out, true_rgb, obj, keep, igr_weight, mask_weight, normal_weight, mono, R)
+    if corr_weight > 0.0 and corr is not None:
+        cl = correspondence_loss(out["weights"], out["z_vals"], 2.0 / renderer.n_samples, rays_o, rays_d, corr, R_all, T_all, K,
+                                 corr_delta_px)
+        losses["corr_loss"] = cl["loss"]
+        losses["loss"] = losses["loss"] + corr_weight * cl["loss"]
     optimizer.zero_grad()
     losses["loss"].backward()
     optimizer.step()

@@ -1,0 +1,173 @@
+"""Same-box A/B of single MLP stages on the benchmark's own workspace (development tool, round 2).
+
+    python scripts/ab_stage.py [--lib dynhor_amd/libdynhor_hip_noslp.so] [--dw-variants 0,1,2,3,4] [--reps 20]
+
+Runs a few real training iterations of the bench configuration (2048 rays x 64+64 samples) so that the saved tiles hold real
+data, then re-launches individual C-ABI stages on that workspace, interleaved A/B/A/B, timed with HIP events on the launch
+stream.  Re-launching is idempotent: every stage reads tiles an earlier stage wrote and overwrites its own outputs.
+Also prints the flat gradient's relative difference between variants (must be ~1e-7: same arithmetic, different schedule).
+"""
+import argparse, ctypes, json, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--lib", type=str, default=None)
+    ap.add_argument("--dw-variants", type=str, default="0")
+    ap.add_argument("--reps", type=int, default=20)
+    ap.add_argument("--stage-variants", type=str, default="",
+                    help="dev_variant key:stage:v0,v1,... triples separated by ';', e.g. '1:sdf_forward:0,1,2,3'")
+    ap.add_argument("--out", type=str, default=None)
+    ap.add_argument("--stamps", action="store_true", help="the library is a -DDH_STAMPS build: dump per-phase cycle stamps")
+    args = ap.parse_args()
+    from dynhor_amd import _lib
+    if args.lib:
+        _lib.LIB_PATH = os.path.join(ROOT, args.lib)
+    import torch
+    from dynhor_amd.runner import Runner
+    from dynhor_amd.renderer import _p
+    L = _lib.lib()
+    try:
+        L.dh_dev_variant.restype = ctypes.c_int
+        L.dh_dev_variant.argtypes = [ctypes.c_int, ctypes.c_int]
+        have_dev = True
+    except AttributeError:
+        have_dev = False
+    conf = {"seq_name": "ab", "exp_name": "ab", "data_info": {"synthetic": {"n_frames": 8, "H": 512, "W": 512, "seed": 4321}},
+            "train": {"batch_size": 2048, "normal_weight": 0.05, "report_freq": 10 ** 9, "save_freq": 10 ** 9, "val_freq": 0}}
+    r = Runner(conf=conf, device="cuda:0", exp_root="/tmp/dh_ab")
+    ren = r.renderer
+    cap = {}
+    orig = ren._net_backward
+
+    def capture(s, d_sdf, d_normals, d_colors, grad):
+        cap.update(s=s, d_sdf=d_sdf, d_normals=d_normals.clone(), d_colors=d_colors, grad=grad)
+        return orig(s, d_sdf, d_normals, d_colors, grad)
+
+    for _ in range(3):
+        r.train_iteration()
+    ren._net_backward = capture
+    r.train_iteration()
+    ren._net_backward = orig
+    torch.cuda.synchronize()
+    s, st = cap["s"], ren.store
+    P = s.B * s.n
+    packed = st.ensure_packed()
+    stream = _lib.stream()
+    dn = cap["d_normals"]          # colour backward ACCUMULATES into d_normals: give it a scratch copy each time
+
+    stages = {
+        "sdf_forward": lambda: L.dh_sdf_forward(_p(packed), _p(s.pts), P, _p(s.ws), _p(s.sdf), stream),
+        "sdf_gradient": lambda: L.dh_sdf_gradient(_p(packed), _p(s.pts), P, _p(s.ws), _p(s.normals), 1, stream),
+        "color_forward": lambda: L.dh_color_forward(_p(packed), _p(s.pts), _p(s.rays_d), s.n, _p(s.normals), P, _p(s.ws), _p(s.colors), 1, stream),
+        "color_backward": lambda: L.dh_color_backward(_p(packed), _p(s.colors), _p(cap["d_colors"]), P, _p(s.ws), _p(dn.clone()), stream),
+        "sdf_tangent": lambda: L.dh_sdf_tangent(_p(packed), _p(s.pts), _p(dn), P, _p(s.ws), stream),
+        "sdf_backward": lambda: L.dh_sdf_backward(_p(packed), _p(cap["d_sdf"]), P, _p(s.ws), stream),
+        "weight_grads_gemm": lambda: L.dh_weight_grads_gemm(P, _p(s.ws), stream),
+    }
+
+    def time_stage(fn, reps):
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+        for a, b in ev:
+            a.record(); _lib.check(fn()); b.record()
+        torch.cuda.synchronize()
+        t = sorted(a.elapsed_time(b) for a, b in ev)
+        return {"median_ms": t[len(t) // 2], "min_ms": t[0], "mean_ms": sum(t) / len(t)}
+
+    res = {"lib": args.lib or "libdynhor_hip.so", "stages": {}}
+    for name, fn in stages.items():
+        if name == "weight_grads_gemm":
+            continue
+        for _ in range(2):
+            _lib.check(fn())
+        res["stages"][name] = time_stage(fn, args.reps)
+        print(name, res["stages"][name], flush=True)
+    # weight gradients: dev variants interleaved
+    variants = [int(v) for v in args.dw_variants.split(",")]
+    dw = {v: [] for v in variants}
+    grads = {}
+    for rnd in range(4):
+        for v in variants:
+            if have_dev:
+                L.dh_dev_variant(0, v)
+            _lib.check(stages["weight_grads_gemm"]())
+            dw[v].append(time_stage(stages["weight_grads_gemm"], max(args.reps // 4, 3)))
+            if rnd == 0:
+                g = torch.zeros(st.n, device="cuda:0")       # the fold leaves the variance slot alone
+                _lib.check(L.dh_weight_grads_fold(_p(packed), _p(st.flat), P, _p(s.ws), _p(g), stream))
+                grads[v] = g
+    if have_dev:
+        L.dh_dev_variant(0, 0)
+    res["weight_grads_gemm"] = {}
+    for v in variants:
+        med = sorted(x["median_ms"] for x in dw[v])
+        rel = float((grads[v] - grads[variants[0]]).norm() / grads[variants[0]].norm())
+        res["weight_grads_gemm"][str(v)] = {"median_ms_rounds": med, "grad_rel_diff_vs_first": rel,
+                                            "finite": bool(torch.isfinite(grads[v]).all())}
+        print("dW variant", v, res["weight_grads_gemm"][str(v)], flush=True)
+    # chain-kernel variants (dev_variant keys >= 1): interleaved rounds, outputs compared bit for bit through the workspace
+    res["stage_variants"] = {}
+    for spec in [x for x in args.stage_variants.split(";") if x]:
+        key, stage, vs = spec.split(":")
+        key, vs = int(key), [int(v) for v in vs.split(",")]
+        inf_f, fwd_f, tot_f = _lib.workspace_floats(P)
+        tm = {v: [] for v in vs}
+        snap = {}
+        for rnd in range(4):
+            for v in vs:
+                L.dh_dev_variant(key, v)
+                _lib.check(stages[stage]())
+                tm[v].append(time_stage(stages[stage], max(args.reps // 4, 3))["median_ms"])
+                if rnd == 0:
+                    torch.cuda.synchronize()
+                    # checksum of the whole saved-tile workspace (minus the dW slabs) + the stage's plain outputs
+                    ws = s.ws[:tot_f - (256 + 1) * sum(8 * nb * 1024 for nb in [2, 8, 8, 8, 8, 8, 8, 8, 2, 8, 8, 2, 8, 8, 8])]
+                    snap[v] = (ws.double().sum().item(), ws.abs().double().sum().item(), s.sdf.double().sum().item(), s.normals.double().sum().item())
+        L.dh_dev_variant(key, 0)
+        _lib.check(stages[stage]())
+        res["stage_variants"][spec] = {str(v): {"median_ms_rounds": sorted(tm[v]), "same_outputs_as_first": snap[v] == snap[vs[0]]} for v in vs}
+        for v in vs:
+            print(stage, "variant", v, res["stage_variants"][spec][str(v)], flush=True)
+    if args.stamps:
+        import numpy as np
+        n = 512 * 4 * 2 * 10 * 8
+        out = {}
+        for key, reader, stage in (("sdf_forward", "dh_dev_read_stamps_fwd", "sdf_forward"), ("sdf_tangent", "dh_dev_read_stamps_bwd", "sdf_tangent")):
+            _lib.check(stages[stage]())
+            torch.cuda.synchronize()
+            buf = (ctypes.c_ulonglong * n)()
+            fn = getattr(L, reader)
+            fn.restype = ctypes.c_int
+            fn.argtypes = [ctypes.c_void_p, ctypes.c_longlong]
+            assert fn(ctypes.cast(buf, ctypes.c_void_p), n) == 0
+            a = np.frombuffer(buf, dtype=np.uint64).reshape(512, 4, 2, 10, 8).astype(np.float64)
+            d = {}
+            nl = 8
+            # per layer (1..6: steady layers), phase durations in cycles, averaged over blocks / waves / the two recorded iterations
+            lay = a[:, :, :, 1:7, :]
+            names = ["gemm", "epilogue_math(+loads)", "tile_store_issue", "barrier1", "lds_write", "barrier2"]
+            for i, nm in enumerate(names):
+                dd = lay[..., i + 1] - lay[..., i]
+                d[nm] = {"mean": float(dd.mean()), "p10": float(np.percentile(dd, 10)), "p90": float(np.percentile(dd, 90))}
+            tot = lay[..., 6] - lay[..., 0]
+            d["layer_total"] = {"mean": float(tot.mean()), "p10": float(np.percentile(tot, 10)), "p90": float(np.percentile(tot, 90))}
+            # phase alignment across the chip: spread of the layer-3 start stamp (iteration 2) over workgroups
+            st3 = a[:, 0, 0, 3, 0]
+            d["layer3_start_spread_cycles"] = {"p5": float(np.percentile(st3 - st3.min(), 5)), "p50": float(np.percentile(st3 - st3.min(), 50)),
+                                               "p95": float(np.percentile(st3 - st3.min(), 95))}
+            # are the two co-resident workgroups (b, b + 256 share a CU only by chance) in phase?  report the histogram of
+            # (start of layer 3) mod (mean layer time) over all workgroups
+            ph = np.mod(st3 - st3.min(), d["layer_total"]["mean"]) / d["layer_total"]["mean"]
+            d["layer3_phase_hist10"] = np.histogram(ph, bins=10, range=(0, 1))[0].tolist()
+            out[key] = d
+            print(key, json.dumps(d, indent=1), flush=True)
+        res["stamps"] = out
+    if args.out:
+        os.makedirs(os.path.dirname(os.path.join(ROOT, args.out)), exist_ok=True)
+        json.dump(res, open(os.path.join(ROOT, args.out), "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()
