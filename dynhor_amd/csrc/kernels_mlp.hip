@@ -358,10 +358,13 @@ __global__ __launch_bounds__(256 * TEAMS, 2) void sdf_fwd_train_s_kernel(Sdf16Pt
         for (int l = 0; l < 8; ++l) {
             DH_STAMP(it, l, 0);
             acc_zero(acc);
-            if (TRICKLE && l > 0 && tv) {
+            if (TRICKLE == 1 && l > 0 && tv) {
                 TileTrickle tr{smain, reinterpret_cast<f32x4*>(act + ((int64_t)(l - 1) * ntiles + tile) * TILE_F) + woff, wave, lane, 0};
                 gemm_rows_s(acc, smain, LDX, l == 4 ? 14 : 16, P.main16[l], wave, lane, tr);
                 if (l == 4) { tr.j0 = 14; gemm_rows_s(acc, saux, LDA, AUX_KC, P.aux16[l], wave, lane, tr); }
+            } else if (TRICKLE >= 2) {      // timing experiment: FAKE = TRICKLE - 1
+                if (l > 0) gemm_rows_s<NoTrickle, TRICKLE - 1>(acc, smain, LDX, l == 4 ? 14 : 16, P.main16[l], wave, lane);
+                if (l == 0 || l == 4) gemm_rows_s(acc, saux, LDA, AUX_KC, P.aux16[l], wave, lane);
             } else {
                 if (l > 0) gemm_rows_s(acc, smain, LDX, l == 4 ? 14 : 16, P.main16[l], wave, lane);
                 if (l == 0 || l == 4) gemm_rows_s(acc, saux, LDA, AUX_KC, P.aux16[l], wave, lane);
@@ -370,7 +373,7 @@ __global__ __launch_bounds__(256 * TEAMS, 2) void sdf_fwd_train_s_kernel(Sdf16Pt
             const float b0 = P.bias[l][acc_col(wave, 0, lane)], b1 = P.bias[l][acc_col(wave, 1, lane)];
             acc_map(acc, [&](int, int t, int, float v) { return softplus100(v + (t ? b1 : b0)); });
             DH_STAMP(it, l, 2);
-            if (!TRICKLE && tv) acc_store_native(acc, act + ((int64_t)l * ntiles + tile) * TILE_F, wave, lane);
+            if (TRICKLE != 1 && tv) acc_store_native(acc, act + ((int64_t)l * ntiles + tile) * TILE_F, wave, lane);
             DH_STAMP(it, l, 3);
             __syncthreads();
             DH_STAMP(it, l, 4);
@@ -383,7 +386,7 @@ __global__ __launch_bounds__(256 * TEAMS, 2) void sdf_fwd_train_s_kernel(Sdf16Pt
         const int64_t gp = tile * TM + tid / TPP;
         if (tid % TPP == 0 && gp < npts) sdf_out[gp] = s;
         acc_zero(acc);
-        if (TRICKLE && tv) {
+        if (TRICKLE == 1 && tv) {
             TileTrickle tr{smain, reinterpret_cast<f32x4*>(act + ((int64_t)7 * ntiles + tile) * TILE_F) + woff, wave, lane, 0};
             gemm_rows_s(acc, smain, LDX, 16, P.main16[8], wave, lane, tr);
         } else {
@@ -471,6 +474,8 @@ int launch_sdf_fwd_train(const float* packed, const float* pts, int64_t npts, fl
             case 1: hipLaunchKernelGGL((sdf_fwd_train_s_kernel<1, 1>), dim3(g), dim3(256), 0, stream, P, pts, npts, sdf, feat, act, eaux); break;
             case 2: hipLaunchKernelGGL((sdf_fwd_train_s_kernel<2, 0>), dim3(g2), dim3(512), 0, stream, P, pts, npts, sdf, feat, act, eaux); break;
             case 3: hipLaunchKernelGGL((sdf_fwd_train_s_kernel<2, 1>), dim3(g2), dim3(512), 0, stream, P, pts, npts, sdf, feat, act, eaux); break;
+            case 4: hipLaunchKernelGGL((sdf_fwd_train_s_kernel<1, 2>), dim3(g), dim3(256), 0, stream, P, pts, npts, sdf, feat, act, eaux); break;
+            case 5: hipLaunchKernelGGL((sdf_fwd_train_s_kernel<1, 3>), dim3(g), dim3(256), 0, stream, P, pts, npts, sdf, feat, act, eaux); break;
             default: hipLaunchKernelGGL((sdf_fwd_train_s_kernel<1, 0>), dim3(g), dim3(256), 0, stream, P, pts, npts, sdf, feat, act, eaux); break;
         }
     }

@@ -148,7 +148,9 @@ __device__ __forceinline__ void tile_prefetch(TileRegs& t, const float* __restri
 struct NoTrickle { __device__ __forceinline__ void operator()(int) const {} };
 // `side(kc)` runs once per k-chunk inside the loop (default: nothing): the chains use it to trickle the PREVIOUS layer's
 // activation tile from the LDS image to HBM under the MFMAs instead of storing it in one burst after the epilogue.
-template <class Side = NoTrickle>
+// FAKE != 0 (timing experiments only, results are garbage): 1 = no split at all (the fetched bits are used as pieces), i.e. the
+// chain with ZERO split VALU work; 2 = no weight loads either (B fragments held constant).
+template <class Side = NoTrickle, int FAKE = 0>
 __device__ __forceinline__ void gemm_rows_s(f32x16 (&acc)[MT][2], const float* xs, const int ldx, const int nkc,
                                             const bf16x8* __restrict__ wp, const int wave, const int lane, Side side = Side()) {
     const float* xrow = xs + (lane & 31) * ldx + 8 * (lane >> 5);
@@ -157,18 +159,28 @@ __device__ __forceinline__ void gemm_rows_s(f32x16 (&acc)[MT][2], const float* x
     const int last = nkc - 1;
     auto fetch = [&](Bf3 (&a)[MT], Bf3 (&b)[2], int kc) {
         kc = kc < last ? kc : last;
-        DH_UNROLL for (int t = 0; t < 2; ++t)
-            DH_UNROLL for (int p = 0; p < 3; ++p) b[t].p[p] = wl[((kc * 8 + t) * 3 + p) * 64];
+        if (FAKE != 2) {
+            DH_UNROLL for (int t = 0; t < 2; ++t)
+                DH_UNROLL for (int p = 0; p < 3; ++p) b[t].p[p] = wl[((kc * 8 + t) * 3 + p) * 64];
+        }
         DH_UNROLL for (int m = 0; m < MT; ++m) {
             const f32x4 lo = *reinterpret_cast<const f32x4*>(xrow + m * 32 * ldx + kc * 16);
             const f32x4 hi = *reinterpret_cast<const f32x4*>(xrow + m * 32 * ldx + kc * 16 + 4);
-            a[m] = split3(lo, hi);
+            if (FAKE == 0) a[m] = split3(lo, hi);
+            else {
+                a[m].p[0] = __builtin_bit_cast(bf16x8, lo); a[m].p[1] = __builtin_bit_cast(bf16x8, hi);
+                a[m].p[2] = __builtin_bit_cast(bf16x8, lo);
+            }
         }
     };
     auto mul = [&](const Bf3 (&a)[MT], const Bf3 (&b)[2]) {
         DH_UNROLL for (int m = 0; m < MT; ++m)
             DH_UNROLL for (int t = 0; t < 2; ++t) acc[m][t] = mfma6(a[m], b[t], acc[m][t]);
     };
+    if (FAKE == 2) {
+        DH_UNROLL for (int t = 0; t < 2; ++t)
+            DH_UNROLL for (int p = 0; p < 3; ++p) { b0[t].p[p] = wl[(t * 3 + p) * 64]; b1[t].p[p] = wl[((8 + t) * 3 + p) * 64]; }
+    }
     fetch(a0, b0, 0);
     _Pragma("unroll 1") for (int kc = 0; kc < nkc; kc += 2) {
         fetch(a1, b1, kc + 1);
