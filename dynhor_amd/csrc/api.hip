@@ -13,8 +13,6 @@ static int g_arith = DH_ARITH_SPLIT_BF16;
 static int g_hash_scatter = 0;
 bool arith_fp32() { return __atomic_load_n(&g_arith, __ATOMIC_RELAXED) == DH_ARITH_FP32_MFMA; }
 int hash_scatter_mode() { return __atomic_load_n(&g_hash_scatter, __ATOMIC_RELAXED); }
-static int g_dev[16] = {0};
-int dev_variant(int key) { return g_dev[key & 15]; }
 }  // namespace dh
 
 namespace {
@@ -32,8 +30,6 @@ int dh_set_arithmetic(int mode) {
     return DH_OK;
 }
 int dh_get_arithmetic(void) { return __atomic_load_n(&dh::g_arith, __ATOMIC_RELAXED); }
-
-int dh_dev_variant(int key, int value) { dh::g_dev[key & 15] = value; return 0; }   /* DEVELOPMENT ONLY, not in the header */
 
 int dh_hash_set_scatter_mode(int mode) {
     if (mode < 0 || mode > 2) return DH_ERR_BAD_ARG;

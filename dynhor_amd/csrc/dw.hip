@@ -180,7 +180,7 @@ __device__ __forceinline__ void dw_body_lds(const DwJob& J, int64_t t0, int64_t 
 constexpr int DWP_TILE = 3 * 1024;                 // bytes of one tile's three pieces (64 lanes x 16 B each)
 constexpr int DWP_BUF = 16 * DWP_TILE;             // one k-pair: A tiles 0..7, B tiles 8..15
 
-template <int NB, int PUB, int DEPTH>
+template <int NB>
 __device__ __forceinline__ void dw_body_pieces(const DwJob& J, int64_t t0, int64_t t1, float* __restrict__ out, int wave,
                                                int lane, char* lds) {
     constexpr int KQ = MT * 4;
@@ -213,23 +213,19 @@ __device__ __forceinline__ void dw_body_pieces(const DwJob& J, int64_t t0, int64
             if (++ld_tile == t1) { ld_tile = t0; if (++ld_pair == npairs) ld_pair = 0; }    // past the end: wrap (harmless re-read)
         }
     };
-    auto fake3 = [&](const f32x4& lo, const f32x4& hi) {  // timing experiment (PUB 5): no split, garbage pieces
-        Bf3 r; r.p[0] = __builtin_bit_cast(bf16x8, lo); r.p[1] = __builtin_bit_cast(bf16x8, hi); r.p[2] = __builtin_bit_cast(bf16x8, lo); return r;
-    };
-    auto publish_a = [&](const Raw& r, int par) {         // split this wave's A tile and write its pieces
+    auto publish_a = [&](const Raw& r, int par) {         // split this wave's A tile and write its three pieces
         char* base = lds + par * DWP_BUF + lane * 16;
-        const Bf3 pa = (PUB == 5) ? fake3(r.a0, r.a1) : split3(r.a0, r.a1);
+        const Bf3 pa = split3(r.a0, r.a1);
         DH_UNROLL for (int p = 0; p < 3; ++p) *reinterpret_cast<bf16x8*>(base + wave * DWP_TILE + p * 1024) = pa.p[p];
     };
     auto publish_b = [&](const Raw& r, int par) {
         char* base = lds + par * DWP_BUF + lane * 16;
         if (has_b) {
-            const Bf3 pb = (PUB == 5) ? fake3(r.b0, r.b1) : split3(r.b0, r.b1);
+            const Bf3 pb = split3(r.b0, r.b1);
             const int bn = (NB == 8) ? wave : (wave & 1);
             DH_UNROLL for (int p = 0; p < 3; ++p) *reinterpret_cast<bf16x8*>(base + (8 + bn) * DWP_TILE + p * 1024) = pb.p[p];
         }
     };
-    auto publish = [&](const Raw& r, int par) { publish_a(r, par); publish_b(r, par); };
     auto piece = [&](int par, int tile) {
         Bf3 f;
         const char* base = lds + par * DWP_BUF + tile * DWP_TILE + lane * 16;
@@ -237,90 +233,53 @@ __device__ __forceinline__ void dw_body_pieces(const DwJob& J, int64_t t0, int64
         return f;
     };
     if (NP > 0) {
-        Raw r0, r1, r2;
+        Raw r0, r1;
         load(r0);
         load(r1);
-        if (DEPTH == 3) load(r2);
         __builtin_amdgcn_sched_barrier(0);
-        publish(r0, 0);
-        load(r0);                                          // pair 2 (DEPTH 3: pair 3) in flight
+        publish_a(r0, 0);
+        publish_b(r0, 0);
+        load(r0);                                          // pair 2 in flight
         __syncthreads();
         constexpr int H = NBW / 2;
         // one k-pair; `nxt` holds the raw operands of pair p+1 (published here) and is refilled with pair p+3.  The two
         // register sets alternate STATICALLY (the loop is unrolled by two): selecting the set with a run-time index makes the
         // compiler load into temporaries and wait for them on the spot, which exposes the full HBM latency every pair.
         // Buffer par^1 was last read before the barrier that ended the previous step, so the next pair's split + piece
-        // writes may sit ANYWHERE in this step; PUB picks where (measured, DESIGN.md section 3 "Weight gradients"):
-        //   0  before the MFMAs, pinned (under the LDS latency of the piece reads only)
-        //   1  between the two MFMA halves, pinned
-        //   2  in one scheduling region with the first MFMA half (the compiler interleaves VALU / DS writes with MFMAs)
-        //   3  as 2, with an explicit 1 MFMA : 4 VALU pipeline (sched_group_barrier)
-        //   4  A tile's pieces with the first MFMA half, B tile's with the second (compiler-interleaved)
-        auto step = [&](int p, int par, Raw& nxt) {
+        // writes may sit ANYWHERE in this step: the A tile's go into one scheduling region with the first half of the MFMAs,
+        // the B tile's with the second half, and the compiler interleaves the VALU / ds_write work with the matrix
+        // instructions (round 2, same-box A/B: before the MFMAs, pinned 3.55 ms; between the halves 3.58; all with the first
+        // half 3.44; this form 3.44; explicit 1 MFMA : 4 VALU sched_group_barrier pipeline 3.48).  UNCONDITIONAL -- a branch
+        // would end the scheduling region: after the last pair this writes wrapped-around data into the idle buffer, which
+        // the next job's prologue overwrites behind a barrier.
+        auto step = [&](int par, Raw& nxt) {
             Bf3 a[NA], b[H];
             DH_UNROLL for (int ii = 0; ii < NA; ++ii) a[ii] = piece(par, (NB == 8) ? ((wave >> 1) * 2 + ii) : wave);
             DH_UNROLL for (int j = 0; j < H; ++j) b[j] = piece(par, 8 + ((NB == 8) ? ((wave & 1) * 4 + j) : j));
             __builtin_amdgcn_sched_barrier(0);
-            const bool pub = p + 1 < NP;
-            if (PUB == 0) {
-                if (pub) publish(nxt, par ^ 1);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            // PUB >= 2: UNCONDITIONAL (a branch would end the scheduling region); after the last pair this writes wrapped-around
-            // data into the idle buffer, which the next job's prologue overwrites behind a barrier
-            if (PUB == 2 || PUB == 3) publish(nxt, par ^ 1);
-            if (PUB >= 4) publish_a(nxt, par ^ 1);
+            publish_a(nxt, par ^ 1);
             DH_UNROLL for (int ii = 0; ii < NA; ++ii)
                 DH_UNROLL for (int j = 0; j < H; ++j) acc[ii][j] = mfma6(a[ii], b[j], acc[ii][j]);
-            if (PUB == 3) {
-                DH_UNROLL for (int q = 0; q < NA * H * 6; ++q) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // 1 MFMA
-                    __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);      // 4 VALU
-                    if ((q & 3) == 3) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);   // 1 DS write
-                }
-            }
             __builtin_amdgcn_sched_barrier(0);
-            if (PUB == 1) {
-                if (pub) publish(nxt, par ^ 1);
-                __builtin_amdgcn_sched_barrier(0);
-            }
             if (H < NBW) {
                 DH_UNROLL for (int j = 0; j < H; ++j) b[j] = piece(par, 8 + ((NB == 8) ? ((wave & 1) * 4 + H + j) : (H + j)));
             }
-            if (PUB >= 4) publish_b(nxt, par ^ 1);
-            if (PUB < 4) {
-                load(nxt);  // pair p+3; UNCONDITIONAL so the compiler can count on it being in flight (vmcnt(4..7) at the next
-                            // publish instead of draining everything); past the end the cursor wraps onto valid memory
-                __builtin_amdgcn_sched_barrier(0);
-            }
+            publish_b(nxt, par ^ 1);
             DH_UNROLL for (int ii = 0; ii < NA; ++ii)
                 DH_UNROLL for (int j = 0; j < H; ++j) acc[ii][H + j] = mfma6(a[ii], b[j], acc[ii][H + j]);
             __builtin_amdgcn_sched_barrier(0);
-            if (PUB == 4 || PUB == 5) { load(nxt); __builtin_amdgcn_sched_barrier(0); }      // PUB 6 (timing experiment): no global loads
+            load(nxt);      // pair p+3; UNCONDITIONAL so the compiler can count on it being in flight (vmcnt(4..7) at the next
+                            // publish instead of draining everything); past the end the cursor wraps onto valid memory.  A third
+                            // register set (pair p+4 in flight) measured the same 3.47 ms: the depth is not what limits it
+            __builtin_amdgcn_sched_barrier(0);
             __syncthreads();
         };
         int p = 0;
-        if (DEPTH == 3) {
-            // three raw register sets: the pair published in step p was loaded THREE steps earlier (two with DEPTH 2), i.e.
-            // ~3 x 32 KB per workgroup in flight -- the HBM latency under load is 2-4 us = 1.5-3 steps.  The LDS buffer
-            // alternates with period 2 and the register set with period 3: unrolled by 6 so both stay static.
-            for (; p + 5 < NP; p += 6) {
-                step(p, 0, r1); step(p + 1, 1, r2); step(p + 2, 0, r0);
-                step(p + 3, 1, r1); step(p + 4, 0, r2); step(p + 5, 1, r0);
-            }
-            // remainder (NP is a multiple of KQ/2 = 4 per tile, so 0, 2 or 4 steps remain): same rotation, guarded
-            if (p < NP) { step(p, 0, r1); ++p; }
-            if (p < NP) { step(p, 1, r2); ++p; }
-            if (p < NP) { step(p, 0, r0); ++p; }
-            if (p < NP) { step(p, 1, r1); ++p; }
-            if (p < NP) { step(p, 0, r2); ++p; }
-        } else {
-            for (; p + 1 < NP; p += 2) {
-                step(p, 0, r1);
-                step(p + 1, 1, r0);
-            }
-            if (p < NP) step(p, 0, r1);
+        for (; p + 1 < NP; p += 2) {
+            step(0, r1);
+            step(1, r0);
         }
+        if (p < NP) step(0, r1);
     }
     DH_UNROLL for (int i = 0; i < NA; ++i)
         DH_UNROLL for (int j = 0; j < NBW; ++j) {
@@ -331,7 +290,6 @@ __device__ __forceinline__ void dw_body_pieces(const DwJob& J, int64_t t0, int64
         }
 }
 
-template <int PUB, int DEPTH = 2>
 __global__ __launch_bounds__(512, 1) void dw_bf16x3_kernel(DwJobs jobs, int64_t ntiles, float* __restrict__ slabs, int64_t gstride) {
     __shared__ __attribute__((aligned(16))) char pieces[2 * DWP_BUF];
     const int G = gridDim.x, g = blockIdx.x;
@@ -340,8 +298,8 @@ __global__ __launch_bounds__(512, 1) void dw_bf16x3_kernel(DwJobs jobs, int64_t 
     float* base = slabs + (int64_t)g * gstride;
     for (int job = 0; job < jobs.n; ++job) {
         const DwJob J = jobs.j[job];
-        if (J.nb == 8) dw_body_pieces<8, PUB, DEPTH>(J, t0, t1, base + J.off, wave, lane, pieces);
-        else dw_body_pieces<2, PUB, 2>(J, t0, t1, base + J.off, wave, lane, pieces);
+        if (J.nb == 8) dw_body_pieces<8>(J, t0, t1, base + J.off, wave, lane, pieces);
+        else dw_body_pieces<2>(J, t0, t1, base + J.off, wave, lane, pieces);
     }
 }
 
@@ -520,16 +478,7 @@ int launch_weight_grads_gemm(const Workspace& w, float* slabs, int G, hipStream_
     SlabPtrs S{};
     build_dw_jobs(w, slabs + (int64_t)G * gstride, J, S);
     if (arith_fp32()) hipLaunchKernelGGL(dw_lds_kernel, dim3(G), dim3(512), 0, st, J, w.ntiles, slabs, gstride);
-    else switch (dev_variant(0)) {       // 0 = shipping (PUB 4); 10 + p = publish placement p (A/B, scripts/ab_stage.py)
-        case 10: hipLaunchKernelGGL(dw_bf16x3_kernel<0>, dim3(G), dim3(512), 0, st, J, w.ntiles, slabs, gstride); break;
-        case 11: hipLaunchKernelGGL(dw_bf16x3_kernel<1>, dim3(G), dim3(512), 0, st, J, w.ntiles, slabs, gstride); break;
-        case 12: hipLaunchKernelGGL(dw_bf16x3_kernel<2>, dim3(G), dim3(512), 0, st, J, w.ntiles, slabs, gstride); break;
-        case 13: hipLaunchKernelGGL(dw_bf16x3_kernel<3>, dim3(G), dim3(512), 0, st, J, w.ntiles, slabs, gstride); break;
-        case 17: hipLaunchKernelGGL((dw_bf16x3_kernel<4, 3>), dim3(G), dim3(512), 0, st, J, w.ntiles, slabs, gstride); break;
-        case 15: hipLaunchKernelGGL(dw_bf16x3_kernel<5>, dim3(G), dim3(512), 0, st, J, w.ntiles, slabs, gstride); break;
-        case 16: hipLaunchKernelGGL(dw_bf16x3_kernel<6>, dim3(G), dim3(512), 0, st, J, w.ntiles, slabs, gstride); break;
-        default: hipLaunchKernelGGL(dw_bf16x3_kernel<4>, dim3(G), dim3(512), 0, st, J, w.ntiles, slabs, gstride); break;
-    }
+    else hipLaunchKernelGGL(dw_bf16x3_kernel, dim3(G), dim3(512), 0, st, J, w.ntiles, slabs, gstride);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 

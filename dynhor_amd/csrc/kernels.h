@@ -10,7 +10,6 @@ namespace dh {
 // fp32 MFMA.  One process-global word, read at every launch.
 bool arith_fp32();
 int hash_scatter_mode();
-int dev_variant(int key);          // DEVELOPMENT ONLY (round-2 A/B experiments): removed once the winners are hard-wired
 
 int launch_pack_weights(const float* params, float* packed, hipStream_t stream);
 

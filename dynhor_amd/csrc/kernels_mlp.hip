@@ -16,7 +16,7 @@ namespace dh {
 // K1: SDF forward, no grad, sdf only (hierarchical up-sampling evaluations; SURVEY §8 a5 "no-grad").
 // lin8 reduces to its row 0: a 256-long dot per point, done on the VALU.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, TM == 128 ? 1 : 2) void sdf_nograd_kernel(SdfPtrs P, const float* __restrict__ pts, int64_t npts,
+__global__ __launch_bounds__(256, 2) void sdf_nograd_kernel(SdfPtrs P, const float* __restrict__ pts, int64_t npts,
                                                              float* __restrict__ sdf_out) {
     __shared__ __attribute__((aligned(16))) float smain[TM * LDX];
     __shared__ __attribute__((aligned(16))) float saux[TM * LDA];
@@ -50,7 +50,7 @@ __global__ __launch_bounds__(256, TM == 128 ? 1 : 2) void sdf_nograd_kernel(SdfP
 // post-softplus, native tiles), writes feat = lin8 rows 1..256 (native) and sdf = lin8 row 0 (VALU dot).
 //   act : [8][ntiles][TILE_F]   (act[l-1] <-> input of layer l)
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, TM == 128 ? 1 : 2) void sdf_fwd_train_kernel(SdfPtrs P, const float* __restrict__ pts, int64_t npts,
+__global__ __launch_bounds__(256, 2) void sdf_fwd_train_kernel(SdfPtrs P, const float* __restrict__ pts, int64_t npts,
                                                                 float* __restrict__ sdf_out, float* __restrict__ feat,
                                                                 float* __restrict__ act, float* __restrict__ eaux) {
     __shared__ __attribute__((aligned(16))) float smain[TM * LDX];
@@ -93,7 +93,7 @@ __global__ __launch_bounds__(256, TM == 128 ? 1 : 2) void sdf_fwd_train_kernel(S
 //   ge = a_0 W_0 + a_4 W_4[:,217:]/sqrt2 ;  n = J_e(x)^T ge.   Saves a_l (l=0..7) for the backward pass.
 //   asave : [8][ntiles][TILE_F]
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, TM == 128 ? 1 : 2) void sdf_grad_kernel(SdfPtrs P, const float* __restrict__ pts, int64_t npts,
+__global__ __launch_bounds__(256, 2) void sdf_grad_kernel(SdfPtrs P, const float* __restrict__ pts, int64_t npts,
                                                            const float* __restrict__ act, float* __restrict__ asave,
                                                            float* __restrict__ normals, int save) {
     __shared__ __attribute__((aligned(16))) float smain[TM * LDX];
@@ -246,7 +246,7 @@ __global__ __launch_bounds__(256, 1) void sdf_grad16_kernel(Sdf16Ptrs P, const f
 // activations cact[l] (l=1..4 -> slot l-1) and writes colour = sigmoid(lin4).
 //   dirs: [nrays,3], point gp belongs to ray gp / n_per_ray.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, TM == 128 ? 1 : 2) void color_fwd_kernel(ColPtrs C, const float* __restrict__ pts, const float* __restrict__ dirs,
+__global__ __launch_bounds__(256, 2) void color_fwd_kernel(ColPtrs C, const float* __restrict__ pts, const float* __restrict__ dirs,
                                                             int n_per_ray, const float* __restrict__ normals,
                                                             const float* __restrict__ feat, int64_t npts,
                                                             float* __restrict__ color, float* __restrict__ cact,
@@ -305,7 +305,7 @@ __global__ __launch_bounds__(256, TM == 128 ? 1 : 2) void color_fwd_kernel(ColPt
 }
 
 // K1, split-on-fetch (tile16.h): the fp32 LDS image of sdf_nograd_kernel, GEMMs as six bf16 products
-__global__ __launch_bounds__(256, TM == 128 ? 1 : 2) void sdf_nograd_s_kernel(Sdf16Ptrs P, const float* __restrict__ pts, int64_t npts,
+__global__ __launch_bounds__(256, 2) void sdf_nograd_s_kernel(Sdf16Ptrs P, const float* __restrict__ pts, int64_t npts,
                                                              float* __restrict__ sdf_out) {
     __shared__ __attribute__((aligned(16))) float smain[TM * LDX];
     __shared__ __attribute__((aligned(16))) float saux[TM * LDA];
@@ -332,48 +332,30 @@ __global__ __launch_bounds__(256, TM == 128 ? 1 : 2) void sdf_nograd_s_kernel(Sd
     }
 }
 
-// K2a, split-on-fetch.  TEAMS = 1: one 64-point tile per 4-wave workgroup, two workgroups per CU (independent phases).
-// TEAMS = 2: one 8-wave workgroup per CU whose two 4-wave teams run the same layer on two tiles in lockstep, so each B
-// fragment is fetched from L2 once per CU (the second team's load hits L1).  TRICKLE = 1: the activation tile is saved from
-// the LDS image under the NEXT layer's MFMAs (TileTrickle) instead of as a 16-store burst after the epilogue.
-template <int TEAMS, int TRICKLE>
-__global__ __launch_bounds__(256 * TEAMS, 2) void sdf_fwd_train_s_kernel(Sdf16Ptrs P, const float* __restrict__ pts, int64_t npts,
+// K2a, split-on-fetch
+__global__ __launch_bounds__(256, 2) void sdf_fwd_train_s_kernel(Sdf16Ptrs P, const float* __restrict__ pts, int64_t npts,
                                                                 float* __restrict__ sdf_out, float* __restrict__ feat,
                                                                 float* __restrict__ act, float* __restrict__ eaux) {
-    __shared__ __attribute__((aligned(16))) float smain_all[TEAMS * TM * LDX];
-    __shared__ __attribute__((aligned(16))) float saux_all[TEAMS * TM * LDA];
-    const int team = threadIdx.x >> 8, tid = threadIdx.x & 255, wave = tid >> 6, lane = tid & 63;
-    float* smain = smain_all + team * TM * LDX;
-    float* saux = saux_all + team * TM * LDA;
+    __shared__ __attribute__((aligned(16))) float smain[TM * LDX];
+    __shared__ __attribute__((aligned(16))) float saux[TM * LDA];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int64_t ntiles = (npts + TM - 1) / TM;
     int it = 0;
-    for (int64_t tile0 = (int64_t)blockIdx.x * TEAMS; tile0 < ntiles; tile0 += (int64_t)gridDim.x * TEAMS, ++it) {
-        const int64_t tile = tile0 + team;
-        const bool tv = tile < ntiles;                      // an odd tile count leaves the last workgroup's second team idle
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x, ++it) {
         embed_tile(pts, tile * TM, npts, saux, tid);
         __syncthreads();
-        if (tv) aux_lds_to_native(saux, eaux + tile * AUXT_F, wave, lane);
+        aux_lds_to_native(saux, eaux + tile * AUXT_F, wave, lane);
         f32x16 acc[MT][2];
-        const size_t woff = (size_t)wave * MT * 8 * 64 + lane;
         for (int l = 0; l < 8; ++l) {
             DH_STAMP(it, l, 0);
             acc_zero(acc);
-            if (TRICKLE == 1 && l > 0 && tv) {
-                TileTrickle tr{smain, reinterpret_cast<f32x4*>(act + ((int64_t)(l - 1) * ntiles + tile) * TILE_F) + woff, wave, lane, 0};
-                gemm_rows_s(acc, smain, LDX, l == 4 ? 14 : 16, P.main16[l], wave, lane, tr);
-                if (l == 4) { tr.j0 = 14; gemm_rows_s(acc, saux, LDA, AUX_KC, P.aux16[l], wave, lane, tr); }
-            } else if (TRICKLE >= 2) {      // timing experiment: FAKE = TRICKLE - 1
-                if (l > 0) gemm_rows_s<NoTrickle, TRICKLE - 1>(acc, smain, LDX, l == 4 ? 14 : 16, P.main16[l], wave, lane);
-                if (l == 0 || l == 4) gemm_rows_s(acc, saux, LDA, AUX_KC, P.aux16[l], wave, lane);
-            } else {
-                if (l > 0) gemm_rows_s(acc, smain, LDX, l == 4 ? 14 : 16, P.main16[l], wave, lane);
-                if (l == 0 || l == 4) gemm_rows_s(acc, saux, LDA, AUX_KC, P.aux16[l], wave, lane);
-            }
+            if (l > 0) gemm_rows_s(acc, smain, LDX, l == 4 ? 14 : 16, P.main16[l], wave, lane);
+            if (l == 0 || l == 4) gemm_rows_s(acc, saux, LDA, AUX_KC, P.aux16[l], wave, lane);
             DH_STAMP(it, l, 1);
             const float b0 = P.bias[l][acc_col(wave, 0, lane)], b1 = P.bias[l][acc_col(wave, 1, lane)];
             acc_map(acc, [&](int, int t, int, float v) { return softplus100(v + (t ? b1 : b0)); });
             DH_STAMP(it, l, 2);
-            if (TRICKLE != 1 && tv) acc_store_native(acc, act + ((int64_t)l * ntiles + tile) * TILE_F, wave, lane);
+            acc_store_native(acc, act + ((int64_t)l * ntiles + tile) * TILE_F, wave, lane);
             DH_STAMP(it, l, 3);
             __syncthreads();
             DH_STAMP(it, l, 4);
@@ -386,21 +368,16 @@ __global__ __launch_bounds__(256 * TEAMS, 2) void sdf_fwd_train_s_kernel(Sdf16Pt
         const int64_t gp = tile * TM + tid / TPP;
         if (tid % TPP == 0 && gp < npts) sdf_out[gp] = s;
         acc_zero(acc);
-        if (TRICKLE == 1 && tv) {
-            TileTrickle tr{smain, reinterpret_cast<f32x4*>(act + ((int64_t)7 * ntiles + tile) * TILE_F) + woff, wave, lane, 0};
-            gemm_rows_s(acc, smain, LDX, 16, P.main16[8], wave, lane, tr);
-        } else {
-            gemm_rows_s(acc, smain, LDX, 16, P.main16[8], wave, lane);
-        }
+        gemm_rows_s(acc, smain, LDX, 16, P.main16[8], wave, lane);
         const float b0 = P.bias[8][acc_col(wave, 0, lane)], b1 = P.bias[8][acc_col(wave, 1, lane)];
         acc_map(acc, [&](int, int t, int, float v) { return v + (t ? b1 : b0); });
-        if (tv) acc_store_native(acc, feat + tile * TILE_F, wave, lane);
+        acc_store_native(acc, feat + tile * TILE_F, wave, lane);
         __syncthreads();
     }
 }
 
 // K2c, split-on-fetch
-__global__ __launch_bounds__(256, TM == 128 ? 1 : 2) void color_fwd_s_kernel(Col16Ptrs C, const float* __restrict__ pts, const float* __restrict__ dirs,
+__global__ __launch_bounds__(256, 2) void color_fwd_s_kernel(Col16Ptrs C, const float* __restrict__ pts, const float* __restrict__ dirs,
                                                             int n_per_ray, const float* __restrict__ normals,
                                                             const float* __restrict__ feat, int64_t npts,
                                                             float* __restrict__ color, float* __restrict__ cact,
@@ -466,19 +443,7 @@ int launch_sdf_fwd_train(const float* packed, const float* pts, int64_t npts, fl
                          float* eaux, int grid, hipStream_t stream) {
     const int g = grid_for(npts, grid);
     if (arith_fp32()) hipLaunchKernelGGL(sdf_fwd_train_kernel, dim3(g), dim3(256), 0, stream, make_sdf_ptrs(packed), pts, npts, sdf, feat, act, eaux);
-    else {
-        const int64_t ntiles = (npts + TM - 1) / TM;
-        const int g2 = (int)(((ntiles + 1) / 2) < 256 ? ((ntiles + 1) / 2) : 256);
-        const Sdf16Ptrs P = make_sdf16_ptrs(packed);
-        switch (dev_variant(1)) {       // A/B (scripts/ab_stage.py): 0 shipping
-            case 1: hipLaunchKernelGGL((sdf_fwd_train_s_kernel<1, 1>), dim3(g), dim3(256), 0, stream, P, pts, npts, sdf, feat, act, eaux); break;
-            case 2: hipLaunchKernelGGL((sdf_fwd_train_s_kernel<2, 0>), dim3(g2), dim3(512), 0, stream, P, pts, npts, sdf, feat, act, eaux); break;
-            case 3: hipLaunchKernelGGL((sdf_fwd_train_s_kernel<2, 1>), dim3(g2), dim3(512), 0, stream, P, pts, npts, sdf, feat, act, eaux); break;
-            case 4: hipLaunchKernelGGL((sdf_fwd_train_s_kernel<1, 2>), dim3(g), dim3(256), 0, stream, P, pts, npts, sdf, feat, act, eaux); break;
-            case 5: hipLaunchKernelGGL((sdf_fwd_train_s_kernel<1, 3>), dim3(g), dim3(256), 0, stream, P, pts, npts, sdf, feat, act, eaux); break;
-            default: hipLaunchKernelGGL((sdf_fwd_train_s_kernel<1, 0>), dim3(g), dim3(256), 0, stream, P, pts, npts, sdf, feat, act, eaux); break;
-        }
-    }
+    else hipLaunchKernelGGL(sdf_fwd_train_s_kernel, dim3(g), dim3(256), 0, stream, make_sdf16_ptrs(packed), pts, npts, sdf, feat, act, eaux);
     return ok();
 }
 int launch_sdf_grad(const float* packed, const float* pts, int64_t npts, const float* act, float* asave, float* normals,

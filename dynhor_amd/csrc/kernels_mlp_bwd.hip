@@ -24,7 +24,7 @@ enum : int { TP_SDF_B0 = 0, TP_SDF_B8 = 8, TP_W8ROW0_T = 9, TP_W8ROW0_S = 10, TP
 // ------------------------------------------------------------------------------------------------
 // K6: RenderingNetwork backward.  d_colors is wrt the post-sigmoid colour.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, TM == 128 ? 1 : 2) void color_bwd_kernel(ColPtrs C, const float* __restrict__ colors,
+__global__ __launch_bounds__(256, 2) void color_bwd_kernel(ColPtrs C, const float* __restrict__ colors,
                                                             const float* __restrict__ d_colors, int64_t npts,
                                                             const float* __restrict__ cact, float* __restrict__ czbar,
                                                             float* __restrict__ featbar, float* __restrict__ d_normals,
@@ -215,7 +215,7 @@ __global__ __launch_bounds__(256, 1) void color_bwd16_kernel(Col16Ptrs C, const 
 // ------------------------------------------------------------------------------------------------
 // K7a: tangent chain (forward direction) -> t_l, r_l ; colsum(t_8) feeds Wbar_8[0,:]
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, TM == 128 ? 1 : 2) void sdf_tangent_kernel(SdfPtrs P, const float* __restrict__ pts,
+__global__ __launch_bounds__(256, 2) void sdf_tangent_kernel(SdfPtrs P, const float* __restrict__ pts,
                                                               const float* __restrict__ d_normals, int64_t npts,
                                                               const float* __restrict__ act, const float* __restrict__ asave,
                                                               float* __restrict__ t0aux, float* __restrict__ tsave,
@@ -291,7 +291,7 @@ __global__ __launch_bounds__(256, TM == 128 ? 1 : 2) void sdf_tangent_kernel(Sdf
 // ------------------------------------------------------------------------------------------------
 // K7b: backward chain -> zbar_l (l = 7..0), bias-gradient partials, Wbar_8[0,:] partial
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, TM == 128 ? 1 : 2) void sdf_bwd_kernel(SdfPtrs P, const float* __restrict__ d_sdf, int64_t npts,
+__global__ __launch_bounds__(256, 2) void sdf_bwd_kernel(SdfPtrs P, const float* __restrict__ d_sdf, int64_t npts,
                                                           const float* __restrict__ act, const float* __restrict__ rsave,
                                                           const float* __restrict__ featbar, float* __restrict__ zbar,
                                                           float* __restrict__ tpart) {
@@ -371,7 +371,7 @@ __global__ __launch_bounds__(256, TM == 128 ? 1 : 2) void sdf_bwd_kernel(SdfPtrs
 }
 
 // K7a, split-on-fetch
-__global__ __launch_bounds__(256, TM == 128 ? 1 : 2) void sdf_tangent_s_kernel(Sdf16Ptrs P, const float* __restrict__ pts,
+__global__ __launch_bounds__(256, 2) void sdf_tangent_s_kernel(Sdf16Ptrs P, const float* __restrict__ pts,
                                                               const float* __restrict__ d_normals, int64_t npts,
                                                               const float* __restrict__ act, const float* __restrict__ asave,
                                                               float* __restrict__ t0aux, float* __restrict__ tsave,
@@ -451,7 +451,7 @@ __global__ __launch_bounds__(256, TM == 128 ? 1 : 2) void sdf_tangent_s_kernel(S
 }
 
 // K7b, split-on-fetch
-__global__ __launch_bounds__(256, TM == 128 ? 1 : 2) void sdf_bwd_s_kernel(Sdf16Ptrs P, const float* __restrict__ d_sdf, int64_t npts,
+__global__ __launch_bounds__(256, 2) void sdf_bwd_s_kernel(Sdf16Ptrs P, const float* __restrict__ d_sdf, int64_t npts,
                                                           const float* __restrict__ act, const float* __restrict__ rsave,
                                                           const float* __restrict__ featbar, float* __restrict__ zbar,
                                                           float* __restrict__ tpart) {

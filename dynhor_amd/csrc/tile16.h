@@ -145,71 +145,36 @@ __device__ __forceinline__ void tile_prefetch(TileRegs& t, const float* __restri
 // bf16x3_fp32lds_micro.hip measures 233-247 TFLOP/s fp32-equivalent for this chain WITH softplus and write-back,
 // against 218 for the piece-plane image at one workgroup per CU.  No sched_barrier between the fetch/split block and the
 // MFMA block: interleaving them is exactly what is wanted (micro: 247 vs 233 pinned).
-struct NoTrickle { __device__ __forceinline__ void operator()(int) const {} };
-// `side(kc)` runs once per k-chunk inside the loop (default: nothing): the chains use it to trickle the PREVIOUS layer's
-// activation tile from the LDS image to HBM under the MFMAs instead of storing it in one burst after the epilogue.
-// FAKE != 0 (timing experiments only, results are garbage): 1 = no split at all (the fetched bits are used as pieces), i.e. the
-// chain with ZERO split VALU work; 2 = no weight loads either (B fragments held constant).
-template <class Side = NoTrickle, int FAKE = 0>
 __device__ __forceinline__ void gemm_rows_s(f32x16 (&acc)[MT][2], const float* xs, const int ldx, const int nkc,
-                                            const bf16x8* __restrict__ wp, const int wave, const int lane, Side side = Side()) {
+                                            const bf16x8* __restrict__ wp, const int wave, const int lane) {
     const float* xrow = xs + (lane & 31) * ldx + 8 * (lane >> 5);
     const bf16x8* wl = wp + (2 * wave) * 3 * 64 + lane;
     Bf3 a0[MT], b0[2], a1[MT], b1[2];
     const int last = nkc - 1;
     auto fetch = [&](Bf3 (&a)[MT], Bf3 (&b)[2], int kc) {
         kc = kc < last ? kc : last;
-        if (FAKE != 2) {
-            DH_UNROLL for (int t = 0; t < 2; ++t)
-                DH_UNROLL for (int p = 0; p < 3; ++p) b[t].p[p] = wl[((kc * 8 + t) * 3 + p) * 64];
-        }
+        DH_UNROLL for (int t = 0; t < 2; ++t)
+            DH_UNROLL for (int p = 0; p < 3; ++p) b[t].p[p] = wl[((kc * 8 + t) * 3 + p) * 64];
         DH_UNROLL for (int m = 0; m < MT; ++m) {
             const f32x4 lo = *reinterpret_cast<const f32x4*>(xrow + m * 32 * ldx + kc * 16);
             const f32x4 hi = *reinterpret_cast<const f32x4*>(xrow + m * 32 * ldx + kc * 16 + 4);
-            if (FAKE == 0) a[m] = split3(lo, hi);
-            else {
-                a[m].p[0] = __builtin_bit_cast(bf16x8, lo); a[m].p[1] = __builtin_bit_cast(bf16x8, hi);
-                a[m].p[2] = __builtin_bit_cast(bf16x8, lo);
-            }
+            a[m] = split3(lo, hi);
         }
     };
     auto mul = [&](const Bf3 (&a)[MT], const Bf3 (&b)[2]) {
         DH_UNROLL for (int m = 0; m < MT; ++m)
             DH_UNROLL for (int t = 0; t < 2; ++t) acc[m][t] = mfma6(a[m], b[t], acc[m][t]);
     };
-    if (FAKE == 2) {
-        DH_UNROLL for (int t = 0; t < 2; ++t)
-            DH_UNROLL for (int p = 0; p < 3; ++p) { b0[t].p[p] = wl[(t * 3 + p) * 64]; b1[t].p[p] = wl[((8 + t) * 3 + p) * 64]; }
-    }
     fetch(a0, b0, 0);
     _Pragma("unroll 1") for (int kc = 0; kc < nkc; kc += 2) {
         fetch(a1, b1, kc + 1);
-        side(kc);
         mul(a0, b0);
         if (kc + 1 < nkc) {
             fetch(a0, b0, kc + 2);
-            side(kc + 1);
             mul(a1, b1);
         }
     }
 }
-
-// One k-chunk's share of "LDS image -> native HBM tile" (tile.h layout): float4 j of this wave's 16, read back from the
-// fp32 image with four ds_read_b32 (rows 4 apart in a lane pair, conflict free) and stored as one 1 KiB wave store.
-struct TileTrickle {
-    const float* img;      // LDS image of the tile being saved (row stride LDX)
-    f32x4* dst;            // native tile + wave * MT * 8 * 64 + lane
-    int wave, lane, j0;    // j0: first float4 index this GEMM is responsible for
-    __device__ __forceinline__ void operator()(int kc) const {
-        const int j = j0 + kc;
-        if (j >= MT * 8) return;
-        const int m = j >> 3, t = (j >> 2) & 1, r4 = j & 3;
-        const float* src = img + (m * 32 + 8 * r4 + 4 * (lane >> 5)) * LDX + 64 * wave + 32 * t + (lane & 31);
-        f32x4 v;
-        v[0] = src[0]; v[1] = src[LDX]; v[2] = src[2 * LDX]; v[3] = src[3 * LDX];
-        dst[j * 64] = v;
-    }
-};
 
 // 64-wide "aux" output from the fp32 main image (tile.h gemm_auxout), split-on-fetch
 __device__ __forceinline__ void gemm_auxout_s(f32x16 (&acc2)[AUX_NTW], const float* xs, const int nkc,

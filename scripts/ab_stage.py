@@ -1,11 +1,11 @@
-"""Same-box A/B of single MLP stages on the benchmark's own workspace (development tool, round 2).
+"""Single MLP stages timed on the benchmark's own workspace, and the per-phase cycle stamps of a -DDH_STAMPS build
+(development tool; the round-2 A/B variants it was written for are in git history, their numbers in DESIGN.md section 3).
 
-    python scripts/ab_stage.py [--lib dynhor_amd/libdynhor_hip_noslp.so] [--dw-variants 0,1,2,3,4] [--reps 20]
+    python scripts/ab_stage.py [--lib dynhor_amd/libdynhor_hip_stamps.so --stamps] [--reps 20]      # scripts/stamps.sh
 
 Runs a few real training iterations of the bench configuration (2048 rays x 64+64 samples) so that the saved tiles hold real
 data, then re-launches individual C-ABI stages on that workspace, interleaved A/B/A/B, timed with HIP events on the launch
 stream.  Re-launching is idempotent: every stage reads tiles an earlier stage wrote and overwrites its own outputs.
-Also prints the flat gradient's relative difference between variants (must be ~1e-7: same arithmetic, different schedule).
 """
 import argparse, ctypes, json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -15,10 +15,7 @@ sys.path.insert(0, ROOT)
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--lib", type=str, default=None)
-    ap.add_argument("--dw-variants", type=str, default="0")
     ap.add_argument("--reps", type=int, default=20)
-    ap.add_argument("--stage-variants", type=str, default="",
-                    help="dev_variant key:stage:v0,v1,... triples separated by ';', e.g. '1:sdf_forward:0,1,2,3'")
     ap.add_argument("--out", type=str, default=None)
     ap.add_argument("--stamps", action="store_true", help="the library is a -DDH_STAMPS build: dump per-phase cycle stamps")
     args = ap.parse_args()
@@ -29,12 +26,6 @@ def main():
     from dynhor_amd.runner import Runner
     from dynhor_amd.renderer import _p
     L = _lib.lib()
-    try:
-        L.dh_dev_variant.restype = ctypes.c_int
-        L.dh_dev_variant.argtypes = [ctypes.c_int, ctypes.c_int]
-        have_dev = True
-    except AttributeError:
-        have_dev = False
     conf = {"seq_name": "ab", "exp_name": "ab", "data_info": {"synthetic": {"n_frames": 8, "H": 512, "W": 512, "seed": 4321}},
             "train": {"batch_size": 2048, "normal_weight": 0.05, "report_freq": 10 ** 9, "save_freq": 10 ** 9, "val_freq": 0}}
     r = Runner(conf=conf, device="cuda:0", exp_root="/tmp/dh_ab")
@@ -84,52 +75,8 @@ def main():
             _lib.check(fn())
         res["stages"][name] = time_stage(fn, args.reps)
         print(name, res["stages"][name], flush=True)
-    # weight gradients: dev variants interleaved
-    variants = [int(v) for v in args.dw_variants.split(",")]
-    dw = {v: [] for v in variants}
-    grads = {}
-    for rnd in range(4):
-        for v in variants:
-            if have_dev:
-                L.dh_dev_variant(0, v)
-            _lib.check(stages["weight_grads_gemm"]())
-            dw[v].append(time_stage(stages["weight_grads_gemm"], max(args.reps // 4, 3)))
-            if rnd == 0:
-                g = torch.zeros(st.n, device="cuda:0")       # the fold leaves the variance slot alone
-                _lib.check(L.dh_weight_grads_fold(_p(packed), _p(st.flat), P, _p(s.ws), _p(g), stream))
-                grads[v] = g
-    if have_dev:
-        L.dh_dev_variant(0, 0)
-    res["weight_grads_gemm"] = {}
-    for v in variants:
-        med = sorted(x["median_ms"] for x in dw[v])
-        rel = float((grads[v] - grads[variants[0]]).norm() / grads[variants[0]].norm())
-        res["weight_grads_gemm"][str(v)] = {"median_ms_rounds": med, "grad_rel_diff_vs_first": rel,
-                                            "finite": bool(torch.isfinite(grads[v]).all())}
-        print("dW variant", v, res["weight_grads_gemm"][str(v)], flush=True)
-    # chain-kernel variants (dev_variant keys >= 1): interleaved rounds, outputs compared bit for bit through the workspace
-    res["stage_variants"] = {}
-    for spec in [x for x in args.stage_variants.split(";") if x]:
-        key, stage, vs = spec.split(":")
-        key, vs = int(key), [int(v) for v in vs.split(",")]
-        inf_f, fwd_f, tot_f = _lib.workspace_floats(P)
-        tm = {v: [] for v in vs}
-        snap = {}
-        for rnd in range(4):
-            for v in vs:
-                L.dh_dev_variant(key, v)
-                _lib.check(stages[stage]())
-                tm[v].append(time_stage(stages[stage], max(args.reps // 4, 3))["median_ms"])
-                if rnd == 0:
-                    torch.cuda.synchronize()
-                    # checksum of the whole saved-tile workspace (minus the dW slabs) + the stage's plain outputs
-                    ws = s.ws[:tot_f - (256 + 1) * sum(8 * nb * 1024 for nb in [2, 8, 8, 8, 8, 8, 8, 8, 2, 8, 8, 2, 8, 8, 8])]
-                    snap[v] = (ws.double().sum().item(), ws.abs().double().sum().item(), s.sdf.double().sum().item(), s.normals.double().sum().item())
-        L.dh_dev_variant(key, 0)
-        _lib.check(stages[stage]())
-        res["stage_variants"][spec] = {str(v): {"median_ms_rounds": sorted(tm[v]), "same_outputs_as_first": snap[v] == snap[vs[0]]} for v in vs}
-        for v in vs:
-            print(stage, "variant", v, res["stage_variants"][spec][str(v)], flush=True)
+    res["stages"]["weight_grads_gemm"] = time_stage(stages["weight_grads_gemm"], args.reps)
+    print("weight_grads_gemm", res["stages"]["weight_grads_gemm"], flush=True)
     if args.stamps:
         import numpy as np
         n = 512 * 4 * 2 * 10 * 8
