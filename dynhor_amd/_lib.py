@@ -60,6 +60,7 @@ SIGNATURES = {
     "dh_render_scan_fwd": (_i32, [_vp] * 7 + [_f32, _f32, _vp, _i64, _i32] + [_vp] * 9),
     "dh_render_scan_bwd": (_i32, [_vp] * 7 + [_f32, _f32, _vp, _i64, _i32] + [_vp] * 11),
     "dh_neus_loss": (_i32, [_vp] * 6 + [_i64, _f32, _f32, _f32] + [_vp] * 6),
+    "dh_corr_loss": (_i32, [_vp] * 7 + [_i32, _vp, _i64, _i32, _f32, _f32, _f32, _vp, _vp, _vp, _vp]),
 }
 
 

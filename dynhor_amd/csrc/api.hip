@@ -269,6 +269,16 @@ int dh_neus_loss(const float* color, const float* weight_sum, const float* norma
                        d_color, d_weight_sum, d_normal_map, eik_coef, static_cast<hipStream_t>(stream));
 }
 
+int dh_corr_loss(const float* rays_o, const float* rays_d, const float* z, const float* weights, const float* corr,
+                 const float* R_all, const float* T_all, int n_frames, const float* K, int64_t B, int n, float sample_dist,
+                 float delta_px, float corr_weight, float* stats, float* residual_px, float* d_weights, void* stream) {
+    if (B <= 0 || n <= 0 || n_frames <= 0 || !(delta_px > 0.f)) return DH_ERR_BAD_ARG;
+    if (!rays_o || !rays_d || !z || !weights || !corr || !R_all || !T_all || !K || !stats || !residual_px || !d_weights)
+        return DH_ERR_BAD_ARG;
+    return launch_corr_loss(rays_o, rays_d, z, weights, corr, R_all, T_all, n_frames, K, B, n, sample_dist, delta_px, corr_weight,
+                            stats, residual_px, d_weights, static_cast<hipStream_t>(stream));
+}
+
 int64_t dh_hashgrid_entries(void) { return hashgrid_entries(); }
 
 int dh_hashgrid_level(int level, float* scale, uint32_t* resolution, uint32_t* offset, uint32_t* dense) {

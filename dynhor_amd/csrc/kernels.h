@@ -49,6 +49,10 @@ int launch_loss(const float* color, const float* wsum, const float* nmap, const 
                 const float* R, int64_t B, float igr_w, float mask_w, float normal_w, float* stats, float* d_color,
                 float* d_wsum, float* d_nmap, float* eik_coef, hipStream_t st);
 
+int launch_corr_loss(const float* rays_o, const float* rays_d, const float* z, const float* weights, const float* corr,
+                     const float* R_all, const float* T_all, int n_frames, const float* K, int64_t B, int n, float sample_dist,
+                     float delta_px, float corr_w, float* stats, float* residual_px, float* d_weights, hipStream_t st);
+
 // backward chains (kernels_mlp_bwd.hip) and weight gradients (dw.hip)
 int launch_color_bwd(const float* packed, const float* colors, const float* d_colors, int64_t npts, const float* cact,
                      float* czbar, float* featbar, float* d_normals, float* tpart, int grid, hipStream_t st);

@@ -95,11 +95,98 @@ __global__ __launch_bounds__(1024) void loss_kernel(const float* __restrict__ co
     }
 }
 
+// ---------------------------------------------------------------- n4: dense-correspondence reprojection loss (one workgroup)
+// Specification: oracle/neus_oracle.py:correspondence_loss (the reference names only the input folder,
+// README.md:43).  corr [B,4] = (u_j, v_j, certainty, frame_j).  Pass 1: one ray per thread -> expected depth t^ = sum_k w_k m_k,
+// x = o + t^ d, reprojection into frame j, Huber cost and d cost / d t^ (un-normalised, kept in residual_px's neighbour
+// buffer dt); fixed-order block sums -> deterministic.  Pass 2: d_weights[r,k] = dt[r] / (sum c v + 1e-5) * m_k, coalesced.
+__global__ __launch_bounds__(1024) void corr_loss_kernel(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+                                                         const float* __restrict__ z, const float* __restrict__ weights,
+                                                         const float* __restrict__ corr, const float* __restrict__ R_all,
+                                                         const float* __restrict__ T_all, int n_frames,
+                                                         const float* __restrict__ K, int64_t B, int n, float sample_dist,
+                                                         float delta_px, float corr_w, float* __restrict__ stats,
+                                                         float* __restrict__ residual_px, float* __restrict__ d_weights) {
+    __shared__ float s_red[16];
+    const int tid = threadIdx.x;
+    const float fx = K[0], fy = K[4], cx = K[2], cy = K[5];
+    const float delta = delta_px / fx;
+    float a_cv = 0.f, a_l = 0.f, a_r = 0.f;
+    for (int64_t b = tid; b < B; b += blockDim.x) {
+        const float conf = corr[b * 4 + 2];
+        float dt = 0.f, res = 0.f;
+        const int j = (int)corr[b * 4 + 3];
+        if (conf > 0.f && j >= 0 && j < n_frames) {
+            float depth = 0.f;
+            const float* zr = z + b * n;
+            const float* wr = weights + b * n;
+            for (int k = 0; k < n; ++k) {
+                const float dist = (k + 1 < n) ? zr[k + 1] - zr[k] : sample_dist;
+                depth = fmaf(wr[k], zr[k] + 0.5f * dist, depth);
+            }
+            float x[3], y[3], g[3];
+            DH_UNROLL for (int c = 0; c < 3; ++c) x[c] = rays_o[b * 3 + c] + depth * rays_d[b * 3 + c];
+            const float* Rj = R_all + (int64_t)j * 9;
+            DH_UNROLL for (int i = 0; i < 3; ++i) {
+                y[i] = Rj[i * 3] * x[0] + Rj[i * 3 + 1] * x[1] + Rj[i * 3 + 2] * x[2] + T_all[j * 3 + i];
+                g[i] = Rj[i * 3] * rays_d[b * 3] + Rj[i * 3 + 1] * rays_d[b * 3 + 1] + Rj[i * 3 + 2] * rays_d[b * 3 + 2];
+            }
+            if (y[2] > 1e-3f) {
+                const float iz = 1.f / y[2];
+                const float eu = fx * y[0] * iz + cx - corr[b * 4 + 0], ev = fy * y[1] * iz + cy - corr[b * 4 + 1];
+                const float e2 = eu * eu + ev * ev;
+                const float en = sqrtf(e2 + 1e-24f);
+                const float sres = en / fx;
+                res = en;
+                const float rho = sres <= delta ? sres * sres / (2.f * delta) : sres - 0.5f * delta;
+                const float dpu = fx * (g[0] * y[2] - y[0] * g[2]) * iz * iz, dpv = fy * (g[1] * y[2] - y[1] * g[2]) * iz * iz;
+                const float ep = eu * dpu + ev * dpv;                    // e . d pi / d t^
+                const float drho = sres <= delta ? ep / (fx * fx * delta) : ep / (en * fx);
+                a_cv += conf; a_l += conf * rho; a_r += conf * en;
+                dt = conf * drho;
+            }
+        }
+        residual_px[b] = res;
+        d_weights[b * n] = dt;          // parked in the ray's first slot until the normaliser is known
+    }
+    const float cv = block_sum(a_cv, s_red), ls = block_sum(a_l, s_red), rs = block_sum(a_r, s_red);
+    const float inv = corr_w / (cv + 1e-5f);
+    __syncthreads();
+    __shared__ float s_dt[1024];
+    for (int64_t b0 = 0; b0 < B; b0 += blockDim.x) {      // a chunk of 1024 rays at a time: coefficients through LDS
+        const int64_t b = b0 + tid;
+        s_dt[tid] = b < B ? d_weights[b * n] * inv : 0.f;
+        __syncthreads();
+        const int64_t nb = (B - b0) < (int64_t)blockDim.x ? (B - b0) : (int64_t)blockDim.x;
+        for (int64_t e = tid; e < nb * n; e += blockDim.x) {
+            const int64_t r = e / n; const int k = (int)(e % n);
+            const float* zr = z + (b0 + r) * n;
+            const float dist = (k + 1 < n) ? zr[k + 1] - zr[k] : sample_dist;
+            d_weights[(b0 + r) * n + k] = s_dt[r] * (zr[k] + 0.5f * dist);
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        stats[0] = ls / (cv + 1e-5f);            // L_corr (unweighted)
+        stats[1] = cv;                           // sum of certainties of the valid matches
+        stats[2] = rs / (cv + 1e-5f);            // certainty-weighted mean reprojection residual, pixels
+        stats[3] = corr_w * stats[0];            // its contribution to the total loss
+    }
+}
+
 int launch_loss(const float* color, const float* wsum, const float* nmap, const float* eik, const float* rays,
                 const float* R, int64_t B, float igr_w, float mask_w, float normal_w, float* stats, float* d_color,
                 float* d_wsum, float* d_nmap, float* eik_coef, hipStream_t st) {
     hipLaunchKernelGGL(loss_kernel, dim3(1), dim3(1024), 0, st, color, wsum, nmap, eik, rays, R, B, igr_w, mask_w, normal_w,
                        stats, d_color, d_wsum, d_nmap, eik_coef);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+int launch_corr_loss(const float* rays_o, const float* rays_d, const float* z, const float* weights, const float* corr,
+                     const float* R_all, const float* T_all, int n_frames, const float* K, int64_t B, int n, float sample_dist,
+                     float delta_px, float corr_w, float* stats, float* residual_px, float* d_weights, hipStream_t st) {
+    hipLaunchKernelGGL(corr_loss_kernel, dim3(1), dim3(1024), 0, st, rays_o, rays_d, z, weights, corr, R_all, T_all, n_frames, K, B, n,
+                       sample_dist, delta_px, corr_w, stats, residual_px, d_weights);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 

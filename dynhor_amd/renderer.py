@@ -322,10 +322,13 @@ class NeuSRenderer:
     # ------------------------------------------------------------------ fused training step (Runner hot loop)
     @torch.no_grad()
     def train_step_core(self, rays, near, far, R, cos_anneal_ratio, igr_weight=0.1, mask_weight=0.1, normal_weight=0.0,
-                        background_rgb=None, t_rand=None):
+                        background_rgb=None, t_rand=None, corr=None, corr_weight=0.0, corr_frames=None, corr_delta_px=4.0):
         """rays [B,14] (dh_gen_rays layout), R [3,3] object->camera of the frame.  Returns stats [8] on device:
         loss, colour, eikonal, mask, normal, psnr, sum(obj*keep), sum(keep); leaves the flat gradient in
-        store.grad_flat.  No host synchronisation."""
+        store.grad_flat.  No host synchronisation.
+        Full loss stack (BASELINE.json configs[4]): corr [B,4] = (u_j, v_j, certainty, frame_j) per ray with
+        corr_frames = (R_all [F,3,3], T_all [F,3], K [3,3]) adds corr_weight * the dense-correspondence reprojection loss
+        (dh_corr_loss); its statistics land in self.last_corr_stats [4] and self.last_corr_residual_px [B]."""
         L = _lib.lib()
         dev = rays.device
         B = rays.shape[0]
@@ -343,6 +346,18 @@ class NeuSRenderer:
         _lib.check(L.dh_neus_loss(_p(s.color), _p(s.wsum), _p(s.nmap), _p(s.eik), _p(rays), _p(Rc), B, float(igr_weight),
                                   float(mask_weight), float(normal_weight), _p(stats), _p(d_color), _p(d_wsum),
                                   _p(d_nmap), _p(eik_coef), _lib.stream()))
-        self._backward_core(s, d_color, d_wsum, None, None, d_nmap, eik_coef)
+        d_weights = None
+        if corr is not None and corr_weight > 0.0:
+            R_all, T_all, K = corr_frames
+            cstats = torch.empty(4, device=dev)
+            resid = torch.empty(B, device=dev)
+            d_weights = torch.empty(B, s.n, device=dev)
+            _lib.check(L.dh_corr_loss(_p(rays_o), _p(rays_d), _p(z_vals), _p(s.weights), _p(corr.contiguous()),
+                                      _p(R_all.contiguous()), _p(T_all.contiguous()), int(R_all.shape[0]), _p(K.contiguous()),
+                                      B, s.n, s.sample_dist, float(corr_delta_px), float(corr_weight), _p(cstats), _p(resid),
+                                      _p(d_weights), _lib.stream()))
+            stats[0] += cstats[3]
+            self.last_corr_stats, self.last_corr_residual_px = cstats, resid
+        self._backward_core(s, d_color, d_wsum, d_weights, None, d_nmap, eik_coef)
         self.last_state = s
         return stats

@@ -29,7 +29,9 @@ DEFAULT_CONF = {
     "train": {"learning_rate": 5e-4, "learning_rate_alpha": 0.05, "end_iter": 300000, "batch_size": 2048,
               "warm_up_end": 5000, "anneal_end": 50000, "igr_weight": 0.1, "mask_weight": 0.1, "normal_weight": 0.0,
               "save_freq": 10000, "val_freq": 2500, "report_freq": 100, "use_white_bkgd": False, "keep_only": False,
-              "seed": 1234, "ray_seed": 4321},
+              "seed": 1234, "ray_seed": 4321,
+              # full loss stack (BASELINE.json configs[4]): dense-correspondence reprojection term, DESIGN.md section 9
+              "corr_weight": 0.0, "corr_fraction": 0.25, "corr_delta_px": 4.0, "corr_vote_freq": 0, "corr_vote_tau_px": 8.0},
     # family "neus": the 8x256 / 4x256 fp32 MLPs (BASELINE.json configs[1]); "hash": hash-grid + shallow MLPs (configs[3])
     "model": {"family": "neus", "sdf_network": {}, "variance_network": {"init_val": 0.3}, "rendering_network": {},
               "hash_sdf_network": {}, "sh_rendering_network": {},
@@ -72,6 +74,8 @@ class Runner:
         self.igr_weight = tr["igr_weight"]; self.mask_weight = tr["mask_weight"]; self.normal_weight = tr["normal_weight"]
         self.save_freq = tr["save_freq"]; self.val_freq = tr["val_freq"]; self.report_freq = tr["report_freq"]
         self.use_white_bkgd = tr["use_white_bkgd"]; self.keep_only = tr["keep_only"]
+        self.corr_weight = tr["corr_weight"]; self.corr_fraction = tr["corr_fraction"]; self.corr_delta_px = tr["corr_delta_px"]
+        self.corr_vote_freq = tr["corr_vote_freq"]; self.corr_vote_tau_px = tr["corr_vote_tau_px"]
         self.iter_step = 0
 
         if dataset is None:
@@ -137,7 +141,14 @@ class Runner:
     # ------------------------------------------------------------------ one iteration (the hot loop)
     def train_iteration(self):
         frame = self.frame_for_slot(schedules.frame_slot(self.iter_step, self.rank, self.world))
-        rays = self.dataset.gen_random_rays_at(frame, self.batch_size, keep_only=self.keep_only, generator=self.ray_gen)
+        corr = None
+        if self.corr_weight > 0.0 and self.dataset.corr is not None:
+            if self.corr_vote_freq and self.iter_step > 0 and self.iter_step % self.corr_vote_freq == 0:
+                self.vote_correspondences()
+            rays, corr, _ = self.dataset.gen_corr_rays_at(frame, self.batch_size, int(self.batch_size * self.corr_fraction),
+                                                         generator=self.ray_gen)
+        else:
+            rays = self.dataset.gen_random_rays_at(frame, self.batch_size, keep_only=self.keep_only, generator=self.ray_gen)
         near, far = self.dataset._last_near_far
         self._last_rays = rays
         bg = torch.ones(3, device=self.device) if self.use_white_bkgd else None
@@ -145,7 +156,9 @@ class Runner:
         t_rand = torch.rand([rays.shape[0], 1], device=self.device, generator=self.ray_gen) if self.renderer.perturb > 0 else None
         stats = self.renderer.train_step_core(rays, near, far, self.dataset.R[frame], self.get_cos_anneal_ratio(),
                                               self.igr_weight, self.mask_weight, self.normal_weight, background_rgb=bg,
-                                              t_rand=t_rand)
+                                              t_rand=t_rand, corr=corr, corr_weight=self.corr_weight,
+                                              corr_frames=self.dataset.corr_frames() if corr is not None else None,
+                                              corr_delta_px=self.corr_delta_px)
         grad = self.store.grad_flat
         dh_dist.allreduce_sum_(grad)                             # RCCL over xGMI: one 3.2 MB bucket
         lr = self.current_lr()          # 0 at iter_step 0, as upstream (update_learning_rate() runs before the loop)
@@ -169,6 +182,8 @@ class Runner:
         v = dh_dist.mean_stats(stats).tolist()
         rec = {"iter": self.iter_step, "Loss/loss": v[0], "Loss/color_loss": v[1], "Loss/eikonal_loss": v[2],
                "Loss/mask_loss": v[3], "Loss/normal_loss": v[4], "Statistics/psnr": v[5],
+               **({"Loss/corr_loss": float(self.renderer.last_corr_stats[0]), "Statistics/corr_residual_px": float(self.renderer.last_corr_stats[2])}
+                  if self.corr_weight > 0.0 and getattr(self.renderer, "last_corr_stats", None) is not None else {}),
                "Statistics/s_val": float(1.0 / self.store.inv_s().item()), "lr": self.current_lr()}
         st = getattr(self.renderer, "last_state", None)
         if st is not None and getattr(self, "_last_rays", None) is not None:
@@ -182,6 +197,36 @@ class Runner:
             with open(os.path.join(self.base_exp_dir, "scalars.jsonl"), "a") as f:
                 f.write(json.dumps(rec) + "\n")
         return rec
+
+    @torch.no_grad()
+    def vote_correspondences(self, chunk=8192):
+        """Outlier voting over ALL matches with the current geometry (forward-only render of every matched ray, residuals from
+        dh_corr_loss, then Dataset.vote_correspondences).  Every rank evaluates the same matches with the same weights, so
+        the certainties stay identical across ranks without a collective."""
+        from . import _lib
+        from .renderer import _p
+        ds, ren = self.dataset, self.renderer
+        res = torch.full((ds.corr.shape[0],), float("nan"), device=self.device)
+        R_all, T_all, K = ds.corr_frames()
+        for f, (lo, hi) in ds._corr_range.items():
+            for s0 in range(lo, hi, chunk):
+                m = ds.corr[s0:min(s0 + chunk, hi)]
+                B = m.shape[0]
+                rays = ds.gen_rays_at_pixels(f, m[:, 0].long(), m[:, 1].long())
+                near, far = ds._last_near_far
+                o, d = rays[:, :3].contiguous(), rays[:, 3:6].contiguous()
+                z = ren.sample_z(o, d, near, far, perturb_overwrite=0)
+                st = ren._forward_core(o, d, z, self.get_cos_anneal_ratio(), None, want_nmap=False, infer_only=True)
+                corr = torch.cat([m[:, 2:4], torch.ones(B, 1, device=self.device), m[:, 5:6]], -1).contiguous()
+                cst = torch.empty(4, device=self.device); r = torch.empty(B, device=self.device)
+                dw = torch.empty(B, st.n, device=self.device)
+                _lib.check(_lib.lib().dh_corr_loss(_p(o), _p(d), _p(z), _p(st.weights), _p(corr), _p(R_all), _p(T_all),
+                                                  int(R_all.shape[0]), _p(K), B, st.n, st.sample_dist, float(self.corr_delta_px), 1.0,
+                                                  _p(cst), _p(r), _p(dw), _lib.stream()))
+                # rays that render (almost) nothing have no surface estimate yet: leave them un-voted
+                res[s0:s0 + B] = torch.where(st.wsum.view(-1) > 0.5, r, torch.full_like(r, float("nan")))
+        self.last_vote = ds.vote_correspondences(res, tau_px=self.corr_vote_tau_px)
+        return self.last_vote
 
     # ------------------------------------------------------------------ checkpoints (App. A.8 layout)
     def save_checkpoint(self):

@@ -118,6 +118,77 @@ def make_sequence(n_frames=64, H=512, W=512, seed=4321, device="cpu", hand=True,
     return {"rgb": rgb, "label": label, "normal": normal, "R": R.to(dev), "T": T.to(dev), "K": K.to(dev)}
 
 
+@torch.no_grad()
+def make_correspondences(frames: dict, n_per_pair=2048, offsets=(1, 2, 5), noise_px=0.5, outlier_frac=0.1, seed=99):
+    """Synthetic stand-in for the reference's `correspondence_infos` (README.md:43: dense DKM matches): for every frame i and
+    partner j = i + offset, pixels of i on the visible object (label 1) are sphere-traced to the analytic surface and
+    projected into j; matches whose surface point faces camera j and lands on j's visible object are kept, their partner
+    pixel gets Gaussian noise, and a fraction is replaced by gross outliers (random pixel of j) -- what the outlier voting
+    is for.  Returns a list of dicts {i, j, kpts0 [M,2] (integer pixel of i, float32), kpts1 [M,2], conf [M]} on the CPU."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    lab = frames["label"]
+    dev = lab.device
+    F_, H, W = lab.shape
+    R, T, K = frames["R"].to(dev), frames["T"].reshape(-1, 3).to(dev), frames["K"].to(dev)
+    Kinv = torch.inverse(K)
+    out = []
+    for i in range(F_):
+        idx = (lab[i].reshape(-1) == 1).nonzero().reshape(-1)
+        if idx.numel() == 0:
+            continue
+        for off in offsets:
+            j = (i + off) % F_
+            if j == i:
+                continue
+            sel = idx[torch.randint(0, idx.numel(), (n_per_pair,), generator=g).to(dev)]
+            px, py = (sel % W).float(), (sel // W).float()
+            dcam = torch.stack([px, py, torch.ones_like(px)], -1) @ Kinv.T
+            dcam = dcam / torch.linalg.norm(dcam, dim=-1, keepdim=True)
+            d = dcam @ R[i]
+            o = (-(T[i] @ R[i])).expand_as(d)
+            t = (-(o * d).sum(-1) - 0.75).clone()
+            for _ in range(64):
+                sdf = scene_sdf(o + d * t[:, None])
+                t = torch.where(sdf < 5e-4, t, t + sdf.clamp(min=1e-4)).clamp(max=6.0)
+            x = o + d * t[:, None]
+            n = _normal(x)
+            cam_j = -(T[j] @ R[j])
+            facing = (n * torch.nn.functional.normalize(cam_j - x, dim=-1)).sum(-1) > 0.15
+            y = x @ R[j].T + T[j]
+            u = K[0, 0] * y[:, 0] / y[:, 2] + K[0, 2]
+            v = K[1, 1] * y[:, 1] / y[:, 2] + K[1, 2]
+            ui, vi = u.round().long(), v.round().long()
+            inside = (ui >= 0) & (ui < W) & (vi >= 0) & (vi < H) & (y[:, 2] > 0.1)
+            vis = torch.zeros_like(inside)
+            vis[inside] = lab[j][vi[inside], ui[inside]] == 1
+            keep = facing & inside & vis & (scene_sdf(x) < 2e-3)
+            k0 = torch.stack([px, py], -1)[keep].cpu()
+            k1 = torch.stack([u, v], -1)[keep].cpu()
+            m = k0.shape[0]
+            if m == 0:
+                continue
+            k1 = k1 + noise_px * torch.randn(m, 2, generator=g)
+            conf = 0.6 + 0.4 * torch.rand(m, generator=g)
+            bad = torch.rand(m, generator=g) < outlier_frac
+            k1[bad] = torch.stack([torch.rand(int(bad.sum()), generator=g) * (W - 1), torch.rand(int(bad.sum()), generator=g) * (H - 1)], -1)
+            conf[bad] = 0.3 + 0.6 * torch.rand(int(bad.sum()), generator=g)
+            out.append({"i": i, "j": j, "kpts0": k0.float(), "kpts1": k1.float(), "conf": conf.float(), "is_outlier": bad})
+    return out
+
+
+def write_correspondences_to_disk(matches, dataroot: str, stems=None):
+    """<dataroot>/correspondence_infos/<stem_i>_<stem_j>.npz with kpts0 [M,2], kpts1 [M,2] (pixels x, y) and conf [M] -- the
+    folder name is the reference's (README.md:43); the file layout inside it is this build's (the reference releases none)."""
+    import os
+    import numpy as np
+    d = os.path.join(dataroot, "correspondence_infos")
+    os.makedirs(d, exist_ok=True)
+    for m in matches:
+        si = stems[m["i"]] if stems else "%04d" % m["i"]
+        sj = stems[m["j"]] if stems else "%04d" % m["j"]
+        np.savez(os.path.join(d, f"{si}_{sj}.npz"), kpts0=m["kpts0"].numpy(), kpts1=m["kpts1"].numpy(), conf=m["conf"].numpy())
+
+
 def write_sequence_to_disk(frames: dict, dataroot: str, pose_dir: str | None = None, ext: str = "png"):
     """Write a sequence in the reference's data convention (README.md:27-45; ObjTracker/run.py:74-88,165-179):
     <dataroot>/rgb/%04d.<ext>, sam_seg/%04d.png (channel 1 == 255 object, last channel == 255 hand),

@@ -158,6 +158,20 @@ int dh_neus_loss(const float* color, const float* weight_sum, const float* norma
                  const float* rays, const float* R, int64_t B, float igr_weight, float mask_weight, float normal_weight,
                  float* stats, float* d_color, float* d_weight_sum, float* d_normal_map, float* eik_coef, void* stream);
 
+/* Dense-correspondence reprojection term of the full loss stack (BASELINE.json configs[4]; reference README.md:43 names the
+ * input folder `correspondence_infos` "obtained using DKM for reconstruction and outlier-voting" and nothing else, so the form
+ * is this build's specification -- oracle/neus_oracle.py:correspondence_loss, DESIGN.md section 9, parity unpinned):
+ *   corr [B,4] = (u_j, v_j, certainty, frame_j) per ray, certainty 0 = no match; poses x_cam = R x_obj + T of all n_frames
+ *   frames (reference ObjTracker/run.py:166), K [3,3] row-major (run.py:119-123).
+ *   t^ = sum_k weights[r,k] m_k (m = mid-point depths of z as in dh_render_scan_fwd), x = o + t^ d, pi = K (R_j x + T_j),
+ *   s = |pi - (u_j,v_j)| / fx, rho = Huber(s; delta_px / fx), L = sum c v rho / (sum c v + 1e-5), v = [depth in camera j > 1e-3].
+ * stats[4] = L, sum c v, certainty-weighted mean residual in pixels, corr_weight * L.  residual_px [B] (0 for rays without a
+ * valid match) feeds the outlier voting (host side).  d_weights [B,n] = d (corr_weight * L) / d weights, written for EVERY ray
+ * (zeros where there is no match): pass it to dh_render_scan_bwd as d_weights. */
+int dh_corr_loss(const float* rays_o, const float* rays_d, const float* z, const float* weights, const float* corr,
+                 const float* R_all, const float* T_all, int n_frames, const float* K, int64_t B, int n, float sample_dist,
+                 float delta_px, float corr_weight, float* stats, float* residual_px, float* d_weights, void* stream);
+
 /* ---- optimiser -----------------------------------------------------------------------------------------
  * torch.optim.Adam step (upstream Runner uses Adam, App. A.8; the reference's own optimisers are Adam too:
  * ObjTracker/pose_initializtion.py:346, jointopt.py:135-141) fused over the flat vector; step counts from 1;
