@@ -31,6 +31,8 @@ SIGNATURES = {
     "dh_color_backward": (_i32, [_vp, _vp, _vp, _i64, _vp, _vp, _vp]),
     "dh_sdf_tangent": (_i32, [_vp, _vp, _vp, _i64, _vp, _vp]),
     "dh_sdf_backward": (_i32, [_vp, _vp, _i64, _vp, _vp]),
+    "dh_color_backward_rays": (_i32, [_vp, _vp, _vp, _vp, _i32, _i64, _vp, _vp, _vp, _vp, _vp]),
+    "dh_sdf_backward_rays": (_i32, [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp]),
     "dh_weight_grads_gemm": (_i32, [_i64, _vp, _vp]),
     "dh_weight_grads_fold": (_i32, [_vp, _vp, _i64, _vp, _vp, _vp]),
     "dh_mlp_backward": (_i32, [_vp, _vp, _vp, _i64] + [_vp] * 7),
@@ -59,6 +61,7 @@ SIGNATURES = {
     "dh_midpoints": (_i32, [_vp] * 3 + [_i64, _i32, _f32, _vp, _vp]),
     "dh_render_scan_fwd": (_i32, [_vp] * 7 + [_f32, _f32, _vp, _i64, _i32] + [_vp] * 9),
     "dh_render_scan_bwd": (_i32, [_vp] * 7 + [_f32, _f32, _vp, _i64, _i32] + [_vp] * 11),
+    "dh_render_scan_bwd_rays": (_i32, [_vp] * 7 + [_f32, _f32, _vp, _i64, _i32] + [_vp] * 12),
     "dh_neus_loss": (_i32, [_vp] * 6 + [_i64, _f32, _f32, _f32] + [_vp] * 6),
     "dh_corr_loss": (_i32, [_vp] * 7 + [_i32, _vp, _i64, _i32, _f32, _f32, _f32, _vp, _vp, _vp, _vp]),
 }

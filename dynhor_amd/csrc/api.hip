@@ -100,7 +100,8 @@ int dh_sdf_gradient(const float* packed, const float* pts, int64_t npts, float* 
     if (npts <= 0) return npts == 0 ? DH_OK : DH_ERR_BAD_ARG;
     if (!packed || !pts || !ws || !normals || misaligned16(packed) || misaligned16(ws)) return DH_ERR_BAD_ARG;
     const Workspace w = carve_workspace(ws, npts);
-    return launch_sdf_grad(packed, pts, npts, w.act, w.asave, normals, save, DEFAULT_GRID, static_cast<hipStream_t>(stream));
+    if (save < 0 || save > 2) return DH_ERR_BAD_ARG;
+    return launch_sdf_grad(packed, pts, npts, w.act, w.asave, normals, save, w.gesave, DEFAULT_GRID, static_cast<hipStream_t>(stream));
 }
 
 int dh_color_forward(const float* packed, const float* pts, const float* dirs, int n_per_ray, const float* normals,
@@ -145,6 +146,25 @@ int dh_sdf_backward(const float* packed, const float* d_sdf, int64_t npts, float
     const Workspace w = carve_workspace(ws, npts);
     return launch_sdf_bwd(packed, d_sdf, npts, w.act, w.rsave, w.featbar, w.zbar, w.tpart, DEFAULT_GRID,
                           static_cast<hipStream_t>(stream));
+}
+
+int dh_color_backward_rays(const float* packed, const float* colors, const float* d_colors, const float* dirs, int n_per_ray,
+                           int64_t npts, float* ws, float* d_normals, float* d_pts, float* d_dirs_pts, void* stream) {
+    if (npts <= 0 || n_per_ray <= 0) return DH_ERR_BAD_ARG;
+    if (!packed || !colors || !d_colors || !dirs || !ws || !d_normals || !d_pts || !d_dirs_pts || misaligned16(packed) || misaligned16(ws))
+        return DH_ERR_BAD_ARG;
+    const Workspace w = carve_workspace(ws, npts);
+    return launch_color_bwd_rays(packed, colors, d_colors, dirs, n_per_ray, npts, w.cact, w.czbar, w.featbar, d_normals, w.tpart,
+                                 d_pts, d_dirs_pts, DEFAULT_GRID, static_cast<hipStream_t>(stream));
+}
+
+int dh_sdf_backward_rays(const float* packed, const float* d_sdf, const float* pts, const float* d_normals, int64_t npts,
+                         float* ws, float* d_pts, void* stream) {
+    if (npts <= 0) return DH_ERR_BAD_ARG;
+    if (!packed || !d_sdf || !pts || !d_normals || !ws || !d_pts || misaligned16(packed) || misaligned16(ws)) return DH_ERR_BAD_ARG;
+    const Workspace w = carve_workspace(ws, npts);
+    return launch_sdf_bwd_rays(packed, d_sdf, pts, d_normals, npts, w.act, w.rsave, w.featbar, w.gesave, w.zbar, w.tpart, d_pts,
+                               DEFAULT_GRID, static_cast<hipStream_t>(stream));
 }
 
 int dh_weight_grads_gemm(int64_t npts, float* ws, void* stream) {
@@ -246,7 +266,22 @@ int dh_render_scan_bwd(const float* rays_o, const float* rays_d, const float* z,
         !d_normals || !d_colors || !d_inv_s) return DH_ERR_BAD_ARG;
     return launch_render_bwd(rays_o, rays_d, z, sdf, normals, colors, inv_s, cos_anneal_ratio, sample_dist, background_rgb,
                              B, n, d_color, d_weight_sum, d_weights, d_gradients, d_normal_map, eik_coef, d_sdf, d_normals, d_colors,
-                             d_inv_s, static_cast<hipStream_t>(stream));
+                             d_inv_s, nullptr, static_cast<hipStream_t>(stream));
+}
+
+int dh_render_scan_bwd_rays(const float* rays_o, const float* rays_d, const float* z, const float* sdf, const float* normals,
+                            const float* colors, const float* inv_s, float cos_anneal_ratio, float sample_dist,
+                            const float* background_rgb, int64_t B, int n, const float* d_color, const float* d_weight_sum,
+                            const float* d_weights, const float* d_gradients, const float* d_normal_map, const float* eik_coef,
+                            float* d_sdf, float* d_normals, float* d_colors, float* d_inv_s, float* d_rays_d, void* stream) {
+    if (B < 0 || n <= 0) return DH_ERR_BAD_ARG;
+    if (n > 128) return DH_ERR_UNSUPPORTED;
+    if (B == 0) return DH_OK;
+    if (!rays_o || !rays_d || !z || !sdf || !normals || !colors || !inv_s || !d_color || !eik_coef || !d_sdf ||
+        !d_normals || !d_colors || !d_inv_s || !d_rays_d) return DH_ERR_BAD_ARG;
+    return launch_render_bwd(rays_o, rays_d, z, sdf, normals, colors, inv_s, cos_anneal_ratio, sample_dist, background_rgb,
+                             B, n, d_color, d_weight_sum, d_weights, d_gradients, d_normal_map, eik_coef, d_sdf, d_normals, d_colors,
+                             d_inv_s, d_rays_d, static_cast<hipStream_t>(stream));
 }
 
 int dh_adam_step(float* params, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,

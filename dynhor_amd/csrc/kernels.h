@@ -19,7 +19,7 @@ int launch_sdf_nograd(const float* packed, const float* pts, int64_t npts, float
 int launch_sdf_fwd_train(const float* packed, const float* pts, int64_t npts, float* sdf, float* feat, float* act,
                          float* eaux, int grid, hipStream_t stream);
 int launch_sdf_grad(const float* packed, const float* pts, int64_t npts, const float* act, float* asave, float* normals,
-                    int save, int grid, hipStream_t stream);
+                    int save, float* gesave, int grid, hipStream_t stream);
 int launch_color_fwd(const float* packed, const float* pts, const float* dirs, int n_per_ray, const float* normals,
                      const float* feat, int64_t npts, float* color, float* cact, float* caux, int save, int grid,
                      hipStream_t stream);
@@ -44,7 +44,7 @@ int launch_render_bwd(const float* o, const float* d, const float* z, const floa
                       const float* colors, const float* inv_s, float car, float sample_dist, const float* bg, int64_t B,
                       int n, const float* d_color, const float* d_wsum, const float* d_weights, const float* d_gradients,
                       const float* d_nmap, const float* eik_coef, float* d_sdf, float* d_normals, float* d_colors,
-                      float* d_inv_s, hipStream_t st);
+                      float* d_inv_s, float* d_rays_d, hipStream_t st);
 int launch_loss(const float* color, const float* wsum, const float* nmap, const float* eik, const float* rays,
                 const float* R, int64_t B, float igr_w, float mask_w, float normal_w, float* stats, float* d_color,
                 float* d_wsum, float* d_nmap, float* eik_coef, hipStream_t st);
@@ -56,6 +56,13 @@ int launch_corr_loss(const float* rays_o, const float* rays_d, const float* z, c
 // backward chains (kernels_mlp_bwd.hip) and weight gradients (dw.hip)
 int launch_color_bwd(const float* packed, const float* colors, const float* d_colors, int64_t npts, const float* cact,
                      float* czbar, float* featbar, float* d_normals, float* tpart, int grid, hipStream_t st);
+// pose-refinement variants (split-bf16 arithmetic only): additionally the adjoints w.r.t. the sample points / view directions
+int launch_color_bwd_rays(const float* packed, const float* colors, const float* d_colors, const float* dirs, int n_per_ray,
+                          int64_t npts, const float* cact, float* czbar, float* featbar, float* d_normals, float* tpart,
+                          float* d_pts, float* d_dirs_pts, int grid, hipStream_t st);
+int launch_sdf_bwd_rays(const float* packed, const float* d_sdf, const float* pts, const float* d_normals, int64_t npts,
+                        const float* act, const float* rsave, const float* featbar, const float* gesave, float* zbar,
+                        float* tpart, float* d_pts, int grid, hipStream_t st);
 int launch_sdf_tangent(const float* packed, const float* pts, const float* d_normals, int64_t npts, const float* act,
                        const float* asave, float* t0aux, float* tsave, float* rsave, float* tpart, int grid, hipStream_t st);
 int launch_sdf_bwd(const float* packed, const float* d_sdf, int64_t npts, const float* act, const float* rsave,

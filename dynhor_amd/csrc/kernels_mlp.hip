@@ -95,7 +95,7 @@ __global__ __launch_bounds__(256, 2) void sdf_fwd_train_kernel(SdfPtrs P, const 
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256, 2) void sdf_grad_kernel(SdfPtrs P, const float* __restrict__ pts, int64_t npts,
                                                            const float* __restrict__ act, float* __restrict__ asave,
-                                                           float* __restrict__ normals, int save) {
+                                                           float* __restrict__ normals, int save, float* __restrict__ gesave) {
     __shared__ __attribute__((aligned(16))) float smain[TM * LDX];
     __shared__ __attribute__((aligned(16))) float saux[TM * LDA];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -162,6 +162,7 @@ __global__ __launch_bounds__(256, 2) void sdf_grad_kernel(SdfPtrs P, const float
                     n[c] = v;
                 }
                 normals[gp * 3 + 0] = n[0]; normals[gp * 3 + 1] = n[1]; normals[gp * 3 + 2] = n[2];
+                if (save == 2) { for (int c = 0; c < 40; ++c) gesave[gp * 40 + c] = c < EMB ? g[c] : 0.f; }     // pose refinement
             }
         }
         __syncthreads();
@@ -171,7 +172,7 @@ __global__ __launch_bounds__(256, 2) void sdf_grad_kernel(SdfPtrs P, const float
 // K2b on the split-bf16 core (same saved tiles and outputs as sdf_grad_kernel; the small ge / saux image stays fp32)
 __global__ __launch_bounds__(256, 1) void sdf_grad16_kernel(Sdf16Ptrs P, const float* __restrict__ pts, int64_t npts,
                                                            const float* __restrict__ act, float* __restrict__ asave,
-                                                           float* __restrict__ normals, int save) {
+                                                           float* __restrict__ normals, int save, float* __restrict__ gesave) {
     __shared__ __attribute__((aligned(16))) __bf16 smain[3 * P_MAIN];
     __shared__ __attribute__((aligned(16))) float saux[TM * LDA];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -233,6 +234,7 @@ __global__ __launch_bounds__(256, 1) void sdf_grad16_kernel(Sdf16Ptrs P, const f
                     n[c] = v;
                 }
                 normals[gp * 3 + 0] = n[0]; normals[gp * 3 + 1] = n[1]; normals[gp * 3 + 2] = n[2];
+                if (save == 2) { for (int c = 0; c < 40; ++c) gesave[gp * 40 + c] = c < EMB ? g[c] : 0.f; }     // pose refinement
             }
         }
         __syncthreads();
@@ -447,10 +449,10 @@ int launch_sdf_fwd_train(const float* packed, const float* pts, int64_t npts, fl
     return ok();
 }
 int launch_sdf_grad(const float* packed, const float* pts, int64_t npts, const float* act, float* asave, float* normals,
-                    int save, int grid, hipStream_t stream) {
+                    int save, float* gesave, int grid, hipStream_t stream) {
     // the reverse chain ships in its piece-plane form (one workgroup per CU): 1.68 vs 1.75 ms for split-on-fetch
-    if (arith_fp32()) hipLaunchKernelGGL(sdf_grad_kernel, dim3(grid_for(npts, grid)), dim3(256), 0, stream, make_sdf_ptrs(packed), pts, npts, act, asave, normals, save);
-    else hipLaunchKernelGGL(sdf_grad16_kernel, dim3(grid_for(npts, 256)), dim3(256), 0, stream, make_sdf16_ptrs(packed), pts, npts, act, asave, normals, save);
+    if (arith_fp32()) hipLaunchKernelGGL(sdf_grad_kernel, dim3(grid_for(npts, grid)), dim3(256), 0, stream, make_sdf_ptrs(packed), pts, npts, act, asave, normals, save, gesave);
+    else hipLaunchKernelGGL(sdf_grad16_kernel, dim3(grid_for(npts, 256)), dim3(256), 0, stream, make_sdf16_ptrs(packed), pts, npts, act, asave, normals, save, gesave);
     return ok();
 }
 int launch_color_fwd(const float* packed, const float* pts, const float* dirs, int n_per_ray, const float* normals,

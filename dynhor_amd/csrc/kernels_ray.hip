@@ -340,7 +340,7 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(const float* __restrict
                                                          const float* __restrict__ d_nmap,
                                                          const float* __restrict__ eik_coef, float* __restrict__ d_sdf,
                                                          float* __restrict__ d_normals, float* __restrict__ d_colors,
-                                                         float* __restrict__ d_inv_s) {
+                                                         float* __restrict__ d_inv_s, float* __restrict__ d_rays_d) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int64_t ray = (int64_t)blockIdx.x * 4 + wave;
     if (ray >= B) return;
@@ -371,6 +371,7 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(const float* __restrict
     const float ab0 = wb0 * T0 - (suf + q1) / tA;
     const float ab1 = wb1 * T1 - suf / tB;
     float dinv = 0.f;
+    float ddir[3] = {0.f, 0.f, 0.f};          // d loss / d rays_d through true_cos = d . n (pose refinement only)
     auto elem_bwd = [&](const RenderElem& E, bool valid, float ab, float w, int64_t gp) {
         if (!valid) return;
         const float ar = (E.alpha_raw >= 0.f && E.alpha_raw <= 1.f) ? ab : 0.f;
@@ -381,6 +382,7 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(const float* __restrict
         const float icb = inv_s * E.dist * 0.5f * (xn - xp);
         dinv += xp * E.ep + xn * E.en;
         const float tcb = icb * E.dtc;
+        DH_UNROLL for (int c = 0; c < 3; ++c) ddir[c] += tcb * E.n[c];
         const float ek = (E.nn > 0.f) ? ec * E.relax * 2.f * (E.nn - 1.f) / E.nn : 0.f;
         DH_UNROLL for (int c = 0; c < 3; ++c) {
             float g = tcb * d[c] + ek * E.n[c] + w * dN[c];
@@ -393,6 +395,9 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(const float* __restrict
     elem_bwd(Bq, v1, ab1, w1, ray * n + e1);
     dinv = wave_sum(dinv);
     if (lane == 0) d_inv_s[ray] = dinv;
+    if (d_rays_d) {
+        DH_UNROLL for (int c = 0; c < 3; ++c) { const float v = wave_sum(ddir[c]); if (lane == 0) d_rays_d[ray * 3 + c] = v; }
+    }
 }
 
 // ================================================================ launchers
@@ -440,10 +445,10 @@ int launch_render_bwd(const float* o, const float* d, const float* z, const floa
                       const float* colors, const float* inv_s, float car, float sample_dist, const float* bg, int64_t B,
                       int n, const float* d_color, const float* d_wsum, const float* d_weights, const float* d_gradients,
                       const float* d_nmap, const float* eik_coef, float* d_sdf, float* d_normals, float* d_colors,
-                      float* d_inv_s, hipStream_t st) {
+                      float* d_inv_s, float* d_rays_d, hipStream_t st) {
     hipLaunchKernelGGL(render_bwd_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, st, o, d, z, sdf, normals, colors, inv_s,
                        car, sample_dist, bg, B, n, d_color, d_wsum, d_weights, d_gradients, d_nmap, eik_coef, d_sdf, d_normals,
-                       d_colors, d_inv_s);
+                       d_colors, d_inv_s, d_rays_d);
     return ok();
 }
 

@@ -30,6 +30,7 @@ struct Workspace {
     float* tpart;   // [nt][N_TILE_PART][256]
     float* tred;    // [DW_NS][N_TILE_PART][256]
     float* slabs;   // dW split-K slabs (dw.hip)
+    float* gesave;  // [nt*TM][40]       embedding-gradient vector ge of the normal pass (pose refinement only: dh_sdf_gradient save = 2)
     int64_t infer_floats, fwd_floats, total_floats;   // forward-only (no saves for backward) / forward / everything
 };
 
@@ -57,6 +58,7 @@ inline Workspace carve_workspace(float* base, int64_t npts) {
     w.tpart = take(nt * N_TILE_PART * 256);
     w.tred = take((int64_t)DW_NS * N_TILE_PART * 256);
     w.slabs = take(dw_slab_floats(DW_G));
+    w.gesave = take(nt * TM * 40);
     w.total_floats = o;
     return w;
 }

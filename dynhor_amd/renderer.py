@@ -130,19 +130,29 @@ class NeuSRenderer:
         L, T = _lib.lib(), self.timer
         P = s.B * s.n
         T("sdf_forward", L.dh_sdf_forward, _p(packed), _p(s.pts), P, _p(s.ws), _p(s.sdf), _lib.stream())
-        save = 0 if s.infer_only else 1
+        save = 0 if s.infer_only else (2 if getattr(s, "ray_grads", False) else 1)
         T("sdf_gradient", L.dh_sdf_gradient, _p(packed), _p(s.pts), P, _p(s.ws), _p(s.normals), save, _lib.stream())
         T("color_forward", L.dh_color_forward, _p(packed), _p(s.pts), _p(s.rays_d), s.n, _p(s.normals), P, _p(s.ws),
           _p(s.colors), save, _lib.stream())
 
     def _net_backward(self, s, d_sdf, d_normals, d_colors, grad):
-        """Adjoint of _net_forward into the flat gradient (every slot but `variance`)."""
+        """Adjoint of _net_forward into the flat gradient (every slot but `variance`).  With s.ray_grads (pose refinement) it
+        also leaves s.d_pts [P,3] (d loss / d sample point) and s.d_dirs_pts [P,3] (d loss / d ray direction per point)."""
         L, T, st = _lib.lib(), self.timer, self.store
         P = s.B * s.n
-        T("color_backward", L.dh_color_backward, _p(st.packed), _p(s.colors), _p(d_colors), P, _p(s.ws), _p(d_normals),
-          _lib.stream())
-        T("sdf_tangent", L.dh_sdf_tangent, _p(st.packed), _p(s.pts), _p(d_normals), P, _p(s.ws), _lib.stream())
-        T("sdf_backward", L.dh_sdf_backward, _p(st.packed), _p(d_sdf), P, _p(s.ws), _lib.stream())
+        if getattr(s, "ray_grads", False):
+            s.d_pts = torch.empty(P, 3, device=s.pts.device)
+            s.d_dirs_pts = torch.empty(P, 3, device=s.pts.device)
+            T("color_backward", L.dh_color_backward_rays, _p(st.packed), _p(s.colors), _p(d_colors), _p(s.rays_d), s.n, P, _p(s.ws),
+              _p(d_normals), _p(s.d_pts), _p(s.d_dirs_pts), _lib.stream())
+            T("sdf_tangent", L.dh_sdf_tangent, _p(st.packed), _p(s.pts), _p(d_normals), P, _p(s.ws), _lib.stream())
+            T("sdf_backward", L.dh_sdf_backward_rays, _p(st.packed), _p(d_sdf), _p(s.pts), _p(d_normals), P, _p(s.ws), _p(s.d_pts),
+              _lib.stream())
+        else:
+            T("color_backward", L.dh_color_backward, _p(st.packed), _p(s.colors), _p(d_colors), P, _p(s.ws), _p(d_normals),
+              _lib.stream())
+            T("sdf_tangent", L.dh_sdf_tangent, _p(st.packed), _p(s.pts), _p(d_normals), P, _p(s.ws), _lib.stream())
+            T("sdf_backward", L.dh_sdf_backward, _p(st.packed), _p(d_sdf), P, _p(s.ws), _lib.stream())
         T("weight_grads_gemm", L.dh_weight_grads_gemm, P, _p(s.ws), _lib.stream())
         T("weight_grads_fold", L.dh_weight_grads_fold, _p(st.packed), _p(st.flat), P, _p(s.ws), _p(grad), _lib.stream())
 
@@ -224,7 +234,8 @@ class NeuSRenderer:
 
     # ------------------------------------------------------------------ render_core forward / backward (no autograd)
     @torch.no_grad()
-    def _forward_core(self, rays_o, rays_d, z_vals, cos_anneal_ratio, background_rgb, want_nmap, infer_only=False):
+    def _forward_core(self, rays_o, rays_d, z_vals, cos_anneal_ratio, background_rgb, want_nmap, infer_only=False,
+                      ray_grads=False):
         L = _lib.lib()
         st = self.store
         packed = st.ensure_packed()
@@ -236,6 +247,7 @@ class NeuSRenderer:
         s.rays_o, s.rays_d, s.z_vals, s.bg = rays_o, rays_d, z_vals, background_rgb
         s.ws = self._workspace(P, infer_only)
         s.infer_only = infer_only
+        s.ray_grads = bool(ray_grads) and not infer_only
         self._ws_token += 1
         s.ws_token = self._ws_token
         s.pts = torch.empty(P, 3, device=dev)
@@ -280,10 +292,17 @@ class NeuSRenderer:
         d_normals = torch.empty(P, 3, device=dev)
         d_colors = torch.empty(P, 3, device=dev)
         d_inv_s = torch.empty(B, device=dev)
-        _lib.check(L.dh_render_scan_bwd(_p(s.rays_o), _p(s.rays_d), _p(s.z_vals), _p(s.sdf), _p(s.normals), _p(s.colors),
-                                        _p(s.inv_s), s.car, s.sample_dist, _p(s.bg), B, n, _p(d_color), _p(c(d_wsum)),
-                                        _p(c(d_weights)), _p(c(d_gradients)), _p(c(d_nmap)), _p(eik_coef), _p(d_sdf),
-                                        _p(d_normals), _p(d_colors), _p(d_inv_s), _lib.stream()))
+        if s.ray_grads:
+            d_rays_d = torch.empty(B, 3, device=dev)
+            _lib.check(L.dh_render_scan_bwd_rays(_p(s.rays_o), _p(s.rays_d), _p(s.z_vals), _p(s.sdf), _p(s.normals), _p(s.colors),
+                                                 _p(s.inv_s), s.car, s.sample_dist, _p(s.bg), B, n, _p(d_color), _p(c(d_wsum)),
+                                                 _p(c(d_weights)), _p(c(d_gradients)), _p(c(d_nmap)), _p(eik_coef), _p(d_sdf),
+                                                 _p(d_normals), _p(d_colors), _p(d_inv_s), _p(d_rays_d), _lib.stream()))
+        else:
+            _lib.check(L.dh_render_scan_bwd(_p(s.rays_o), _p(s.rays_d), _p(s.z_vals), _p(s.sdf), _p(s.normals), _p(s.colors),
+                                            _p(s.inv_s), s.car, s.sample_dist, _p(s.bg), B, n, _p(d_color), _p(c(d_wsum)),
+                                            _p(c(d_weights)), _p(c(d_gradients)), _p(c(d_nmap)), _p(eik_coef), _p(d_sdf),
+                                            _p(d_normals), _p(d_colors), _p(d_inv_s), _lib.stream()))
         if d_sdf_out is not None:
             d_sdf = (d_sdf + d_sdf_out.reshape(-1)).contiguous()
         grad = torch.empty(st.n, device=dev)
@@ -293,6 +312,13 @@ class NeuSRenderer:
         passthrough = ((raw >= 1e-6) & (raw <= 1e6)).float()
         grad[st.var_off] = d_inv_s.sum() * 10.0 * raw * passthrough
         st.grad_flat = grad
+        if s.ray_grads:
+            # per-ray reduction of the point adjoints (sample depths are constants): x = o + mid * d
+            dz = torch.cat([s.z_vals[:, 1:] - s.z_vals[:, :-1], torch.full_like(s.z_vals[:, :1], s.sample_dist)], -1)
+            mid = (s.z_vals + 0.5 * dz).unsqueeze(-1)
+            dp = s.d_pts.view(B, n, 3)
+            s.d_rays_o = dp.sum(dim=1)
+            s.d_rays_d = (dp * mid).sum(dim=1) + s.d_dirs_pts.view(B, n, 3).sum(dim=1) + d_rays_d
         return grad
 
     # ------------------------------------------------------------------ render (App. A.5)
@@ -322,13 +348,16 @@ class NeuSRenderer:
     # ------------------------------------------------------------------ fused training step (Runner hot loop)
     @torch.no_grad()
     def train_step_core(self, rays, near, far, R, cos_anneal_ratio, igr_weight=0.1, mask_weight=0.1, normal_weight=0.0,
-                        background_rgb=None, t_rand=None, corr=None, corr_weight=0.0, corr_frames=None, corr_delta_px=4.0):
+                        background_rgb=None, t_rand=None, corr=None, corr_weight=0.0, corr_frames=None, corr_delta_px=4.0,
+                        ray_grads=False):
         """rays [B,14] (dh_gen_rays layout), R [3,3] object->camera of the frame.  Returns stats [8] on device:
         loss, colour, eikonal, mask, normal, psnr, sum(obj*keep), sum(keep); leaves the flat gradient in
         store.grad_flat.  No host synchronisation.
         Full loss stack (BASELINE.json configs[4]): corr [B,4] = (u_j, v_j, certainty, frame_j) per ray with
         corr_frames = (R_all [F,3,3], T_all [F,3], K [3,3]) adds corr_weight * the dense-correspondence reprojection loss
-        (dh_corr_loss); its statistics land in self.last_corr_stats [4] and self.last_corr_residual_px [B]."""
+        (dh_corr_loss); its statistics land in self.last_corr_stats [4] and self.last_corr_residual_px [B].
+        ray_grads (pose refinement): additionally leaves d loss / d rays_o, d loss / d rays_d [B,3] (sample depths constant)
+        and the normal loss's direct gradient w.r.t. R in self.last_ray_grads = (d_rays_o, d_rays_d, d_R or None)."""
         L = _lib.lib()
         dev = rays.device
         B = rays.shape[0]
@@ -336,7 +365,7 @@ class NeuSRenderer:
         rays_d = rays[:, 3:6].contiguous()
         z_vals = self.sample_z(rays_o, rays_d, near, far, t_rand=t_rand)
         bg = None if background_rgb is None else background_rgb.reshape(-1).contiguous().float()
-        s = self._forward_core(rays_o, rays_d, z_vals, cos_anneal_ratio, bg, want_nmap=normal_weight > 0.0)
+        s = self._forward_core(rays_o, rays_d, z_vals, cos_anneal_ratio, bg, want_nmap=normal_weight > 0.0, ray_grads=ray_grads)
         stats = torch.empty(8, device=dev)
         d_color = torch.empty(B, 3, device=dev)
         d_wsum = torch.empty(B, device=dev)
@@ -360,4 +389,10 @@ class NeuSRenderer:
             self.last_corr_stats, self.last_corr_residual_px = cstats, resid
         self._backward_core(s, d_color, d_wsum, d_weights, None, d_nmap, eik_coef)
         self.last_state = s
+        if ray_grads:
+            d_R = None
+            if normal_weight > 0.0 and Rc is not None:
+                # n_cam = R n_obj enters the normal loss directly: d loss / d R = sum_b (R d_nmap_b) nmap_b^T  (d_nmap = R^T d n_cam)
+                d_R = (d_nmap @ Rc.T).T @ s.nmap
+            self.last_ray_grads = (s.d_rays_o, s.d_rays_d, d_R)
         return stats

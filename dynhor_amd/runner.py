@@ -31,7 +31,9 @@ DEFAULT_CONF = {
               "save_freq": 10000, "val_freq": 2500, "report_freq": 100, "use_white_bkgd": False, "keep_only": False,
               "seed": 1234, "ray_seed": 4321,
               # full loss stack (BASELINE.json configs[4]): dense-correspondence reprojection term, DESIGN.md section 9
-              "corr_weight": 0.0, "corr_fraction": 0.25, "corr_delta_px": 4.0, "corr_vote_freq": 0, "corr_vote_tau_px": 8.0},
+              "corr_weight": 0.0, "corr_fraction": 0.25, "corr_delta_px": 4.0, "corr_vote_freq": 0, "corr_vote_tau_px": 8.0,
+              # per-frame pose refinement: 6-D rotation + translation per frame, rotation at 10x lr
+              "refine_poses": False, "pose_lr": 1e-4, "pose_rot_lr_mult": 10.0, "pose_start_iter": 0},
     # family "neus": the 8x256 / 4x256 fp32 MLPs (BASELINE.json configs[1]); "hash": hash-grid + shallow MLPs (configs[3])
     "model": {"family": "neus", "sdf_network": {}, "variance_network": {"init_val": 0.3}, "rendering_network": {},
               "hash_sdf_network": {}, "sh_rendering_network": {},
@@ -105,6 +107,11 @@ class Runner:
         self.store = store_cls(self.sdf_network, self.deviation_network, self.color_network, self.device)
         self.renderer = renderer_cls(self.nerf_outside, self.sdf_network, self.deviation_network, self.color_network,
                                      store=self.store, device=self.device, **self.conf["model"]["neus_renderer"])
+        self.pose_refiner = None
+        if tr["refine_poses"]:
+            from .pose import PoseRefiner
+            self.pose_refiner = PoseRefiner(self.dataset.R, self.dataset.T, lr=tr["pose_lr"], rot_lr_mult=tr["pose_rot_lr_mult"]).to(self.device)
+            self.pose_start_iter = tr["pose_start_iter"]
         self.ray_gen = torch.Generator(device=self.device)
         self.ray_gen.manual_seed(tr["ray_seed"] * 1000003 + self.rank)
         self.frame_perm = schedules.FramePermutation(self.dataset.n_images, tr["ray_seed"])   # same on every rank
@@ -141,6 +148,7 @@ class Runner:
     # ------------------------------------------------------------------ one iteration (the hot loop)
     def train_iteration(self):
         frame = self.frame_for_slot(schedules.frame_slot(self.iter_step, self.rank, self.world))
+        refine = self.pose_refiner is not None and self.iter_step >= self.pose_start_iter
         corr = None
         if self.corr_weight > 0.0 and self.dataset.corr is not None:
             if self.corr_vote_freq and self.iter_step > 0 and self.iter_step % self.corr_vote_freq == 0:
@@ -158,7 +166,18 @@ class Runner:
                                               self.igr_weight, self.mask_weight, self.normal_weight, background_rgb=bg,
                                               t_rand=t_rand, corr=corr, corr_weight=self.corr_weight,
                                               corr_frames=self.dataset.corr_frames() if corr is not None else None,
-                                              corr_delta_px=self.corr_delta_px)
+                                              corr_delta_px=self.corr_delta_px, ray_grads=refine)
+        if refine:
+            # chain the per-ray adjoints into this frame's 9 pose numbers (torch autograd over the ray formula), step, and
+            # write the refined pose back into the resident frame table the HIP ray gather reads
+            px, py = self.dataset._last_pixels
+            o, d, Rf = self.pose_refiner.rays(frame, px, py, self.dataset.Kinv)
+            d_o, d_d, d_R = self.renderer.last_ray_grads
+            self.pose_refiner.step(o, d, Rf, d_o, d_d, d_R, grad_scale=1.0 / self.world,
+                                   allreduce=dh_dist.allreduce_sum_ if self.world > 1 else None)
+            with torch.no_grad():
+                Rn, Tn = self.pose_refiner.poses()
+                self.dataset.R.copy_(Rn); self.dataset.T.copy_(Tn)
         grad = self.store.grad_flat
         dh_dist.allreduce_sum_(grad)                             # RCCL over xGMI: one 3.2 MB bucket
         lr = self.current_lr()          # 0 at iter_step 0, as upstream (update_learning_rate() runs before the loop)
@@ -238,6 +257,8 @@ class Runner:
               # the pixels and frames an uninterrupted one would have drawn
               "dynhor_rng": {"ray_gen": self.ray_gen.get_state(), "frame_perm": self.frame_perm.state_dict(),
                              "rank": self.rank, "world": self.world}}
+        if self.pose_refiner is not None:
+            ck["pose_refiner"] = {"model": self.pose_refiner.state_dict(), "optimizer": self.pose_refiner.opt.state_dict()}
         d = os.path.join(self.base_exp_dir, "checkpoints")
         os.makedirs(d, exist_ok=True)
         path = os.path.join(d, "ckpt_{:0>6d}.pth".format(self.iter_step))
@@ -259,6 +280,12 @@ class Runner:
                 opt = {"state": {i - extra: v for i, v in st.items() if i >= extra}, "param_groups": opt["param_groups"]}
             self.store.load_optimizer_state_dict(opt)
         self.iter_step = ck["iter_step"]
+        if self.pose_refiner is not None and "pose_refiner" in ck:
+            self.pose_refiner.load_state_dict(ck["pose_refiner"]["model"])
+            self.pose_refiner.opt.load_state_dict(ck["pose_refiner"]["optimizer"])
+            with torch.no_grad():
+                Rn, Tn = self.pose_refiner.poses()
+                self.dataset.R.copy_(Rn); self.dataset.T.copy_(Tn)
         rng = ck.get("dynhor_rng")
         if rng is not None:
             self.frame_perm.load_state_dict(rng["frame_perm"])

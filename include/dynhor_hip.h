@@ -95,6 +95,18 @@ int dh_color_backward(const float* packed, const float* colors, const float* d_c
                       float* d_normals, void* stream);
 int dh_sdf_tangent(const float* packed, const float* pts, const float* d_normals, int64_t npts, float* ws, void* stream);
 int dh_sdf_backward(const float* packed, const float* d_sdf, int64_t npts, float* ws, void* stream);
+/* Pose refinement (per-frame object poses as trainable cameras; reference precedent for the 6-D
+ * rotation + translation parameters and their optimiser: ObjTracker/utils/geometry.py:7-25, jointopt.py:125-141).  The same two
+ * stages as above, additionally producing d loss / d sample point (d_pts [npts,3]) and, for the colour network's view embedding,
+ * d loss / d ray direction per point (d_dirs_pts [npts,3]).  Call order: dh_sdf_gradient(save = 2) in the forward (keeps the
+ * embedding-gradient vector in ws), then dh_color_backward_rays (WRITES d_pts, d_dirs_pts) -> dh_sdf_tangent ->
+ * dh_sdf_backward_rays (ACCUMULATES onto d_pts, incl. the second-order path) -> weight-gradient stages as usual.  The caller
+ * reduces per ray: d_rays_o = sum_k d_pts, d_rays_d = sum_k (mid_k d_pts + d_dirs_pts) + dh_render_scan_bwd_rays' d_rays_d;
+ * sample depths are treated as constants.  Split-bf16 arithmetic only (DH_ERR_UNSUPPORTED under DH_ARITH_FP32_MFMA). */
+int dh_color_backward_rays(const float* packed, const float* colors, const float* d_colors, const float* dirs, int n_per_ray,
+                           int64_t npts, float* ws, float* d_normals, float* d_pts, float* d_dirs_pts, void* stream);
+int dh_sdf_backward_rays(const float* packed, const float* d_sdf, const float* pts, const float* d_normals, int64_t npts,
+                         float* ws, float* d_pts, void* stream);
 int dh_weight_grads_gemm(int64_t npts, float* ws, void* stream);
 int dh_weight_grads_fold(const float* packed, const float* params, int64_t npts, float* ws, float* grad_flat, void* stream);
 
@@ -145,6 +157,12 @@ int dh_render_scan_bwd(const float* rays_o, const float* rays_d, const float* z,
                        const float* background_rgb, int64_t B, int n, const float* d_color, const float* d_weight_sum,
                        const float* d_weights, const float* d_gradients, const float* d_normal_map, const float* eik_coef,
                        float* d_sdf, float* d_normals, float* d_colors, float* d_inv_s, void* stream);
+/* The same, additionally d_rays_d [B,3] = d loss / d rays_d through true_cos = d . n (pose refinement). */
+int dh_render_scan_bwd_rays(const float* rays_o, const float* rays_d, const float* z, const float* sdf, const float* normals,
+                            const float* colors, const float* inv_s, float cos_anneal_ratio, float sample_dist,
+                            const float* background_rgb, int64_t B, int n, const float* d_color, const float* d_weight_sum,
+                            const float* d_weights, const float* d_gradients, const float* d_normal_map, const float* eik_coef,
+                            float* d_sdf, float* d_normals, float* d_colors, float* d_inv_s, float* d_rays_d, void* stream);
 
 /* Loss stack of the training step (upstream Runner.train, App. A.8, with Dynhor's hand gating): rays [B,14] as
  * written by dh_gen_rays; m = obj*keep (the keep-mask gating precedent: reference ObjTracker/utils/losses.py:69-71,

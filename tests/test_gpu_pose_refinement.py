@@ -1,0 +1,140 @@
+"""GPU: per-frame pose refinement.  d loss / d rays_o, d loss / d rays_d and the normal loss's direct
+d loss / d R from the HIP path (dh_color_backward_rays, dh_sdf_backward_rays incl. the second-order path,
+dh_render_scan_bwd_rays) against the oracle's autograd in fp64 with the rays as leaves (sample depths constant in both);
+then the full chain into the reference's pose parameters (6-D rotation + translation, ObjTracker/utils/geometry.py:7-25)
+against the oracle differentiated end to end w.r.t. those parameters; finally the Runner wiring."""
+import pytest
+import torch
+
+from oracle import neus_oracle as O
+from tests.test_gpu_render_forward import make_pair
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def tiny_dataset():
+    from dynhor_amd.dataset import Dataset
+    return Dataset.from_synthetic(n_frames=3, H=96, W=96, seed=7, device="cuda:0")
+
+
+def _oracle_loss(o_r, o, d, near, far, z, rays, R, car, nw):
+    out = o_r.render(o, d, near, far, cos_anneal_ratio=car, z_vals=z)
+    return O.neus_losses(out, rays[:, 6:9], rays[:, 9:10], rays[:, 10:11], 0.1, 0.1, nw, rays[:, 11:14], R)["loss"]
+
+
+@pytest.mark.parametrize("normal_w", [0.0, 0.05])
+def test_ray_gradients_match_oracle(tiny_dataset, normal_w):
+    ds = tiny_dataset
+    o_r, p_r = make_pair(seed=51, jitter=0.05, n_samples=32, n_importance=32)
+    B, frame, car = 96, 1, 0.4
+    g = torch.Generator(device="cpu").manual_seed(5)
+    px = torch.randint(0, ds.W, [B], generator=g).cuda(); py = torch.randint(0, ds.H, [B], generator=g).cuda()
+    t_rand = torch.rand(B, 1, generator=g).cuda()
+    rays = ds.gen_rays_at_pixels(frame, px, py)
+    near, far = ds._last_near_far
+    z = o_r.sample_z(rays[:, :3], rays[:, 3:6], near, far, t_rand=t_rand)
+    mods = (o_r.sdf_network, o_r.deviation_network, o_r.color_network)
+    for m in mods:
+        m.double(); m.zero_grad()
+    r64 = rays.double()
+    o = r64[:, :3].clone().requires_grad_(True); d = r64[:, 3:6].clone().requires_grad_(True)
+    R = ds.R[frame].double().clone().requires_grad_(True)
+    _oracle_loss(o_r, o, d, near.double(), far.double(), z.double(), r64, R, car, normal_w).backward()
+    gref = torch.cat([p.grad.reshape(-1) for m in mods for p in m.parameters()])
+    for m in mods:
+        m.float()
+    p_r.sample_z = lambda *a, **k: z
+    p_r.train_step_core(rays, near, far, ds.R[frame], car, 0.1, 0.1, normal_w, ray_grads=True)
+    torch.cuda.synchronize()
+    d_o, d_d, d_R = p_r.last_ray_grads
+    rel_w = ((p_r.store.grad_flat.double() - gref).norm() / gref.norm()).item()
+    rel_o = ((d_o.double() - o.grad).norm() / o.grad.norm()).item()
+    rel_d = ((d_d.double() - d.grad).norm() / d.grad.norm()).item()
+    print(f"normal_w {normal_w}: weight grad rel {rel_w:.2e}; d_rays_o rel {rel_o:.2e}; d_rays_d rel {rel_d:.2e}")
+    assert rel_w < 1e-4, "the pose-refinement kernel variants must leave the weight gradient unchanged"
+    assert rel_o < 5e-4 and rel_d < 5e-4
+    # per-ray, not only in norm: the largest per-ray deviation against the largest per-ray gradient
+    assert (d_o.double() - o.grad).abs().max().item() < 2e-3 * o.grad.abs().max().item()
+    assert (d_d.double() - d.grad).abs().max().item() < 2e-3 * d.grad.abs().max().item()
+    if normal_w > 0:
+        rel_R = ((d_R.double() - R.grad).norm() / R.grad.norm()).item()
+        print(f"d loss / d R (normal loss, direct) rel {rel_R:.2e}")
+        assert rel_R < 5e-4
+    else:
+        assert d_R is None
+
+
+def test_pose_parameter_gradients_match_oracle_end_to_end(tiny_dataset):
+    from dynhor_amd.pose import PoseRefiner, rot6d_to_matrix
+    ds = tiny_dataset
+    o_r, p_r = make_pair(seed=52, jitter=0.05, n_samples=32, n_importance=32)
+    B, frame, car, nw = 128, 2, 0.3, 0.05
+    g = torch.Generator(device="cpu").manual_seed(9)
+    px = torch.randint(0, ds.W, [B], generator=g).cuda(); py = torch.randint(0, ds.H, [B], generator=g).cuda()
+    rays = ds.gen_rays_at_pixels(frame, px, py)
+    near, far = ds._last_near_far
+    z = o_r.sample_z(rays[:, :3], rays[:, 3:6], near, far, t_rand=torch.rand(B, 1, generator=g).cuda())
+    ref = PoseRefiner(ds.R, ds.T).cuda()
+    # the refiner reproduces the stage-1 poses and the HIP ray gather
+    Rn, Tn = ref.poses()
+    assert (Rn - ds.R).abs().max().item() < 1e-6 and torch.equal(Tn.detach(), ds.T)
+    o_t, d_t, R_t = ref.rays(frame, px, py, ds.Kinv)
+    assert (o_t - rays[:, :3]).abs().max().item() < 1e-5 and (d_t - rays[:, 3:6]).abs().max().item() < 1e-5
+    # oracle, fp64, differentiated w.r.t. the pose parameters themselves
+    for m in (o_r.sdf_network, o_r.deviation_network, o_r.color_network):
+        m.double()
+    r6 = ref.rot6d.detach().double().clone().requires_grad_(True)
+    tr = ref.trans.detach().double().clone().requires_grad_(True)
+    R64 = rot6d_to_matrix(r6[frame:frame + 1])[0].T
+    pix = torch.stack([px.double(), py.double(), torch.ones(B, dtype=torch.float64, device="cuda")], -1)
+    dc = torch.nn.functional.normalize(pix @ torch.inverse(ds.K.double()).T, dim=-1)
+    d64 = dc @ R64; o64 = (-(tr[frame] @ R64)).expand_as(d64)
+    _oracle_loss(o_r, o64, d64, near.double(), far.double(), z.double(), rays.double(), R64, car, nw).backward()
+    for m in (o_r.sdf_network, o_r.deviation_network, o_r.color_network):
+        m.float()
+    p_r.sample_z = lambda *a, **k: z
+    p_r.train_step_core(rays, near, far, ds.R[frame], car, 0.1, 0.1, nw, ray_grads=True)
+    d_o, d_d, d_R = p_r.last_ray_grads
+    ref.opt.zero_grad()
+    torch.autograd.backward([o_t, d_t, R_t], [d_o, d_d, d_R])
+    rel_r = ((ref.rot6d.grad[frame].double() - r6.grad[frame]).norm() / r6.grad[frame].norm()).item()
+    rel_t = ((ref.trans.grad[frame].double() - tr.grad[frame]).norm() / tr.grad[frame].norm()).item()
+    print(f"pose gradients vs oracle end to end: rot6d rel {rel_r:.2e}, translation rel {rel_t:.2e}")
+    assert rel_r < 2e-3 and rel_t < 2e-3
+    others = [f for f in range(ds.n_images) if f != frame]
+    assert ref.rot6d.grad[others].abs().max().item() == 0 and ref.trans.grad[others].abs().max().item() == 0
+
+
+def test_fp32_mfma_arithmetic_reports_unsupported(tiny_dataset):
+    from dynhor_amd import _lib
+    ds = tiny_dataset
+    _, p_r = make_pair(seed=53, jitter=0.05, n_samples=32, n_importance=32)
+    rays = ds.gen_random_rays_at(0, 64)
+    near, far = ds._last_near_far
+    _lib.set_arithmetic(_lib.ARITH_FP32_MFMA)
+    try:
+        with pytest.raises(_lib.DynhorHipError, match="unsupported"):
+            p_r.train_step_core(rays, near, far, ds.R[0], 0.3, 0.1, 0.1, 0.05, ray_grads=True)
+    finally:
+        _lib.set_arithmetic(_lib.ARITH_SPLIT_BF16)
+    torch.cuda.synchronize()
+
+
+def test_runner_refines_poses_and_checkpoints_them(tmp_path):
+    from dynhor_amd.runner import Runner
+    conf = {"seq_name": "pose", "exp_name": "e", "data_info": {"synthetic": {"n_frames": 4, "H": 64, "W": 64, "seed": 5}},
+            "train": {"batch_size": 256, "normal_weight": 0.05, "refine_poses": True, "pose_lr": 1e-3, "report_freq": 10 ** 9,
+                      "save_freq": 10 ** 9, "val_freq": 0, "warm_up_end": 10, "end_iter": 100}}
+    r = Runner(conf=conf, device="cuda:0", exp_root=str(tmp_path))
+    R0, T0 = r.dataset.R.clone(), r.dataset.T.clone()
+    r.train(8)
+    assert torch.isfinite(r.dataset.R).all() and torch.isfinite(r.store.flat).all()
+    moved = (r.dataset.T - T0).abs().amax(dim=1)
+    assert (moved > 0).all() and moved.max().item() < 0.05, "every visited frame's pose moved, by a small step"
+    assert ((r.dataset.R @ r.dataset.R.transpose(1, 2)) - torch.eye(3, device="cuda")).abs().max().item() < 1e-5
+    path = r.save_checkpoint()
+    ck = torch.load(path, weights_only=False)
+    assert "pose_refiner" in ck
+    r2 = Runner(conf=conf, device="cuda:0", exp_root=str(tmp_path), is_continue=True)
+    assert torch.allclose(r2.dataset.R, r.dataset.R, atol=1e-6) and torch.allclose(r2.dataset.T, r.dataset.T)
