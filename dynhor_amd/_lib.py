@@ -62,6 +62,10 @@ SIGNATURES = {
     "dh_render_scan_fwd": (_i32, [_vp] * 7 + [_f32, _f32, _vp, _i64, _i32] + [_vp] * 9),
     "dh_render_scan_bwd": (_i32, [_vp] * 7 + [_f32, _f32, _vp, _i64, _i32] + [_vp] * 11),
     "dh_render_scan_bwd_rays": (_i32, [_vp] * 7 + [_f32, _f32, _vp, _i64, _i32] + [_vp] * 12),
+    "dh_march_count": (_i32, [_vp] * 6 + [_i32, _f32, _f32, _f32, _i32, _i64, _vp, _vp]),
+    "dh_march_emit": (_i32, [_vp] * 6 + [_i32, _f32, _f32, _f32, _i32, _i64] + [_vp] * 6),
+    "dh_render_scan_fwd_packed": (_i32, [_vp] * 7 + [_f32, _f32, _vp, _i64] + [_vp] * 11),
+    "dh_render_scan_bwd_packed": (_i32, [_vp] * 7 + [_f32, _f32, _vp, _i64] + [_vp] * 13),
     "dh_neus_loss": (_i32, [_vp] * 6 + [_i64, _f32, _f32, _f32] + [_vp] * 6),
     "dh_corr_loss": (_i32, [_vp] * 7 + [_i32, _vp, _i64, _i32, _f32, _f32, _f32, _vp, _vp, _vp, _vp]),
 }

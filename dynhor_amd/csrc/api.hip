@@ -251,7 +251,7 @@ int dh_render_scan_fwd(const float* rays_o, const float* rays_d, const float* z,
         !weight_max || !cdf || !inside_sphere || !eik_partial) return DH_ERR_BAD_ARG;
     return launch_render_fwd(rays_o, rays_d, z, sdf, normals, colors, inv_s, cos_anneal_ratio, sample_dist, background_rgb,
                              B, n, weights, color, weight_sum, weight_max, cdf, inside_sphere, eik_partial, normal_map,
-                             static_cast<hipStream_t>(stream));
+                             nullptr, nullptr, static_cast<hipStream_t>(stream));
 }
 
 int dh_render_scan_bwd(const float* rays_o, const float* rays_d, const float* z, const float* sdf, const float* normals,
@@ -266,7 +266,7 @@ int dh_render_scan_bwd(const float* rays_o, const float* rays_d, const float* z,
         !d_normals || !d_colors || !d_inv_s) return DH_ERR_BAD_ARG;
     return launch_render_bwd(rays_o, rays_d, z, sdf, normals, colors, inv_s, cos_anneal_ratio, sample_dist, background_rgb,
                              B, n, d_color, d_weight_sum, d_weights, d_gradients, d_normal_map, eik_coef, d_sdf, d_normals, d_colors,
-                             d_inv_s, nullptr, static_cast<hipStream_t>(stream));
+                             d_inv_s, nullptr, nullptr, nullptr, static_cast<hipStream_t>(stream));
 }
 
 int dh_render_scan_bwd_rays(const float* rays_o, const float* rays_d, const float* z, const float* sdf, const float* normals,
@@ -281,7 +281,58 @@ int dh_render_scan_bwd_rays(const float* rays_o, const float* rays_d, const floa
         !d_normals || !d_colors || !d_inv_s || !d_rays_d) return DH_ERR_BAD_ARG;
     return launch_render_bwd(rays_o, rays_d, z, sdf, normals, colors, inv_s, cos_anneal_ratio, sample_dist, background_rgb,
                              B, n, d_color, d_weight_sum, d_weights, d_gradients, d_normal_map, eik_coef, d_sdf, d_normals, d_colors,
-                             d_inv_s, d_rays_d, static_cast<hipStream_t>(stream));
+                             d_inv_s, d_rays_d, nullptr, nullptr, static_cast<hipStream_t>(stream));
+}
+
+int dh_march_count(const float* rays_o, const float* rays_d, const float* near, const float* far, const float* u,
+                   const uint8_t* occupancy, int res, float radius, float step, float half_step, int max_samples, int64_t B,
+                   int32_t* cnt, void* stream) {
+    if (B < 0 || res <= 0 || !(radius > 0.f) || !(step > 0.f) || max_samples <= 0) return DH_ERR_BAD_ARG;
+    if (max_samples > 128) return DH_ERR_UNSUPPORTED;
+    if (B == 0) return DH_OK;
+    if (!rays_o || !rays_d || !near || !far || !occupancy || !cnt) return DH_ERR_BAD_ARG;
+    return launch_march_count(rays_o, rays_d, near, far, u, occupancy, res, radius, step, half_step, max_samples, B, cnt,
+                              static_cast<hipStream_t>(stream));
+}
+
+int dh_march_emit(const float* rays_o, const float* rays_d, const float* near, const float* far, const float* u,
+                  const uint8_t* occupancy, int res, float radius, float step, float half_step, int max_samples, int64_t B,
+                  const int64_t* off, float* t_start, float* pts, float* dirs_pts, int32_t* ray_idx, void* stream) {
+    if (B < 0 || res <= 0 || !(radius > 0.f) || !(step > 0.f) || max_samples <= 0) return DH_ERR_BAD_ARG;
+    if (max_samples > 128) return DH_ERR_UNSUPPORTED;
+    if (B == 0) return DH_OK;
+    if (!rays_o || !rays_d || !near || !far || !occupancy || !off || !t_start || !pts || !dirs_pts || !ray_idx) return DH_ERR_BAD_ARG;
+    return launch_march_emit(rays_o, rays_d, near, far, u, occupancy, res, radius, step, half_step, max_samples, B, off, t_start,
+                             pts, dirs_pts, ray_idx, static_cast<hipStream_t>(stream));
+}
+
+int dh_render_scan_fwd_packed(const float* rays_o, const float* rays_d, const float* t_start, const float* sdf, const float* normals,
+                              const float* colors, const float* inv_s, float cos_anneal_ratio, float step,
+                              const float* background_rgb, int64_t B, const int64_t* seg_off, const int32_t* seg_cnt,
+                              float* weights, float* color, float* weight_sum, float* weight_max, float* cdf,
+                              float* inside_sphere, float* eik_partial, float* normal_map, void* stream) {
+    if (B < 0) return DH_ERR_BAD_ARG;
+    if (B == 0) return DH_OK;
+    if (!rays_o || !rays_d || !t_start || !sdf || !normals || !colors || !inv_s || !seg_off || !seg_cnt || !weights || !color ||
+        !weight_sum || !weight_max || !cdf || !inside_sphere || !eik_partial) return DH_ERR_BAD_ARG;
+    return launch_render_fwd(rays_o, rays_d, t_start, sdf, normals, colors, inv_s, cos_anneal_ratio, step, background_rgb, B, 0,
+                             weights, color, weight_sum, weight_max, cdf, inside_sphere, eik_partial, normal_map, seg_off, seg_cnt,
+                             static_cast<hipStream_t>(stream));
+}
+
+int dh_render_scan_bwd_packed(const float* rays_o, const float* rays_d, const float* t_start, const float* sdf, const float* normals,
+                              const float* colors, const float* inv_s, float cos_anneal_ratio, float step,
+                              const float* background_rgb, int64_t B, const int64_t* seg_off, const int32_t* seg_cnt,
+                              const float* d_color, const float* d_weight_sum, const float* d_weights, const float* d_gradients,
+                              const float* d_normal_map, const float* eik_coef, float* d_sdf, float* d_normals, float* d_colors,
+                              float* d_inv_s, void* stream) {
+    if (B < 0) return DH_ERR_BAD_ARG;
+    if (B == 0) return DH_OK;
+    if (!rays_o || !rays_d || !t_start || !sdf || !normals || !colors || !inv_s || !seg_off || !seg_cnt || !d_color || !eik_coef ||
+        !d_sdf || !d_normals || !d_colors || !d_inv_s) return DH_ERR_BAD_ARG;
+    return launch_render_bwd(rays_o, rays_d, t_start, sdf, normals, colors, inv_s, cos_anneal_ratio, step, background_rgb, B, 0,
+                             d_color, d_weight_sum, d_weights, d_gradients, d_normal_map, eik_coef, d_sdf, d_normals, d_colors,
+                             d_inv_s, nullptr, seg_off, seg_cnt, static_cast<hipStream_t>(stream));
 }
 
 int dh_adam_step(float* params, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,

@@ -39,12 +39,19 @@ int launch_midpoints(const float* o, const float* d, const float* z, int64_t B, 
 int launch_render_fwd(const float* o, const float* d, const float* z, const float* sdf, const float* normals,
                       const float* colors, const float* inv_s, float car, float sample_dist, const float* bg, int64_t B,
                       int n, float* weights, float* color, float* wsum, float* wmax, float* cdf, float* inside, float* eik,
-                      float* nmap, hipStream_t st);
+                      float* nmap, const int64_t* seg_off, const int32_t* seg_cnt, hipStream_t st);
 int launch_render_bwd(const float* o, const float* d, const float* z, const float* sdf, const float* normals,
                       const float* colors, const float* inv_s, float car, float sample_dist, const float* bg, int64_t B,
                       int n, const float* d_color, const float* d_wsum, const float* d_weights, const float* d_gradients,
                       const float* d_nmap, const float* eik_coef, float* d_sdf, float* d_normals, float* d_colors,
-                      float* d_inv_s, float* d_rays_d, hipStream_t st);
+                      float* d_inv_s, float* d_rays_d, const int64_t* seg_off, const int32_t* seg_cnt, hipStream_t st);
+// occupancy-grid marching (march.hip)
+int launch_march_count(const float* o, const float* d, const float* near, const float* far, const float* u, const uint8_t* occ,
+                       int res, float radius, float step, float half_step, int max_samples, int64_t B, int32_t* cnt,
+                       hipStream_t st);
+int launch_march_emit(const float* o, const float* d, const float* near, const float* far, const float* u, const uint8_t* occ,
+                      int res, float radius, float step, float half_step, int max_samples, int64_t B, const int64_t* off,
+                      float* t_start, float* pts, float* dirs_pts, int32_t* ray_idx, hipStream_t st);
 int launch_loss(const float* color, const float* wsum, const float* nmap, const float* eik, const float* rays,
                 const float* R, int64_t B, float igr_w, float mask_w, float normal_w, float* stats, float* d_color,
                 float* d_wsum, float* d_nmap, float* eik_coef, hipStream_t st);

@@ -291,19 +291,25 @@ __global__ __launch_bounds__(256) void render_fwd_kernel(const float* __restrict
                                                          float* __restrict__ weights, float* __restrict__ color_out,
                                                          float* __restrict__ wsum_out, float* __restrict__ wmax_out,
                                                          float* __restrict__ cdf_out, float* __restrict__ inside_out,
-                                                         float* __restrict__ eik_out, float* __restrict__ nmap_out) {
+                                                         float* __restrict__ eik_out, float* __restrict__ nmap_out,
+                                                         const int64_t* __restrict__ seg_off, const int32_t* __restrict__ seg_cnt) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int64_t ray = (int64_t)blockIdx.x * 4 + wave;
     if (ray >= B) return;
     const float inv_s = inv_s_p[0];
     float o[3], d[3];
     DH_UNROLL for (int c = 0; c < 3; ++c) { o[c] = rays_o[ray * 3 + c]; d[c] = rays_d[ray * 3 + c]; }
+    // packed rays (occupancy-grid marching): the ray's samples are the segment [seg_off, seg_off + seg_cnt) of the packed
+    // arrays, z holds the interval starts and every interval is sample_dist long
+    const bool packed = seg_off != nullptr;
+    const int64_t rb = packed ? seg_off[ray] : ray * n;
+    if (packed) n = seg_cnt[ray];
     const int e0 = 2 * lane, e1 = e0 + 1;
-    const float z0 = e0 < n ? z[ray * n + e0] : 0.f, z1 = e1 < n ? z[ray * n + e1] : 0.f;
+    const float z0 = e0 < n ? z[rb + e0] : 0.f, z1 = e1 < n ? z[rb + e1] : 0.f;
     const float z2 = __shfl_down(z0, 1);
     float in0, in1;
-    const RenderElem A = render_elem(e0 < n, ray * n + e0, z0, z1, e0 == n - 1, sample_dist, o, d, sdf, normals, colors, inv_s, car, in0);
-    const RenderElem Bq = render_elem(e1 < n, ray * n + e1, z1, z2, e1 == n - 1, sample_dist, o, d, sdf, normals, colors, inv_s, car, in1);
+    const RenderElem A = render_elem(e0 < n, rb + e0, z0, z1, packed || e0 == n - 1, sample_dist, o, d, sdf, normals, colors, inv_s, car, in0);
+    const RenderElem Bq = render_elem(e1 < n, rb + e1, z1, z2, packed || e1 == n - 1, sample_dist, o, d, sdf, normals, colors, inv_s, car, in1);
     const float tA = 1.f - A.alpha + 1e-7f, tB = 1.f - Bq.alpha + 1e-7f;
     const float excl = wave_excl_prod(((e0 < n) ? tA : 1.f) * ((e1 < n) ? tB : 1.f), lane);
     const float w0 = A.alpha * excl, w1 = Bq.alpha * excl * tA;
@@ -314,8 +320,8 @@ __global__ __launch_bounds__(256) void render_fwd_kernel(const float* __restrict
     DH_UNROLL for (int c = 0; c < 3; ++c) nm[c] = wave_sum(w0 * A.n[c] + w1 * Bq.n[c]);
     const float g0 = (A.nn - 1.f) * (A.nn - 1.f) * A.relax, g1 = (Bq.nn - 1.f) * (Bq.nn - 1.f) * Bq.relax;
     const float en = wave_sum(g0 + g1), ed = wave_sum(A.relax + Bq.relax);
-    if (e0 < n) { weights[ray * n + e0] = w0; cdf_out[ray * n + e0] = A.prev; inside_out[ray * n + e0] = in0; }
-    if (e1 < n) { weights[ray * n + e1] = w1; cdf_out[ray * n + e1] = Bq.prev; inside_out[ray * n + e1] = in1; }
+    if (e0 < n) { weights[rb + e0] = w0; cdf_out[rb + e0] = A.prev; inside_out[rb + e0] = in0; }
+    if (e1 < n) { weights[rb + e1] = w1; cdf_out[rb + e1] = Bq.prev; inside_out[rb + e1] = in1; }
     if (lane == 0) {
         DH_UNROLL for (int c = 0; c < 3; ++c) color_out[ray * 3 + c] = col[c] + (bg_rgb ? bg_rgb[c] * (1.f - ws) : 0.f);
         wsum_out[ray] = ws;
@@ -340,10 +346,14 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(const float* __restrict
                                                          const float* __restrict__ d_nmap,
                                                          const float* __restrict__ eik_coef, float* __restrict__ d_sdf,
                                                          float* __restrict__ d_normals, float* __restrict__ d_colors,
-                                                         float* __restrict__ d_inv_s, float* __restrict__ d_rays_d) {
+                                                         float* __restrict__ d_inv_s, float* __restrict__ d_rays_d,
+                                                         const int64_t* __restrict__ seg_off, const int32_t* __restrict__ seg_cnt) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int64_t ray = (int64_t)blockIdx.x * 4 + wave;
     if (ray >= B) return;
+    const bool packed = seg_off != nullptr;
+    const int64_t rb = packed ? seg_off[ray] : ray * n;
+    if (packed) n = seg_cnt[ray];
     const float inv_s = inv_s_p[0];
     const float ec = eik_coef[0];
     float o[3], d[3], dC[3];
@@ -354,18 +364,18 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(const float* __restrict
     if (bg_rgb) dws -= dC[0] * bg_rgb[0] + dC[1] * bg_rgb[1] + dC[2] * bg_rgb[2];
     const int e0 = 2 * lane, e1 = e0 + 1;
     const bool v0 = e0 < n, v1 = e1 < n;
-    const float z0 = v0 ? z[ray * n + e0] : 0.f, z1 = v1 ? z[ray * n + e1] : 0.f;
+    const float z0 = v0 ? z[rb + e0] : 0.f, z1 = v1 ? z[rb + e1] : 0.f;
     const float z2 = __shfl_down(z0, 1);
     float in0, in1;
-    const RenderElem A = render_elem(v0, ray * n + e0, z0, z1, e0 == n - 1, sample_dist, o, d, sdf, normals, colors, inv_s, car, in0);
-    const RenderElem Bq = render_elem(v1, ray * n + e1, z1, z2, e1 == n - 1, sample_dist, o, d, sdf, normals, colors, inv_s, car, in1);
+    const RenderElem A = render_elem(v0, rb + e0, z0, z1, packed || e0 == n - 1, sample_dist, o, d, sdf, normals, colors, inv_s, car, in0);
+    const RenderElem Bq = render_elem(v1, rb + e1, z1, z2, packed || e1 == n - 1, sample_dist, o, d, sdf, normals, colors, inv_s, car, in1);
     const float tA = v0 ? 1.f - A.alpha + 1e-7f : 1.f, tB = v1 ? 1.f - Bq.alpha + 1e-7f : 1.f;
     const float excl = wave_excl_prod(tA * tB, lane);
     const float T0 = excl, T1 = excl * tA;
     const float w0 = A.alpha * T0, w1 = Bq.alpha * T1;
     float wb0 = dws + dC[0] * A.c[0] + dC[1] * A.c[1] + dC[2] * A.c[2] + dN[0] * A.n[0] + dN[1] * A.n[1] + dN[2] * A.n[2];
     float wb1 = dws + dC[0] * Bq.c[0] + dC[1] * Bq.c[1] + dC[2] * Bq.c[2] + dN[0] * Bq.n[0] + dN[1] * Bq.n[1] + dN[2] * Bq.n[2];
-    if (d_weights) { if (v0) wb0 += d_weights[ray * n + e0]; if (v1) wb1 += d_weights[ray * n + e1]; }
+    if (d_weights) { if (v0) wb0 += d_weights[rb + e0]; if (v1) wb1 += d_weights[rb + e1]; }
     const float q0 = v0 ? wb0 * w0 : 0.f, q1 = v1 ? wb1 * w1 : 0.f;
     const float suf = wave_excl_suffix_sum(q0 + q1, lane);
     const float ab0 = wb0 * T0 - (suf + q1) / tA;
@@ -391,8 +401,8 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(const float* __restrict
             d_colors[gp * 3 + c] = w * dC[c];
         }
     };
-    elem_bwd(A, v0, ab0, w0, ray * n + e0);
-    elem_bwd(Bq, v1, ab1, w1, ray * n + e1);
+    elem_bwd(A, v0, ab0, w0, rb + e0);
+    elem_bwd(Bq, v1, ab1, w1, rb + e1);
     dinv = wave_sum(dinv);
     if (lane == 0) d_inv_s[ray] = dinv;
     if (d_rays_d) {
@@ -436,19 +446,19 @@ int launch_midpoints(const float* o, const float* d, const float* z, int64_t B, 
 int launch_render_fwd(const float* o, const float* d, const float* z, const float* sdf, const float* normals,
                       const float* colors, const float* inv_s, float car, float sample_dist, const float* bg, int64_t B,
                       int n, float* weights, float* color, float* wsum, float* wmax, float* cdf, float* inside, float* eik,
-                      float* nmap, hipStream_t st) {
+                      float* nmap, const int64_t* seg_off, const int32_t* seg_cnt, hipStream_t st) {
     hipLaunchKernelGGL(render_fwd_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, st, o, d, z, sdf, normals, colors, inv_s,
-                       car, sample_dist, bg, B, n, weights, color, wsum, wmax, cdf, inside, eik, nmap);
+                       car, sample_dist, bg, B, n, weights, color, wsum, wmax, cdf, inside, eik, nmap, seg_off, seg_cnt);
     return ok();
 }
 int launch_render_bwd(const float* o, const float* d, const float* z, const float* sdf, const float* normals,
                       const float* colors, const float* inv_s, float car, float sample_dist, const float* bg, int64_t B,
                       int n, const float* d_color, const float* d_wsum, const float* d_weights, const float* d_gradients,
                       const float* d_nmap, const float* eik_coef, float* d_sdf, float* d_normals, float* d_colors,
-                      float* d_inv_s, float* d_rays_d, hipStream_t st) {
+                      float* d_inv_s, float* d_rays_d, const int64_t* seg_off, const int32_t* seg_cnt, hipStream_t st) {
     hipLaunchKernelGGL(render_bwd_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, st, o, d, z, sdf, normals, colors, inv_s,
                        car, sample_dist, bg, B, n, d_color, d_wsum, d_weights, d_gradients, d_nmap, eik_coef, d_sdf, d_normals,
-                       d_colors, d_inv_s, d_rays_d);
+                       d_colors, d_inv_s, d_rays_d, seg_off, seg_cnt);
     return ok();
 }
 

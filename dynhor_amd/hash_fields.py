@@ -21,6 +21,9 @@ from . import _lib
 from .fields import ParamStore, SingleVarianceNetwork, _WNLinearParams
 from .renderer import NeuSRenderer, _p
 
+import ctypes as _ct
+_NULLP = _ct.c_void_p(0)
+
 
 class HashGridTable(nn.Module):
     """The [entries, 2] feature table (state_dict key ``encoding.table``), U(-1e-4, 1e-4) initialised."""
@@ -94,16 +97,64 @@ class HashParamStore(ParamStore):
         _lib.check(_lib.lib().dh_hash_pack_weights(_lib.ptr(self.flat), _lib.ptr(self.packed), _lib.stream()))
 
 
+class OccupancyGrid:
+    """res^3 occupancy image over [-radius, radius]^3 driving the ray marcher (nerfacc OccupancyGrid semantics as restated in
+    oracle/occgrid_oracle.py): occ <- max(occ * decay, alpha(cell)), binary = occ > min(mean(occ), thre); alpha(cell) is the
+    NeuS opacity of one marching step at a jittered point of the cell (instant-nsr-pl's occ_eval_fn).  The SDF queries run
+    through the HIP no-grad kernel; the rest is a handful of elementwise ops on res^3 floats every `update_every` iterations."""
+
+    def __init__(self, res=128, radius=1.0, decay=0.95, thre=0.001, device="cuda"):
+        self.res, self.radius, self.decay, self.thre = int(res), float(radius), float(decay), float(thre)
+        self.device = torch.device(device)
+        self.occ = torch.zeros(self.res ** 3, device=self.device)
+        self.binary = torch.ones(self.res ** 3, dtype=torch.uint8, device=self.device)       # all occupied until the first update
+        ax = torch.arange(self.res, device=self.device, dtype=torch.float32)
+        ix, iy, iz = torch.meshgrid(ax, ax, ax, indexing="ij")
+        self._idx = torch.stack([ix, iy, iz], -1).reshape(-1, 3)
+
+    def cell_points(self, jitter):
+        return ((self._idx + jitter) / self.res * 2.0 - 1.0) * self.radius
+
+    @torch.no_grad()
+    def update(self, sdf_fn, inv_s, step, generator=None, jitter=None):
+        if jitter is None:
+            jitter = torch.rand(self.res ** 3, 3, device=self.device, generator=generator)
+        sdf = sdf_fn(self.cell_points(jitter).contiguous()).reshape(-1)
+        prev = torch.sigmoid((sdf + 0.5 * step) * inv_s)
+        nxt = torch.sigmoid((sdf - 0.5 * step) * inv_s)
+        alpha = ((prev - nxt + 1e-5) / (prev + 1e-5)).clip(0.0, 1.0)
+        self.occ = torch.maximum(self.occ * self.decay, alpha)
+        self.binary = (self.occ > torch.clamp(self.occ.mean(), max=self.thre)).to(torch.uint8).contiguous()
+        return float(self.binary.float().mean())
+
+
 class HashNeuSRenderer(NeuSRenderer):
-    """NeuSRenderer over the hash-grid networks.  Same constructor, render() dict and train_step_core()."""
+    """NeuSRenderer over the hash-grid networks.  Same constructor, render() dict and train_step_core().
+    sampler = "hierarchical": the NeuS 64 + 64 sampler of the fp32 family (four no-grad SDF passes per iteration).
+    sampler = "occgrid": instant-nsr-pl's occupancy-grid marching with packed variable-length rays (csrc/march.hip): the
+    iteration evaluates the networks only on the samples that fall into occupied cells; the fused training step and the
+    forward-only frame renderer take this path, render() (the autograd dict API) stays on the hierarchical sampler."""
 
     def __init__(self, nerf, sdf_network: HashSDFNetwork, deviation_network: SingleVarianceNetwork,
-                 color_network: SHRenderingNetwork, *args, **kwargs):
+                 color_network: SHRenderingNetwork, *args, sampler="hierarchical", march_samples_per_ray=512, grid_res=128,
+                 grid_update_every=16, max_samples=128, **kwargs):
         if not isinstance(sdf_network, HashSDFNetwork) or not isinstance(color_network, SHRenderingNetwork):
             raise TypeError("HashNeuSRenderer needs HashSDFNetwork + SHRenderingNetwork")
+        if sampler not in ("hierarchical", "occgrid"):
+            raise ValueError("sampler must be 'hierarchical' or 'occgrid'")
+        if not 0 < max_samples <= 128:
+            raise ValueError("the packed render scan handles at most 128 samples per ray")
         super().__init__(nerf, sdf_network, deviation_network, color_network, *args, **kwargs)
         self.radius = sdf_network.radius
         self.fd_eps = sdf_network.fd_eps
+        self.sampler = sampler
+        self.max_samples = int(max_samples)
+        # instant-nsr-pl: render_step_size = 1.732 * 2 * radius / num_samples_per_ray
+        self.march_step = 1.732 * 2.0 * self.radius / float(march_samples_per_ray)
+        self.grid_update_every = int(grid_update_every)
+        self.grid = OccupancyGrid(grid_res, self.radius, device=self.store.device) if sampler == "occgrid" else None
+        self._march_iter = 0
+        self.last_march = None
 
     def _make_store(self, sdf_network, deviation_network, color_network, device):
         return HashParamStore(sdf_network, deviation_network, color_network, device)
@@ -137,6 +188,146 @@ class HashNeuSRenderer(NeuSRenderer):
         T("hash_geo_backward", L.dh_hash_geo_backward, _p(st.flat), _p(st.packed), _p(s.pts), _p(d_sdf), _p(d_feat),
           _p(d_normals), P, self.radius, self.fd_eps, _p(s.ws), _lib.stream())
         T("hash_weight_grads", L.dh_hash_weight_grads, _p(st.flat), _p(st.packed), P, _p(s.ws), _p(grad), _lib.stream())
+
+
+    # ------------------------------------------------------------------ occupancy-grid marching path (packed rays)
+    @torch.no_grad()
+    def update_grid(self, generator=None, jitter=None):
+        self.store.ensure_packed()
+        return self.grid.update(lambda p: self.sdf(p), self.store.inv_s(), self.march_step, generator=generator, jitter=jitter)
+
+    @torch.no_grad()
+    def march(self, rays_o, rays_d, near, far, u):
+        """Packed samples of the rays: SimpleNamespace(N, off [B] i64, cnt [B] i32, t_start [N], pts [N,3], dirs [N,3],
+        ray_idx [N]).  One device->host read of the total count (the downstream launches are sized by it)."""
+        from types import SimpleNamespace
+        L = _lib.lib()
+        B = rays_o.shape[0]
+        dev = rays_o.device
+        near = near.contiguous().view(-1); far = far.contiguous().view(-1)
+        u = None if u is None else u.contiguous().view(-1)
+        step = float(torch.tensor(self.march_step, dtype=torch.float32))
+        half = float(torch.tensor(0.5 * self.march_step, dtype=torch.float32))
+        cnt = torch.empty(B, dtype=torch.int32, device=dev)
+        g = self.grid
+        _lib.check(L.dh_march_count(_p(rays_o), _p(rays_d), _p(near), _p(far), _p(u), _p(g.binary), g.res, g.radius, step, half,
+                                    self.max_samples, B, _p(cnt), _lib.stream()))
+        csum = torch.cumsum(cnt, 0, dtype=torch.int64)
+        off = (csum - cnt).contiguous()
+        N = int(csum[-1].item())
+        m = SimpleNamespace(N=N, off=off, cnt=cnt, step=step)
+        m.t_start = torch.empty(max(N, 1), device=dev)
+        m.pts = torch.empty(max(N, 1), 3, device=dev)
+        m.dirs = torch.empty(max(N, 1), 3, device=dev)
+        m.ray_idx = torch.empty(max(N, 1), dtype=torch.int32, device=dev)
+        if N > 0:
+            _lib.check(L.dh_march_emit(_p(rays_o), _p(rays_d), _p(near), _p(far), _p(u), _p(g.binary), g.res, g.radius, step, half,
+                                       self.max_samples, B, _p(off), _p(m.t_start), _p(m.pts), _p(m.dirs), _p(m.ray_idx),
+                                       _lib.stream()))
+        return m
+
+    @torch.no_grad()
+    def _forward_packed(self, rays_o, rays_d, m, cos_anneal_ratio, background_rgb, want_nmap, infer_only=False):
+        from types import SimpleNamespace
+        L, T, st = _lib.lib(), self.timer, self.store
+        packed = st.ensure_packed()
+        dev = rays_o.device
+        B, N = rays_o.shape[0], m.N
+        s = SimpleNamespace(B=B, N=N, m=m, car=float(cos_anneal_ratio), bg=background_rgb, rays_o=rays_o, rays_d=rays_d,
+                            infer_only=infer_only)
+        P = max(N, 1)
+        s.ws = self._workspace(P, infer_only)
+        self._ws_token += 1
+        s.ws_token = self._ws_token
+        s.sdf = torch.zeros(P, device=dev); s.normals = torch.zeros(P, 3, device=dev); s.colors = torch.zeros(P, 3, device=dev)
+        s.feat = torch.zeros(P, 13, device=dev)
+        if N > 0:
+            T("hash_geo_forward", L.dh_hash_geo_forward, _p(st.flat), _p(packed), _p(m.pts), N, self.radius, self.fd_eps,
+              _p(s.ws), 0 if infer_only else 1, _p(s.sdf), _p(s.feat), _p(s.normals), _lib.stream())
+            T("hash_color_forward", L.dh_hash_color_forward, _p(packed), _p(s.feat), _p(s.normals), _p(m.dirs), 1, N,
+              _p(s.colors), _lib.stream())
+        s.inv_s = st.inv_s()
+        s.weights = torch.empty(P, device=dev); s.cdf = torch.empty(P, device=dev); s.inside = torch.empty(P, device=dev)
+        s.color = torch.empty(B, 3, device=dev); s.wsum = torch.empty(B, 1, device=dev); s.wmax = torch.empty(B, 1, device=dev)
+        s.eik = torch.empty(B, 2, device=dev)
+        s.nmap = torch.empty(B, 3, device=dev) if want_nmap else None
+        _lib.check(L.dh_render_scan_fwd_packed(_p(rays_o), _p(rays_d), _p(m.t_start), _p(s.sdf), _p(s.normals), _p(s.colors),
+                                               _p(s.inv_s), s.car, m.step, _p(background_rgb), B, _p(m.off), _p(m.cnt),
+                                               _p(s.weights), _p(s.color), _p(s.wsum), _p(s.wmax), _p(s.cdf), _p(s.inside),
+                                               _p(s.eik), _p(s.nmap), _lib.stream()))
+        return s
+
+    @torch.no_grad()
+    def _backward_packed(self, s, d_color, d_wsum, d_nmap, eik_coef):
+        L, T, st = _lib.lib(), self.timer, self.store
+        if s.ws_token != self._ws_token:
+            raise RuntimeError("workspace was overwritten by a later render before backward()")
+        m, B, N = s.m, s.B, s.N
+        dev = s.color.device
+        P = max(N, 1)
+        d_sdf = torch.zeros(P, device=dev); d_normals = torch.zeros(P, 3, device=dev); d_colors = torch.zeros(P, 3, device=dev)
+        d_inv_s = torch.empty(B, device=dev)
+        _lib.check(L.dh_render_scan_bwd_packed(_p(s.rays_o), _p(s.rays_d), _p(m.t_start), _p(s.sdf), _p(s.normals), _p(s.colors),
+                                               _p(s.inv_s), s.car, m.step, _p(s.bg), B, _p(m.off), _p(m.cnt), _p(d_color),
+                                               _p(d_wsum), _NULLP, _NULLP, _p(d_nmap), _p(eik_coef), _p(d_sdf), _p(d_normals),
+                                               _p(d_colors), _p(d_inv_s), _lib.stream()))
+        grad = torch.zeros(st.n, device=dev)
+        if N > 0:
+            d_feat = torch.empty(N, 13, device=dev)
+            T("hash_color_backward", L.dh_hash_color_backward, _p(st.packed), _p(s.feat), _p(s.normals), _p(m.dirs), _p(d_colors),
+              1, N, _p(s.ws), _p(d_feat), _p(d_normals), _lib.stream())
+            T("hash_geo_backward", L.dh_hash_geo_backward, _p(st.flat), _p(st.packed), _p(m.pts), _p(d_sdf), _p(d_feat),
+              _p(d_normals), N, self.radius, self.fd_eps, _p(s.ws), _lib.stream())
+            T("hash_weight_grads", L.dh_hash_weight_grads, _p(st.flat), _p(st.packed), N, _p(s.ws), _p(grad), _lib.stream())
+        raw = torch.exp(st.flat[st.var_off] * 10.0)
+        passthrough = ((raw >= 1e-6) & (raw <= 1e6)).float()
+        grad[st.var_off] = d_inv_s.sum() * 10.0 * raw * passthrough
+        st.grad_flat = grad
+        return grad
+
+    @torch.no_grad()
+    def train_step_core(self, rays, near, far, R, cos_anneal_ratio, igr_weight=0.1, mask_weight=0.1, normal_weight=0.0,
+                        background_rgb=None, t_rand=None, **kw):
+        if self.sampler != "occgrid":
+            return super().train_step_core(rays, near, far, R, cos_anneal_ratio, igr_weight, mask_weight, normal_weight,
+                                           background_rgb=background_rgb, t_rand=t_rand, **kw)
+        if kw.get("corr") is not None or kw.get("ray_grads"):
+            raise ValueError("the correspondence term / pose refinement run on the hierarchical sampler")
+        L = _lib.lib()
+        dev = rays.device
+        B = rays.shape[0]
+        if self._march_iter % self.grid_update_every == 0:
+            self.update_grid()
+        self._march_iter += 1
+        rays_o = rays[:, 0:3].contiguous(); rays_d = rays[:, 3:6].contiguous()
+        if t_rand is None and self.perturb > 0:
+            t_rand = torch.rand(B, 1, device=dev)
+        m = self.march(rays_o, rays_d, near, far, t_rand if self.perturb > 0 else None)
+        bg = None if background_rgb is None else background_rgb.reshape(-1).contiguous().float()
+        s = self._forward_packed(rays_o, rays_d, m, cos_anneal_ratio, bg, want_nmap=normal_weight > 0.0)
+        stats = torch.empty(8, device=dev)
+        d_color = torch.empty(B, 3, device=dev); d_wsum = torch.empty(B, device=dev)
+        d_nmap = torch.empty(B, 3, device=dev) if normal_weight > 0.0 else None
+        eik_coef = torch.empty(1, device=dev)
+        Rc = R.contiguous().float() if R is not None else None
+        _lib.check(L.dh_neus_loss(_p(s.color), _p(s.wsum), _p(s.nmap), _p(s.eik), _p(rays), _p(Rc), B, float(igr_weight),
+                                  float(mask_weight), float(normal_weight), _p(stats), _p(d_color), _p(d_wsum), _p(d_nmap),
+                                  _p(eik_coef), _lib.stream()))
+        self._backward_packed(s, d_color, d_wsum, d_nmap, eik_coef)
+        self.last_state = s
+        self.last_march = {"samples": m.N, "samples_per_ray": m.N / max(B, 1), "rays_at_cap": int((m.cnt >= self.max_samples).sum())}
+        return stats
+
+    @torch.no_grad()
+    def render_rays(self, rays_o, rays_d, near, far, cos_anneal_ratio, background_rgb=None, want_nmap=True):
+        """Forward-only colour (+ normal map) of a chunk of rays with this renderer's sampler (validation frames)."""
+        if self.sampler != "occgrid":
+            z = self.sample_z(rays_o, rays_d, near, far, perturb_overwrite=0)
+            st = self._forward_core(rays_o, rays_d, z, cos_anneal_ratio, background_rgb, want_nmap=want_nmap, infer_only=True)
+            return st.color, st.nmap
+        m = self.march(rays_o, rays_d, near, far, None)
+        st = self._forward_packed(rays_o, rays_d, m, cos_anneal_ratio, background_rgb, want_nmap, infer_only=True)
+        return st.color, st.nmap
 
 
 def build_hash_models(seed=1234, device="cuda"):

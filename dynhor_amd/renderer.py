@@ -321,6 +321,13 @@ class NeuSRenderer:
             s.d_rays_d = (dp * mid).sum(dim=1) + s.d_dirs_pts.view(B, n, 3).sum(dim=1) + d_rays_d
         return grad
 
+    @torch.no_grad()
+    def render_rays(self, rays_o, rays_d, near, far, cos_anneal_ratio, background_rgb=None, want_nmap=True):
+        """Forward-only colour (+ normal map) of a chunk of rays (validation frames): no perturbation, nothing saved."""
+        z = self.sample_z(rays_o, rays_d, near, far, perturb_overwrite=0)
+        st = self._forward_core(rays_o, rays_d, z, cos_anneal_ratio, background_rgb, want_nmap=want_nmap, infer_only=True)
+        return st.color, st.nmap
+
     # ------------------------------------------------------------------ render (App. A.5)
     def render(self, rays_o, rays_d, near, far, perturb_overwrite=-1, background_rgb=None, cos_anneal_ratio=0.0,
                t_rand=None, z_vals=None):

@@ -37,6 +37,9 @@ DEFAULT_CONF = {
     # family "neus": the 8x256 / 4x256 fp32 MLPs (BASELINE.json configs[1]); "hash": hash-grid + shallow MLPs (configs[3])
     "model": {"family": "neus", "sdf_network": {}, "variance_network": {"init_val": 0.3}, "rendering_network": {},
               "hash_sdf_network": {}, "sh_rendering_network": {},
+              # hash family only: sampler "hierarchical" (NeuS 64+64) or "occgrid" (instant-nsr-pl occupancy-grid marching)
+              "hash_renderer": {"sampler": "hierarchical", "march_samples_per_ray": 512, "grid_res": 128, "grid_update_every": 16,
+                                "max_samples": 128},
               "neus_renderer": {"n_samples": 64, "n_importance": 64, "n_outside": 0, "up_sample_steps": 4, "perturb": 1.0}},
 }
 
@@ -105,8 +108,9 @@ class Runner:
             self.deviation_network = SingleVarianceNetwork(**self.conf["model"]["variance_network"])
         self.nerf_outside = None
         self.store = store_cls(self.sdf_network, self.deviation_network, self.color_network, self.device)
+        extra = self.conf["model"]["hash_renderer"] if family == "hash" else {}
         self.renderer = renderer_cls(self.nerf_outside, self.sdf_network, self.deviation_network, self.color_network,
-                                     store=self.store, device=self.device, **self.conf["model"]["neus_renderer"])
+                                     store=self.store, device=self.device, **self.conf["model"]["neus_renderer"], **extra)
         self.pose_refiner = None
         if tr["refine_poses"]:
             from .pose import PoseRefiner
@@ -306,9 +310,8 @@ class Runner:
         for s in range(0, rays.shape[0], chunk):
             r = rays[s:s + chunk]
             o, d = r[:, :3].contiguous(), r[:, 3:6].contiguous()
-            z = self.renderer.sample_z(o, d, near[s:s + chunk], far[s:s + chunk], perturb_overwrite=0)
-            st = self.renderer._forward_core(o, d, z, self.get_cos_anneal_ratio(), bg, want_nmap=True, infer_only=True)
-            cols.append(st.color); nrms.append(st.nmap)
+            c, nm = self.renderer.render_rays(o, d, near[s:s + chunk], far[s:s + chunk], self.get_cos_anneal_ratio(), bg)
+            cols.append(c); nrms.append(nm)
         return torch.cat(cols).view(h, w, 3), torch.cat(nrms).view(h, w, 3), rays.view(h, w, 14)
 
     @torch.no_grad()

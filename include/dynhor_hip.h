@@ -190,6 +190,36 @@ int dh_corr_loss(const float* rays_o, const float* rays_d, const float* z, const
                  const float* R_all, const float* T_all, int n_frames, const float* K, int64_t B, int n, float sample_dist,
                  float delta_px, float corr_weight, float* stats, float* residual_px, float* d_weights, void* stream);
 
+/* ---- occupancy-grid ray marching, packed variable-length rays (BASELINE.json configs[3]) -------
+ * The sampler of the instant-nsr-pl variant the reference names as its direction (README.md:11,13; code on an unmounted
+ * branch; it calls nerfacc's OccupancyGrid / ray_marching).  Specification: oracle/occgrid_oracle.py (parity unpinned).
+ *   occupancy: res^3 bytes (non-zero = occupied) over the cube [-radius, radius]^3, cell (ix,iy,iz) at (ix*res + iy)*res + iz.
+ *   Step k of ray r is [t_k, t_k + step], t_k = near + (k + u[r]) step (u: one stratified offset per ray, null = 0.5); it is a
+ *   sample iff t_k + step <= far and the cell of its mid-point is occupied; at most max_samples (<= 128) per ray, front to back.
+ *   half_step = (float)(0.5 * step) as the caller rounds it (kept separate so host and device agree bit for bit).
+ * dh_march_count -> cnt [B]; the caller forms off = exclusive prefix sum (int64) and N = sum cnt, then dh_march_emit writes
+ * t_start [N], the mid-point positions pts [N,3], the ray direction per sample dirs_pts [N,3] (pass it as `dirs` with
+ * n_per_ray = 1 to the colour stages) and ray_idx [N].  No atomics: the packed order is a pure function of the inputs. */
+int dh_march_count(const float* rays_o, const float* rays_d, const float* near, const float* far, const float* u,
+                   const uint8_t* occupancy, int res, float radius, float step, float half_step, int max_samples, int64_t B,
+                   int32_t* cnt, void* stream);
+int dh_march_emit(const float* rays_o, const float* rays_d, const float* near, const float* far, const float* u,
+                  const uint8_t* occupancy, int res, float radius, float step, float half_step, int max_samples, int64_t B,
+                  const int64_t* off, float* t_start, float* pts, float* dirs_pts, int32_t* ray_idx, void* stream);
+/* dh_render_scan_fwd / _bwd over packed rays: ray r owns samples [seg_off[r], seg_off[r] + seg_cnt[r]) of the packed arrays
+ * (seg_cnt <= 128), every interval is `step` long and t_start holds the interval starts; per-sample outputs are packed too. */
+int dh_render_scan_fwd_packed(const float* rays_o, const float* rays_d, const float* t_start, const float* sdf, const float* normals,
+                              const float* colors, const float* inv_s, float cos_anneal_ratio, float step,
+                              const float* background_rgb, int64_t B, const int64_t* seg_off, const int32_t* seg_cnt,
+                              float* weights, float* color, float* weight_sum, float* weight_max, float* cdf,
+                              float* inside_sphere, float* eik_partial, float* normal_map, void* stream);
+int dh_render_scan_bwd_packed(const float* rays_o, const float* rays_d, const float* t_start, const float* sdf, const float* normals,
+                              const float* colors, const float* inv_s, float cos_anneal_ratio, float step,
+                              const float* background_rgb, int64_t B, const int64_t* seg_off, const int32_t* seg_cnt,
+                              const float* d_color, const float* d_weight_sum, const float* d_weights, const float* d_gradients,
+                              const float* d_normal_map, const float* eik_coef, float* d_sdf, float* d_normals, float* d_colors,
+                              float* d_inv_s, void* stream);
+
 /* ---- optimiser -----------------------------------------------------------------------------------------
  * torch.optim.Adam step (upstream Runner uses Adam, App. A.8; the reference's own optimisers are Adam too:
  * ObjTracker/pose_initializtion.py:346, jointopt.py:135-141) fused over the flat vector; step counts from 1;

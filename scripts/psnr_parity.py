@@ -126,8 +126,7 @@ def eval_psnr(runner, it, level, frames=None, chunk=8192):
         for s in range(0, rays.shape[0], chunk):
             r = rays[s:s + chunk]
             o, d = r[:, :3].contiguous(), r[:, 3:6].contiguous()
-            z = runner.renderer.sample_z(o, d, near[s:s + chunk], far[s:s + chunk], perturb_overwrite=0)
-            col = runner.renderer._forward_core(o, d, z, car, None, want_nmap=False, infer_only=True).color
+            col, _ = runner.renderer.render_rays(o, d, near[s:s + chunk], far[s:s + chunk], car, None, want_nmap=False)
             m = r[:, 9:10] * r[:, 10:11]
             se += float((((col - r[:, 6:9]) ** 2) * m).sum())
             n += float(m.sum()) * 3.0

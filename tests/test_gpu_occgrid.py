@@ -1,0 +1,225 @@
+"""GPU: occupancy-grid ray marching with packed variable-length rays for the hash family (BASELINE.json configs[3]; SURVEY.md
+section 8f n3; specification oracle/occgrid_oracle.py -- instant-nsr-pl / nerfacc behaviour restated, parity unpinned):
+the marcher selects exactly the oracle's samples, the packed render scan and its adjoint match the oracle's autograd, the
+fused training step on packed rays matches the oracle end to end, and the Runner trains / validates with sampler = occgrid."""
+import pytest
+import torch
+
+from oracle import hashgrid_oracle as HO
+from oracle import neus_oracle as O
+from oracle import occgrid_oracle as G
+
+pytestmark = pytest.mark.gpu
+
+
+def _rays(B, seed):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    o = torch.nn.functional.normalize(torch.randn(B, 3, generator=g), dim=-1) * (2.0 + 0.5 * torch.rand(B, 1, generator=g))
+    d = torch.nn.functional.normalize(-o + 0.35 * torch.randn(B, 3, generator=g), dim=-1)
+    o, d = o.cuda().contiguous(), d.cuda().contiguous()
+    near, far = O.near_far_from_sphere(o, d)
+    u = torch.rand(B, generator=g).cuda()
+    return o, d, near.contiguous(), far.contiguous(), u
+
+
+def _blob_grid(res, seed):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    grid = G.OccupancyGrid(res=res, radius=1.0, device="cuda")
+    ax = (torch.arange(res) + 0.5) / res * 2 - 1
+    x, y, z = torch.meshgrid(ax, ax, ax, indexing="ij")
+    occ = torch.zeros(res, res, res, dtype=torch.bool)
+    for _ in range(6):
+        c = (torch.rand(3, generator=g) - 0.5) * 1.0
+        r = 0.12 + 0.2 * torch.rand(1, generator=g).item()
+        occ |= ((x - c[0]) ** 2 + (y - c[1]) ** 2 + (z - c[2]) ** 2) < r * r
+    grid.binary = occ.reshape(-1).cuda()
+    return grid
+
+
+def _hip_march(o, d, near, far, u, grid, step, max_samples=128):
+    from types import SimpleNamespace
+    from dynhor_amd import _lib
+    from dynhor_amd.renderer import _p
+    L = _lib.lib()
+    B = o.shape[0]
+    binary = grid.binary.to(torch.uint8).contiguous()
+    stepf = float(torch.tensor(step, dtype=torch.float32)); half = float(torch.tensor(0.5 * step, dtype=torch.float32))
+    cnt = torch.empty(B, dtype=torch.int32, device="cuda")
+    nr, fr = near.view(-1).contiguous(), far.view(-1).contiguous()
+    _lib.check(L.dh_march_count(_p(o), _p(d), _p(nr), _p(fr), _p(u), _p(binary), grid.res, grid.radius, stepf, half, max_samples, B,
+                                _p(cnt), _lib.stream()))
+    cs = torch.cumsum(cnt, 0, dtype=torch.int64); off = (cs - cnt).contiguous(); N = int(cs[-1])
+    m = SimpleNamespace(N=N, off=off, cnt=cnt, step=stepf, t_start=torch.empty(N, device="cuda"), pts=torch.empty(N, 3, device="cuda"),
+                        dirs=torch.empty(N, 3, device="cuda"), ray_idx=torch.empty(N, dtype=torch.int32, device="cuda"))
+    _lib.check(L.dh_march_emit(_p(o), _p(d), _p(nr), _p(fr), _p(u), _p(binary), grid.res, grid.radius, stepf, half, max_samples, B,
+                               _p(off), _p(m.t_start), _p(m.pts), _p(m.dirs), _p(m.ray_idx), _lib.stream()))
+    return m
+
+
+@pytest.mark.parametrize("B,res,step,cap", [(513, 64, 0.0135, 128), (2048, 128, 1.732 * 2 / 512, 128), (37, 32, 0.02, 16)])
+def test_marcher_selects_exactly_the_oracle_samples(B, res, step, cap):
+    o, d, near, far, u = _rays(B, seed=B)
+    grid = _blob_grid(res, seed=res)
+    stepf = float(torch.tensor(step, dtype=torch.float32))
+    ref = G.march(o, d, near, far, u, grid, stepf, max_samples=cap)
+    m = _hip_march(o, d, near, far, u, grid, step, cap)
+    assert int(ref["cnt"].sum()) > 5 * B // 4 or cap == 16, "the case must actually produce samples"
+    assert torch.equal(m.cnt.long(), ref["cnt"]), "per-ray sample counts"
+    assert torch.equal(m.off, ref["off"]) and m.N == ref["t_start"].shape[0]
+    assert torch.equal(m.t_start, ref["t_start"]), "interval starts, bit for bit (same fp32 expression order)"
+    assert torch.equal(m.ray_idx.long(), ref["ray_idx"])
+    tm = m.t_start + float(torch.tensor(0.5 * step, dtype=torch.float32))
+    assert torch.equal(m.pts, o[m.ray_idx.long()] + d[m.ray_idx.long()] * tm[:, None])
+    assert torch.equal(m.dirs, d[m.ray_idx.long()])
+    assert (m.cnt <= cap).all() and (m.cnt == cap).any() == bool(ref["truncated"].any())
+    # every sample's mid-point lies in an occupied cell, inside [near, far]
+    assert grid.query(m.pts).all()
+    assert (m.t_start >= near.view(-1)[m.ray_idx.long()] - 1e-6).all() and (m.t_start + stepf <= far.view(-1)[m.ray_idx.long()] + 1e-6).all()
+    # no stratified offsets (validation): u = null means 0.5
+    m2 = _hip_march(o, d, near, far, None, grid, step, cap)
+    ref2 = G.march(o, d, near, far, torch.full_like(u, 0.5), grid, stepf, max_samples=cap)
+    assert torch.equal(m2.t_start, ref2["t_start"])
+
+
+def test_packed_render_scan_and_adjoint_match_oracle():
+    from dynhor_amd import _lib
+    from dynhor_amd.renderer import _p
+    L = _lib.lib()
+    B, step = 300, 0.01
+    o, d, near, far, u = _rays(B, seed=7)
+    grid = _blob_grid(64, seed=3)
+    m = _hip_march(o, d, near, far, u, grid, step, 128)
+    N = m.N
+    g = torch.Generator(device="cpu").manual_seed(1)
+    sdf = (torch.randn(N, generator=g) * 0.05).cuda()
+    normals = torch.nn.functional.normalize(torch.randn(N, 3, generator=g), dim=-1).cuda() * (0.7 + 0.6 * torch.rand(N, 1, generator=g).cuda())
+    colors = torch.rand(N, 3, generator=g).cuda()
+    inv_s = torch.tensor([35.0], device="cuda")
+    car, bg = 0.3, torch.tensor([0.2, 0.5, 0.9], device="cuda")
+    w = torch.empty(N, device="cuda"); cdf = torch.empty(N, device="cuda"); ins = torch.empty(N, device="cuda")
+    col = torch.empty(B, 3, device="cuda"); ws = torch.empty(B, 1, device="cuda"); wm = torch.empty(B, 1, device="cuda")
+    eik = torch.empty(B, 2, device="cuda"); nm = torch.empty(B, 3, device="cuda")
+    _lib.check(L.dh_render_scan_fwd_packed(_p(o), _p(d), _p(m.t_start), _p(sdf), _p(normals), _p(colors), _p(inv_s), car, m.step, _p(bg), B,
+                                           _p(m.off), _p(m.cnt), _p(w), _p(col), _p(ws), _p(wm), _p(cdf), _p(ins), _p(eik), _p(nm), _lib.stream()))
+    s64, n64, c64 = sdf.double().requires_grad_(True), normals.double().requires_grad_(True), colors.double().requires_grad_(True)
+    ref = G.render_packed(m.pts.double(), s64, n64, c64, d.double(), m.ray_idx.long(), m.off, m.cnt.long(), float(m.step), inv_s.double(), car, bg.double())
+    assert (col.double() - ref["color_fine"]).abs().max().item() < 2e-5
+    assert (ws.double() - ref["weight_sum"]).abs().max().item() < 2e-5
+    assert (w.double() - ref["weights"]).abs().max().item() < 2e-5
+    assert (nm.double() - ref["normal_map"]).abs().max().item() < 5e-5
+    ge = eik[:, 0].sum() / (eik[:, 1].sum() + 1e-5)
+    assert abs(ge.item() - ref["gradient_error"].item()) < 1e-5
+    empty = m.cnt == 0
+    assert empty.any() and (ws[empty] == 0).all() and torch.allclose(col[empty], bg.expand(int(empty.sum()), 3))
+    # adjoint: a random linear functional of the outputs
+    gc = torch.randn(B, 3, generator=g).cuda(); gw = torch.randn(B, generator=g).cuda(); gn = torch.randn(B, 3, generator=g).cuda()
+    ec = torch.tensor([0.37], device="cuda")
+    functional = ((ref["color_fine"] * gc.double()).sum() + (ref["weight_sum"][:, 0] * gw.double()).sum()
+                  + (ref["normal_map"] * gn.double()).sum()
+                  + ec.double()[0] * (eik[:, 1].sum().double() + 1e-5) * ref["gradient_error"])
+    functional.backward()
+    d_sdf = torch.empty(N, device="cuda"); d_n = torch.empty(N, 3, device="cuda"); d_c = torch.empty(N, 3, device="cuda"); d_is = torch.empty(B, device="cuda")
+    null = _lib.ptr(torch.empty(1, device="cuda")).__class__(0)
+    _lib.check(L.dh_render_scan_bwd_packed(_p(o), _p(d), _p(m.t_start), _p(sdf), _p(normals), _p(colors), _p(inv_s), car, m.step, _p(bg), B,
+                                           _p(m.off), _p(m.cnt), _p(gc), _p(gw), null, null, _p(gn), _p(ec), _p(d_sdf), _p(d_n), _p(d_c),
+                                           _p(d_is), _lib.stream()))
+    for name, got, want in (("d_sdf", d_sdf, s64.grad), ("d_normals", d_n, n64.grad), ("d_colors", d_c, c64.grad)):
+        rel = ((got.double() - want).norm() / want.norm()).item()
+        print(name, "rel err", f"{rel:.2e}")
+        assert rel < 1e-4, name
+
+
+def _oracle_hash_models(like_runner, dev):
+    sdf, col = HO.build_models(seed=1234, device=dev)
+    var = O.SingleVarianceNetwork(0.3).to(dev)
+    sdf.load_state_dict(like_runner.sdf_network.state_dict()); col.load_state_dict(like_runner.color_network.state_dict())
+    var.load_state_dict(like_runner.deviation_network.state_dict())
+    return sdf, col, var
+
+
+@pytest.fixture(scope="module")
+def occ_runner(tmp_path_factory):
+    from dynhor_amd.runner import Runner
+    conf = {"seq_name": "occ", "exp_name": "e", "data_info": {"synthetic": {"n_frames": 6, "H": 96, "W": 96, "seed": 11}},
+            "train": {"batch_size": 512, "normal_weight": 0.05, "learning_rate": 5e-3, "report_freq": 10 ** 9, "save_freq": 10 ** 9,
+                      "val_freq": 0, "warm_up_end": 20, "end_iter": 2000},
+            "model": {"family": "hash", "hash_renderer": {"sampler": "occgrid", "march_samples_per_ray": 256, "grid_res": 64,
+                                                         "grid_update_every": 8}}}
+    return Runner(conf=conf, device="cuda:0", exp_root=str(tmp_path_factory.mktemp("exps")))
+
+
+def test_fused_training_step_on_packed_rays_matches_oracle(occ_runner):
+    r = occ_runner
+    ren, ds = r.renderer, r.dataset
+    dev = torch.device("cuda:0")
+    o_sdf, o_col, o_var = _oracle_hash_models(r, dev)
+    g = torch.Generator(device=dev); g.manual_seed(3)
+    jitter = torch.rand(ren.grid.res ** 3, 3, device=dev, generator=g)
+    frac = ren.update_grid(jitter=jitter)
+    # the grid the product built == the oracle's update from the same jitter (sdf through the oracle network)
+    og = G.OccupancyGrid(res=ren.grid.res, radius=1.0, device=dev)
+    with torch.no_grad():
+        inv_s = o_var(torch.zeros(1, 3, device=dev))[:, :1].clip(1e-6, 1e6).reshape(())
+        og.update(G.occ_alpha(o_sdf.sdf(og.cell_points(jitter)).reshape(-1), inv_s, ren.march_step))
+    agree = (og.binary == ren.grid.binary.bool()).float().mean().item()
+    print(f"occupied fraction {frac:.3f}; grid agreement with the oracle {agree:.5f}")
+    assert 0.0 < frac < 0.6 and agree > 0.999          # a cell can flip only where fp32 sdf rounding straddles the threshold
+    B, frame, car = 512, 2, 0.2
+    rays = ds.gen_random_rays_at(frame, B, generator=g)
+    near, far = ds._last_near_far
+    u = torch.rand(B, 1, device=dev, generator=g)
+    ren._march_iter = 1                                   # no grid update inside the step
+    stats = ren.train_step_core(rays, near, far, ds.R[frame], car, 0.1, 0.1, 0.05, t_rand=u)
+    torch.cuda.synchronize()
+    m = ren.last_state.m
+    assert m.N > B and ren.last_march["samples"] == m.N
+    # oracle on the SAME packed samples (the marcher itself is checked above), fp64 networks
+    for mod in (o_sdf, o_col, o_var):
+        mod.double(); mod.zero_grad()
+    pts = m.pts.double()
+    out = o_sdf(pts)
+    sdf = out[:, 0]                                       # forward = cat[sdf, feature(13)] (oracle/hashgrid_oracle.py:118)
+    nrm = o_sdf.gradient(pts).reshape(-1, 3)
+    dirs = m.dirs.double()
+    colr = o_col(pts, nrm, dirs, out[:, 1:])
+    inv_s = o_var(torch.zeros(1, 3, device=dev, dtype=torch.float64))[:, :1].clip(1e-6, 1e6).reshape(())
+    ro = G.render_packed(pts, sdf, nrm, colr, rays[:, 3:6].double(), m.ray_idx.long(), m.off, m.cnt.long(), float(m.step), inv_s, car)
+    rd = {"color_fine": ro["color_fine"], "weight_sum": ro["weight_sum"], "gradient_error": ro["gradient_error"],
+          "gradients": ro["normal_map"][:, None, :], "weights": torch.ones(B, 1, dtype=torch.float64, device=dev)}
+    r64 = rays.double()
+    ref = O.neus_losses(rd, r64[:, 6:9], r64[:, 9:10], r64[:, 10:11], 0.1, 0.1, 0.05, r64[:, 11:14], ds.R[frame].double())
+    ref["loss"].backward()
+    names = ["loss", "color_loss", "eikonal_loss", "mask_loss", "normal_loss", "psnr"]
+    for i, k in enumerate(names):
+        assert abs(stats[i].item() - float(ref[k])) < 1e-4 * max(1.0, abs(float(ref[k]))), (k, stats[i].item(), float(ref[k]))
+    # gradient by parameter group (table: float atomics + fp32 finite-difference normals, as in tests/test_gpu_hash_family.py)
+    st = r.store
+    named = {}
+    for mod, pre in ((o_sdf, "sdf."), (o_var, "var."), (o_col, "col.")):
+        for n_, p in mod.named_parameters():
+            named[pre + n_] = p.grad
+    tab = named["sdf.encoding.table"] if "sdf.encoding.table" in named else [v for k, v in named.items() if "table" in k][0]
+    (p0, off0, cnt0) = st.slices[0]
+    got_tab = st.grad_flat[off0:off0 + cnt0].double().view_as(tab)
+    rel_tab = ((got_tab - tab).norm() / tab.norm()).item()
+    print(f"packed-ray step: loss {stats[0].item():.6f} (oracle {float(ref['loss']):.6f}); table grad rel {rel_tab:.2e}; samples/ray {m.N / B:.1f}")
+    assert rel_tab < 2e-3
+    for mod in (o_sdf, o_col, o_var):
+        mod.float()
+
+
+def test_runner_trains_and_validates_with_occupancy_grid_sampler(occ_runner):
+    r = occ_runner
+    first = None
+    for _ in range(40):
+        s = r.train_iteration()
+        first = first if first is not None else float(s[0])
+    assert float(s[0]) < first and torch.isfinite(r.store.flat).all()
+    lm = r.renderer.last_march
+    assert 0 < lm["samples_per_ray"] <= 128
+    occ_frac = float(r.renderer.grid.binary.float().mean())
+    assert 0.0 < occ_frac < 0.6, "the grid prunes empty space"
+    psnr = r.validate_image(idx=0, resolution_level=2)
+    assert psnr == psnr and psnr > 5
+    with pytest.raises(ValueError):
+        r.renderer.train_step_core(r._last_rays, *r.dataset._last_near_far, r.dataset.R[0], 0.1, ray_grads=True)
