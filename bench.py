@@ -98,6 +98,11 @@ def main():
     ap.add_argument("--family", choices=["neus", "hash"], default="neus",
                     help="neus = BASELINE.json configs[1] (the headline); hash = configs[3] (hash-grid encoding + shallow MLPs)")
     ap.add_argument("--arithmetic", choices=["split_bf16", "fp32_mfma"], default="split_bf16")
+    ap.add_argument("--loss", choices=["cfg2", "full"], default="cfg2",
+                    help="cfg2 = rgb + eikonal + mask + mono-normal (the headline config); full = BASELINE.json configs[4]'s loss "
+                         "stack: additionally the dense-correspondence reprojection term on a quarter of the rays")
+    ap.add_argument("--hash-sampler", choices=["hierarchical", "occgrid"], default="hierarchical",
+                    help="hash family only: NeuS 64+64 sampler or instant-nsr-pl occupancy-grid marching (packed rays)")
     ap.add_argument("--rays-per-rank", type=int, default=2048,
                     help="2048 = throughput mode (weak scaling, the headline); 2048/N = fixed global batch (PSNR-parity mode)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -133,11 +138,13 @@ def main():
     arith = _lib.ARITH_FP32_MFMA if args.arithmetic == "fp32_mfma" else _lib.ARITH_SPLIT_BF16
     _lib.set_arithmetic(arith)
     hash_family = args.family == "hash"
+    full = args.loss == "full"
     conf = {"seq_name": "bench_synth", "exp_name": f"r{rank}",
-            "data_info": {"synthetic": {"n_frames": args.frames, "H": 512, "W": 512, "seed": 4321}},
+            "data_info": {"synthetic": {"n_frames": args.frames, "H": 512, "W": 512, "seed": 4321,
+                                        "correspondences": 2048 if full else 0}},
             "train": {"batch_size": args.rays_per_rank, "normal_weight": 0.05, "report_freq": 10 ** 9, "save_freq": 10 ** 9,
-                      "val_freq": 0},
-            "model": {"family": args.family}}
+                      "val_freq": 0, "corr_weight": 0.1 if full else 0.0, "corr_fraction": 0.25},
+            "model": {"family": args.family, "hash_renderer": {"sampler": args.hash_sampler}}}
     runner = Runner(conf=conf, device=device, exp_root=os.path.join("/tmp", "dynhor_bench_exps"))
     B = runner.batch_size
     n_samples = runner.renderer.n_samples + runner.renderer.n_importance
@@ -231,8 +238,9 @@ def main():
             # memory-side-atomic bound.  Algorithmic bytes per launch = every add the per-evaluation scatter defines (7
             # evaluations x 16 levels x 8 corners x 2 features x 4 B per sample) + one read of the dW operands.
             dom = "hash_weight_grads"
-            add_bytes = 7 * P * 16 * 8 * 2 * 4
-            dw_bytes = 7 * P * (64 + 36 + 13 + 64) * 4 + P * (64 + 32 + 64 + 64 + 3 + 64) * 4
+            Pk = runner.renderer.last_march["samples"] if args.hash_sampler == "occgrid" else P     # packed rays: the last step's count
+            add_bytes = 7 * Pk * 16 * 8 * 2 * 4
+            dw_bytes = 7 * Pk * (64 + 36 + 13 + 64) * 4 + Pk * (64 + 32 + 64 + 64 + 3 + 64) * 4
             tsec = per_kernel[dom]["ms"] * 1e-3
             kernel = _lib.HASH_STAGE_KERNELS[dom]
             traffic, tsrc = offline_traffic(dom, kernel)
@@ -242,9 +250,14 @@ def main():
                     "avg_launch_ms": per_kernel[dom]["ms"],
                     "algorithmic_bytes": {"scatter_adds": add_bytes, "dw_operands": dw_bytes},
                     "memory_side_float_atomic_peak_GBps": 1300.0}
+            if args.hash_sampler == "occgrid":
+                lm = runner.renderer.last_march
+                per_kernel["march"] = {"samples_per_ray_last_step": round(lm["samples_per_ray"], 2), "rays_at_cap": lm["rays_at_cap"]}
             workload = (f"instant-nsr-pl-shaped hash-grid family (BASELINE.json configs[3]): 16-level x 2-feature hash grid (T = 2^19) + "
                         f"1x64 geometry MLP with finite-difference normals + SH-4 2x64 colour MLP, custom_shoes-shaped synthetic seq, "
-                        f"512x512, {B} rays x (64+64) samples per rank, full training iteration")
+                        f"512x512, {B} rays x " + ("(64+64) samples" if args.hash_sampler == "hierarchical" else
+                                                     "occupancy-grid marching (packed rays, <= 128 samples per ray)")
+                        + " per rank, full training iteration")
             arithmetic = "fp32 everywhere (VALU / fp32 MFMA for the small dW GEMMs); table gradient by float atomics"
         else:
             names = _lib.STAGE_KERNELS[arith]
@@ -279,7 +292,9 @@ def main():
                "scaling": "weak" if args.rays_per_rank == 2048 else "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": workload, "family": args.family, "frames": args.frames, "rays_per_rank": B,
                           "samples_per_ray": n_samples, "parallelism": f"dp{world}",
-                          "loss": "rgb L1 + 0.1 eikonal + 0.1 mask BCE + 0.05 mono-normal", "arithmetic": arithmetic},
+                          "loss": "rgb L1 + 0.1 eikonal + 0.1 mask BCE + 0.05 mono-normal"
+                                  + (" + 0.1 dense-correspondence reprojection (Huber 4 px) on 25 % of the rays" if full else ""),
+                          "arithmetic": arithmetic},
                "roofline": roof, "kernels": per_kernel,
                "final_stats": {"loss": round(float(stats[0]), 5), "psnr": round(float(stats[5]), 3)}}
         if comm is not None:

@@ -8,13 +8,21 @@
 // prefix pop-counts give every kept step its slot, so samples come out front to back with no atomics and no sort -- packed
 // order is a pure function of the inputs (bitwise reproducible).  Two launches: count -> (exclusive scan on the caller's side)
 // -> emit, both running the identical test.
-// Positions and cell indices use explicitly rounded fp32 operations (no fma contraction) in the order the oracle's tensor
-// expressions evaluate, so the two select exactly the same cells.
+// Positions and cell indices use separately rounded fp32 operations in the order the oracle's tensor expressions evaluate, so
+// the two select exactly the same cells and produce bit-identical interval starts.  HIP's __fmul_rn / __fadd_rn are plain
+// operators that hipcc contracts into fma (also under `#pragma clang fp contract(off)` once inlined): the multiplies go
+// through a one-instruction asm, which nothing can fuse.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "kernels.h"
 
 namespace dh {
+
+__device__ __forceinline__ float mul_rn(float a, float b) {
+    float r;
+    asm("v_mul_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 
 struct MarchRay {
     float o[3], d[3], near, far, u;
@@ -23,19 +31,19 @@ struct MarchRay {
 // returns whether step k of the ray is a sample; x = mid-point position, t0 = interval start
 __device__ __forceinline__ bool march_test(const MarchRay& r, int k, float step, float half_step, float inv2r, int res,
                                            const uint8_t* __restrict__ occ, float& t0, float (&x)[3]) {
-    t0 = __fadd_rn(r.near, __fmul_rn(__fadd_rn((float)k, r.u), step));
-    const float tm = __fadd_rn(t0, half_step);
+    t0 = r.near + mul_rn((float)k + r.u, step);
+    const float tm = t0 + half_step;
     bool inside = true;
     int idx[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-        x[c] = __fadd_rn(r.o[c], __fmul_rn(r.d[c], tm));
-        const float g = __fmul_rn(__fadd_rn(__fmul_rn(x[c], inv2r), 0.5f), (float)res);
+        x[c] = r.o[c] + mul_rn(r.d[c], tm);
+        const float g = mul_rn(mul_rn(x[c], inv2r) + 0.5f, (float)res);
         const float f = floorf(g);
         inside = inside && f >= 0.f && f < (float)res;
         idx[c] = (int)f;
     }
-    if (!(__fadd_rn(t0, step) <= r.far) || !inside) return false;
+    if (!(t0 + step <= r.far) || !inside) return false;
     return occ[((int64_t)idx[0] * res + idx[1]) * res + idx[2]] != 0;
 }
 
