@@ -105,11 +105,10 @@ __global__ __launch_bounds__(256) void hash_sdf_nograd_kernel(HashLevels H, cons
 //      8-byte gathers instead of 7 x 128.  Writes the encodings feature-major into rows 3..34 of GIN [36][lde]
 //      (row r = e n + p) -- the same rows the backward's weight-gradient GEMM reads, so nothing is gathered twice.
 //   2. hash_geo_mlp_fwd_kernel -- one thread per point: the 35 -> 64 -> 13 MLP on the 7 encoded inputs (weights in LDS).
-// COARSE_LDS levels (0 and 1: 16^3 and 23^3 entries = 32 / 95 KiB) are launched apart with persistent workgroups that first copy
-// the level's dense table slice into LDS and gather from there ("LDS-resident grid tiles", BASELINE.json configs[3]); the finer
-// levels (238 KiB and up, then 4 MiB hashed) gather from L2 / Infinity Cache.  `lvl` = the level's entries (global or LDS),
-// indices are level-local.
-constexpr int HG_LDS_LEVELS = 2;
+// `lvl` = the level's entries, indices are level-local.  (Round 2 tried "LDS-resident grid tiles" as BASELINE.json configs[3] words
+// it: levels 0 and 1 -- 16^3 and 23^3 entries = 32 / 95 KiB, the only ones that fit -- launched apart with persistent workgroups
+// that copy the level's slice into LDS and gather from there.  At 262,144 points the staging costs more than the L1 / L2 hits it
+// replaces: hash_geo_forward 0.48 vs 0.44 ms on one box, so the single launch below stays)
 __device__ __forceinline__ uint32_t hg_index_local(const HashLevels& H, int l, uint32_t x, uint32_t y, uint32_t z) {
     const uint32_t res = H.res[l];
     return H.dense[l] ? ((x + y * res + z * res * res) % H.size[l]) : (((x * 1u) ^ (y * 2654435761u) ^ (z * 805459861u)) & (HG_T - 1));
@@ -183,20 +182,6 @@ __global__ __launch_bounds__(256) void hash_encode7_kernel(HashLevels H, const f
     const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (p >= n) return;
     encode7_point(H, reinterpret_cast<const float2*>(table) + H.offset[l], l, p, pts, n, radius, eps, gin, lde);
-}
-
-// coarse levels: persistent workgroups, the level's table slice staged in LDS once per workgroup
-__global__ __launch_bounds__(256) void hash_encode7_lds_kernel(HashLevels H, const float* __restrict__ table,
-                                                               const float* __restrict__ pts, int64_t n, float radius, float eps,
-                                                               float* __restrict__ gin, int64_t lde) {
-    extern __shared__ __attribute__((aligned(16))) float2 lvl_lds[];
-    const int l = blockIdx.y;
-    const f32x4* src = reinterpret_cast<const f32x4*>(reinterpret_cast<const float2*>(table) + H.offset[l]);
-    f32x4* dst = reinterpret_cast<f32x4*>(lvl_lds);
-    for (uint32_t i = threadIdx.x; i < H.size[l] / 2; i += 256) dst[i] = src[i];      // size is a multiple of 8 entries
-    __syncthreads();
-    for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < n; p += (int64_t)gridDim.x * 256)
-        encode7_point(H, lvl_lds, l, p, pts, n, radius, eps, gin, lde);
 }
 
 // the geometry MLP on one encoded input (rows 3..34 of GIN); FULL: all 13 outputs, else sdf only
@@ -739,21 +724,8 @@ int launch_hash_geo_fwd(const float* params, const float* hp, const float* pts, 
     const HashWs O = make_hash_ws(n);
     float* gin = save ? ws + O.gin : ws;               // forward-only callers hand over just the GIN rows
     const unsigned nb = (unsigned)((n + 255) / 256);
-    const HashLevels HL = hashgrid_levels();
-    const float* table = params + hash_param_off().table;
-    // levels 0..1: LDS-resident table slices (dynamic LDS = the larger level: 95 KiB -> one persistent workgroup per CU)
-    static bool lds_attr = false;
-    const size_t lds_bytes = (size_t)HL.size[HG_LDS_LEVELS - 1] * sizeof(float2);
-    if (!lds_attr) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(hash_encode7_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)lds_bytes) != hipSuccess) return -3;
-        lds_attr = true;
-    }
-    const unsigned nbl = nb < 256u ? nb : 256u;
-    hipLaunchKernelGGL(hash_encode7_lds_kernel, dim3(nbl, HG_LDS_LEVELS), dim3(256), lds_bytes, st, HL, table, pts, n, radius, eps,
-                       gin, O.lde);
-    hipLaunchKernelGGL(hash_encode7_kernel, dim3(nb, HG_L - HG_LDS_LEVELS), dim3(256), 0, st, HL, table, pts, n, radius, eps, gin,
-                       O.lde, HG_LDS_LEVELS);
+    hipLaunchKernelGGL(hash_encode7_kernel, dim3(nb, HG_L), dim3(256), 0, st, hashgrid_levels(), params + hash_param_off().table, pts,
+                       n, radius, eps, gin, O.lde, 0);
     hipLaunchKernelGGL(hash_geo_mlp_fwd_kernel, dim3(nb), dim3(256), 0, st, hp, pts, n, radius, eps, gin, O.lde, sdf, feat, grad);
     return ok();
 }

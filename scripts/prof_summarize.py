@@ -1,5 +1,5 @@
 """Condense rocprofv3 CSV output (kernel_stats / counter_collection) into small per-kernel summaries."""
-import csv, glob, json, os, sys, collections
+import csv, glob, json, os, re, sys, collections
 
 out_dir = sys.argv[1]
 summary = {}
@@ -16,7 +16,7 @@ for d in sorted(glob.glob(os.path.join(out_dir, "prof_pmc*"))):
             name = r.get("Kernel_Name", "")
             if "dh" not in name:
                 continue
-            short = name.split("(")[0].replace("dh::", "")
+            short = re.sub(r"<.*", "", name.split("(")[0].replace("dh::", "").replace("void ", ""))     # template instances -> kernel name
             a = agg[short][r["Counter_Name"]]
             a[0] += float(r["Counter_Value"]); a[1] += 1
     summary[os.path.basename(d)] = {k: {c: {"mean_per_dispatch": v[0] / v[1], "dispatches": v[1]} for c, v in cs.items()}
