@@ -288,7 +288,7 @@ int dh_march_count(const float* rays_o, const float* rays_d, const float* near, 
                    const uint8_t* occupancy, int res, float radius, float step, float half_step, int max_samples, int64_t B,
                    int32_t* cnt, void* stream) {
     if (B < 0 || res <= 0 || !(radius > 0.f) || !(step > 0.f) || max_samples <= 0) return DH_ERR_BAD_ARG;
-    if (max_samples > 128) return DH_ERR_UNSUPPORTED;
+    if (max_samples > 1024) return DH_ERR_UNSUPPORTED;
     if (B == 0) return DH_OK;
     if (!rays_o || !rays_d || !near || !far || !occupancy || !cnt) return DH_ERR_BAD_ARG;
     return launch_march_count(rays_o, rays_d, near, far, u, occupancy, res, radius, step, half_step, max_samples, B, cnt,
@@ -299,7 +299,7 @@ int dh_march_emit(const float* rays_o, const float* rays_d, const float* near, c
                   const uint8_t* occupancy, int res, float radius, float step, float half_step, int max_samples, int64_t B,
                   const int64_t* off, float* t_start, float* pts, float* dirs_pts, int32_t* ray_idx, void* stream) {
     if (B < 0 || res <= 0 || !(radius > 0.f) || !(step > 0.f) || max_samples <= 0) return DH_ERR_BAD_ARG;
-    if (max_samples > 128) return DH_ERR_UNSUPPORTED;
+    if (max_samples > 1024) return DH_ERR_UNSUPPORTED;
     if (B == 0) return DH_OK;
     if (!rays_o || !rays_d || !near || !far || !occupancy || !off || !t_start || !pts || !dirs_pts || !ray_idx) return DH_ERR_BAD_ARG;
     return launch_march_emit(rays_o, rays_d, near, far, u, occupancy, res, radius, step, half_step, max_samples, B, off, t_start,

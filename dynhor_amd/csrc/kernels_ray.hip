@@ -283,6 +283,10 @@ __device__ __forceinline__ RenderElem render_elem(bool valid, int64_t gp, float 
 }
 
 // outputs: weights [B,n], color [B,3], wsum [B], wmax [B], cdf [B,n] (prev_cdf), inside [B,n], eik [B,2] (num, den)
+// One wave per ray, two samples per lane, 128 samples per trip.  The NeuS sampler has n <= 128 (one trip).  Packed rays
+// (occupancy-grid marching: the ray owns the segment [seg_off, seg_off + seg_cnt) of the packed arrays, z holds the interval starts
+// and every interval is sample_dist long) may be longer: further trips carry the transmittance reached so far.
+constexpr int RENDER_MAX_CHUNKS = 8;           // packed segments up to 1024 samples
 __global__ __launch_bounds__(256) void render_fwd_kernel(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
                                                          const float* __restrict__ z, const float* __restrict__ sdf,
                                                          const float* __restrict__ normals, const float* __restrict__ colors,
@@ -299,29 +303,32 @@ __global__ __launch_bounds__(256) void render_fwd_kernel(const float* __restrict
     const float inv_s = inv_s_p[0];
     float o[3], d[3];
     DH_UNROLL for (int c = 0; c < 3; ++c) { o[c] = rays_o[ray * 3 + c]; d[c] = rays_d[ray * 3 + c]; }
-    // packed rays (occupancy-grid marching): the ray's samples are the segment [seg_off, seg_off + seg_cnt) of the packed
-    // arrays, z holds the interval starts and every interval is sample_dist long
     const bool packed = seg_off != nullptr;
     const int64_t rb = packed ? seg_off[ray] : ray * n;
-    if (packed) n = seg_cnt[ray];
-    const int e0 = 2 * lane, e1 = e0 + 1;
-    const float z0 = e0 < n ? z[rb + e0] : 0.f, z1 = e1 < n ? z[rb + e1] : 0.f;
-    const float z2 = __shfl_down(z0, 1);
-    float in0, in1;
-    const RenderElem A = render_elem(e0 < n, rb + e0, z0, z1, packed || e0 == n - 1, sample_dist, o, d, sdf, normals, colors, inv_s, car, in0);
-    const RenderElem Bq = render_elem(e1 < n, rb + e1, z1, z2, packed || e1 == n - 1, sample_dist, o, d, sdf, normals, colors, inv_s, car, in1);
-    const float tA = 1.f - A.alpha + 1e-7f, tB = 1.f - Bq.alpha + 1e-7f;
-    const float excl = wave_excl_prod(((e0 < n) ? tA : 1.f) * ((e1 < n) ? tB : 1.f), lane);
-    const float w0 = A.alpha * excl, w1 = Bq.alpha * excl * tA;
-    const float ws = wave_sum(w0 + w1);
-    const float wm = wave_max(fmaxf(w0, w1));
-    float col[3], nm[3];
-    DH_UNROLL for (int c = 0; c < 3; ++c) col[c] = wave_sum(w0 * A.c[c] + w1 * Bq.c[c]);
-    DH_UNROLL for (int c = 0; c < 3; ++c) nm[c] = wave_sum(w0 * A.n[c] + w1 * Bq.n[c]);
-    const float g0 = (A.nn - 1.f) * (A.nn - 1.f) * A.relax, g1 = (Bq.nn - 1.f) * (Bq.nn - 1.f) * Bq.relax;
-    const float en = wave_sum(g0 + g1), ed = wave_sum(A.relax + Bq.relax);
-    if (e0 < n) { weights[rb + e0] = w0; cdf_out[rb + e0] = A.prev; inside_out[rb + e0] = in0; }
-    if (e1 < n) { weights[rb + e1] = w1; cdf_out[rb + e1] = Bq.prev; inside_out[rb + e1] = in1; }
+    if (packed) n = min(seg_cnt[ray], 128 * RENDER_MAX_CHUNKS);
+    float T_in = 1.f, ws = 0.f, wm = 0.f, en = 0.f, ed = 0.f;
+    float col[3] = {0.f, 0.f, 0.f}, nm[3] = {0.f, 0.f, 0.f};
+    for (int c0 = 0; c0 == 0 || c0 < n; c0 += 128) {
+        const int e0 = c0 + 2 * lane, e1 = e0 + 1;
+        const float z0 = e0 < n ? z[rb + e0] : 0.f, z1 = e1 < n ? z[rb + e1] : 0.f;
+        float z2 = __shfl_down(z0, 1);
+        if (lane == 63) z2 = (e1 + 1 < n) ? z[rb + e1 + 1] : 0.f;       // first sample of the next trip (never used by a last sample)
+        float in0, in1;
+        const RenderElem A = render_elem(e0 < n, rb + e0, z0, z1, packed || e0 == n - 1, sample_dist, o, d, sdf, normals, colors, inv_s, car, in0);
+        const RenderElem Bq = render_elem(e1 < n, rb + e1, z1, z2, packed || e1 == n - 1, sample_dist, o, d, sdf, normals, colors, inv_s, car, in1);
+        const float tA = (e0 < n) ? 1.f - A.alpha + 1e-7f : 1.f, tB = (e1 < n) ? 1.f - Bq.alpha + 1e-7f : 1.f;
+        const float excl = T_in * wave_excl_prod(tA * tB, lane);
+        const float w0 = A.alpha * excl, w1 = Bq.alpha * excl * tA;
+        ws += wave_sum(w0 + w1);
+        wm = fmaxf(wm, wave_max(fmaxf(w0, w1)));
+        DH_UNROLL for (int c = 0; c < 3; ++c) col[c] += wave_sum(w0 * A.c[c] + w1 * Bq.c[c]);
+        DH_UNROLL for (int c = 0; c < 3; ++c) nm[c] += wave_sum(w0 * A.n[c] + w1 * Bq.n[c]);
+        const float g0 = (A.nn - 1.f) * (A.nn - 1.f) * A.relax, g1 = (Bq.nn - 1.f) * (Bq.nn - 1.f) * Bq.relax;
+        en += wave_sum(g0 + g1); ed += wave_sum(A.relax + Bq.relax);
+        if (e0 < n) { weights[rb + e0] = w0; cdf_out[rb + e0] = A.prev; inside_out[rb + e0] = in0; }
+        if (e1 < n) { weights[rb + e1] = w1; cdf_out[rb + e1] = Bq.prev; inside_out[rb + e1] = in1; }
+        T_in = __shfl(excl * tA * tB, 63);                               // transmittance after this trip's last sample
+    }
     if (lane == 0) {
         DH_UNROLL for (int c = 0; c < 3; ++c) color_out[ray * 3 + c] = col[c] + (bg_rgb ? bg_rgb[c] * (1.f - ws) : 0.f);
         wsum_out[ray] = ws;
@@ -336,6 +343,10 @@ __global__ __launch_bounds__(256) void render_fwd_kernel(const float* __restrict
 // inputs: d_color [B,3], d_wsum [B], d_weights [B,n] (nullable), d_gradients [P,3] (nullable),
 //         eik_coef[0] = d_gradient_error / (sum relax + 1e-5)   (device scalar)
 // outputs: d_sdf [P], d_normals [P,3], d_colors [P,3] (wrt post-sigmoid colour), d_inv_s [B] (per-ray partial)
+// A sample's adjoint needs the transmittance before it and the sum q = wbar * w over the samples behind it.  With more than one
+// 128-sample trip (packed rays only) a first sweep records each trip's entry transmittance and q total, the second sweep runs the
+// per-trip scans with those carries.
+struct RenderPair { RenderElem A, Bq; float tA, tB, wb0, wb1; bool v0, v1; };
 __global__ __launch_bounds__(256) void render_bwd_kernel(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
                                                          const float* __restrict__ z, const float* __restrict__ sdf,
                                                          const float* __restrict__ normals, const float* __restrict__ colors,
@@ -348,12 +359,13 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(const float* __restrict
                                                          float* __restrict__ d_normals, float* __restrict__ d_colors,
                                                          float* __restrict__ d_inv_s, float* __restrict__ d_rays_d,
                                                          const int64_t* __restrict__ seg_off, const int32_t* __restrict__ seg_cnt) {
+    __shared__ float s_tin[4][RENDER_MAX_CHUNKS], s_q[4][RENDER_MAX_CHUNKS];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int64_t ray = (int64_t)blockIdx.x * 4 + wave;
     if (ray >= B) return;
     const bool packed = seg_off != nullptr;
     const int64_t rb = packed ? seg_off[ray] : ray * n;
-    if (packed) n = seg_cnt[ray];
+    if (packed) n = min(seg_cnt[ray], 128 * RENDER_MAX_CHUNKS);
     const float inv_s = inv_s_p[0];
     const float ec = eik_coef[0];
     float o[3], d[3], dC[3];
@@ -362,24 +374,34 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(const float* __restrict
     if (d_nmap) { DH_UNROLL for (int c = 0; c < 3; ++c) dN[c] = d_nmap[ray * 3 + c]; }
     float dws = d_wsum ? d_wsum[ray] : 0.f;
     if (bg_rgb) dws -= dC[0] * bg_rgb[0] + dC[1] * bg_rgb[1] + dC[2] * bg_rgb[2];
-    const int e0 = 2 * lane, e1 = e0 + 1;
-    const bool v0 = e0 < n, v1 = e1 < n;
-    const float z0 = v0 ? z[rb + e0] : 0.f, z1 = v1 ? z[rb + e1] : 0.f;
-    const float z2 = __shfl_down(z0, 1);
-    float in0, in1;
-    const RenderElem A = render_elem(v0, rb + e0, z0, z1, packed || e0 == n - 1, sample_dist, o, d, sdf, normals, colors, inv_s, car, in0);
-    const RenderElem Bq = render_elem(v1, rb + e1, z1, z2, packed || e1 == n - 1, sample_dist, o, d, sdf, normals, colors, inv_s, car, in1);
-    const float tA = v0 ? 1.f - A.alpha + 1e-7f : 1.f, tB = v1 ? 1.f - Bq.alpha + 1e-7f : 1.f;
-    const float excl = wave_excl_prod(tA * tB, lane);
-    const float T0 = excl, T1 = excl * tA;
-    const float w0 = A.alpha * T0, w1 = Bq.alpha * T1;
-    float wb0 = dws + dC[0] * A.c[0] + dC[1] * A.c[1] + dC[2] * A.c[2] + dN[0] * A.n[0] + dN[1] * A.n[1] + dN[2] * A.n[2];
-    float wb1 = dws + dC[0] * Bq.c[0] + dC[1] * Bq.c[1] + dC[2] * Bq.c[2] + dN[0] * Bq.n[0] + dN[1] * Bq.n[1] + dN[2] * Bq.n[2];
-    if (d_weights) { if (v0) wb0 += d_weights[rb + e0]; if (v1) wb1 += d_weights[rb + e1]; }
-    const float q0 = v0 ? wb0 * w0 : 0.f, q1 = v1 ? wb1 * w1 : 0.f;
-    const float suf = wave_excl_suffix_sum(q0 + q1, lane);
-    const float ab0 = wb0 * T0 - (suf + q1) / tA;
-    const float ab1 = wb1 * T1 - suf / tB;
+    auto load_pair = [&](int c0) {
+        RenderPair P;
+        const int e0 = c0 + 2 * lane, e1 = e0 + 1;
+        P.v0 = e0 < n; P.v1 = e1 < n;
+        const float z0 = P.v0 ? z[rb + e0] : 0.f, z1 = P.v1 ? z[rb + e1] : 0.f;
+        float z2 = __shfl_down(z0, 1);
+        if (lane == 63) z2 = (e1 + 1 < n) ? z[rb + e1 + 1] : 0.f;
+        float in0, in1;
+        P.A = render_elem(P.v0, rb + e0, z0, z1, packed || e0 == n - 1, sample_dist, o, d, sdf, normals, colors, inv_s, car, in0);
+        P.Bq = render_elem(P.v1, rb + e1, z1, z2, packed || e1 == n - 1, sample_dist, o, d, sdf, normals, colors, inv_s, car, in1);
+        P.tA = P.v0 ? 1.f - P.A.alpha + 1e-7f : 1.f; P.tB = P.v1 ? 1.f - P.Bq.alpha + 1e-7f : 1.f;
+        P.wb0 = dws + dC[0] * P.A.c[0] + dC[1] * P.A.c[1] + dC[2] * P.A.c[2] + dN[0] * P.A.n[0] + dN[1] * P.A.n[1] + dN[2] * P.A.n[2];
+        P.wb1 = dws + dC[0] * P.Bq.c[0] + dC[1] * P.Bq.c[1] + dC[2] * P.Bq.c[2] + dN[0] * P.Bq.n[0] + dN[1] * P.Bq.n[1] + dN[2] * P.Bq.n[2];
+        if (d_weights) { if (P.v0) P.wb0 += d_weights[rb + e0]; if (P.v1) P.wb1 += d_weights[rb + e1]; }
+        return P;
+    };
+    const int nchunks = n > 128 ? (n + 127) / 128 : 1;
+    if (nchunks > 1) {                                     // sweep 1: per-trip entry transmittance and q total
+        float T_in = 1.f;
+        for (int ch = 0; ch < nchunks; ++ch) {
+            const RenderPair P = load_pair(ch * 128);
+            const float excl = T_in * wave_excl_prod(P.tA * P.tB, lane);
+            const float q = (P.v0 ? P.wb0 * P.A.alpha * excl : 0.f) + (P.v1 ? P.wb1 * P.Bq.alpha * excl * P.tA : 0.f);
+            const float qs = wave_sum(q);
+            if (lane == 0) { s_tin[wave][ch] = T_in; s_q[wave][ch] = qs; }
+            T_in = __shfl(excl * P.tA * P.tB, 63);
+        }
+    }
     float dinv = 0.f;
     float ddir[3] = {0.f, 0.f, 0.f};          // d loss / d rays_d through true_cos = d . n (pose refinement only)
     auto elem_bwd = [&](const RenderElem& E, bool valid, float ab, float w, int64_t gp) {
@@ -401,8 +423,23 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(const float* __restrict
             d_colors[gp * 3 + c] = w * dC[c];
         }
     };
-    elem_bwd(A, v0, ab0, w0, rb + e0);
-    elem_bwd(Bq, v1, ab1, w1, rb + e1);
+    for (int ch = 0; ch < nchunks; ++ch) {
+        const RenderPair P = load_pair(ch * 128);
+        float T_in = 1.f, q_after = 0.f;
+        if (nchunks > 1) {
+            T_in = s_tin[wave][ch];
+            for (int k = ch + 1; k < nchunks; ++k) q_after += s_q[wave][k];
+        }
+        const float excl = T_in * wave_excl_prod(P.tA * P.tB, lane);
+        const float T0 = excl, T1 = excl * P.tA;
+        const float w0 = P.A.alpha * T0, w1 = P.Bq.alpha * T1;
+        const float q0 = P.v0 ? P.wb0 * w0 : 0.f, q1 = P.v1 ? P.wb1 * w1 : 0.f;
+        const float suf = wave_excl_suffix_sum(q0 + q1, lane) + q_after;
+        const float ab0 = P.wb0 * T0 - (suf + q1) / P.tA;
+        const float ab1 = P.wb1 * T1 - suf / P.tB;
+        elem_bwd(P.A, P.v0, ab0, w0, rb + ch * 128 + 2 * lane);
+        elem_bwd(P.Bq, P.v1, ab1, w1, rb + ch * 128 + 2 * lane + 1);
+    }
     dinv = wave_sum(dinv);
     if (lane == 0) d_inv_s[ray] = dinv;
     if (d_rays_d) {

@@ -142,8 +142,8 @@ class HashNeuSRenderer(NeuSRenderer):
             raise TypeError("HashNeuSRenderer needs HashSDFNetwork + SHRenderingNetwork")
         if sampler not in ("hierarchical", "occgrid"):
             raise ValueError("sampler must be 'hierarchical' or 'occgrid'")
-        if not 0 < max_samples <= 128:
-            raise ValueError("the packed render scan handles at most 128 samples per ray")
+        if not 0 < max_samples <= 1024:
+            raise ValueError("the packed render scan handles at most 1024 samples per ray")
         super().__init__(nerf, sdf_network, deviation_network, color_network, *args, **kwargs)
         self.radius = sdf_network.radius
         self.fd_eps = sdf_network.fd_eps

@@ -195,7 +195,7 @@ int dh_corr_loss(const float* rays_o, const float* rays_d, const float* z, const
  * branch; it calls nerfacc's OccupancyGrid / ray_marching).  Specification: oracle/occgrid_oracle.py (parity unpinned).
  *   occupancy: res^3 bytes (non-zero = occupied) over the cube [-radius, radius]^3, cell (ix,iy,iz) at (ix*res + iy)*res + iz.
  *   Step k of ray r is [t_k, t_k + step], t_k = near + (k + u[r]) step (u: one stratified offset per ray, null = 0.5); it is a
- *   sample iff t_k + step <= far and the cell of its mid-point is occupied; at most max_samples (<= 128) per ray, front to back.
+ *   sample iff t_k + step <= far and the cell of its mid-point is occupied; at most max_samples (<= 1024) per ray, front to back.
  *   half_step = (float)(0.5 * step) as the caller rounds it (kept separate so host and device agree bit for bit).
  * dh_march_count -> cnt [B]; the caller forms off = exclusive prefix sum (int64) and N = sum cnt, then dh_march_emit writes
  * t_start [N], the mid-point positions pts [N,3], the ray direction per sample dirs_pts [N,3] (pass it as `dirs` with
@@ -207,7 +207,8 @@ int dh_march_emit(const float* rays_o, const float* rays_d, const float* near, c
                   const uint8_t* occupancy, int res, float radius, float step, float half_step, int max_samples, int64_t B,
                   const int64_t* off, float* t_start, float* pts, float* dirs_pts, int32_t* ray_idx, void* stream);
 /* dh_render_scan_fwd / _bwd over packed rays: ray r owns samples [seg_off[r], seg_off[r] + seg_cnt[r]) of the packed arrays
- * (seg_cnt <= 128), every interval is `step` long and t_start holds the interval starts; per-sample outputs are packed too. */
+ * (seg_cnt <= 1024: the wave takes 128 samples per trip and carries the transmittance), every interval is `step` long and
+ * t_start holds the interval starts; per-sample outputs are packed too. */
 int dh_render_scan_fwd_packed(const float* rays_o, const float* rays_d, const float* t_start, const float* sdf, const float* normals,
                               const float* colors, const float* inv_s, float cos_anneal_ratio, float step,
                               const float* background_rgb, int64_t B, const int64_t* seg_off, const int32_t* seg_cnt,

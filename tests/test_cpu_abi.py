@@ -91,3 +91,36 @@ def test_example_configs_parse_into_upstream_constructor_kwargs():
         assert sum(p.numel() for m in (sdf, col, var) for p in m.parameters()) == 802491
         r = conf["model"]["neus_renderer"]
         assert r["n_samples"] + r["n_importance"] <= 128 and r["n_outside"] == 0
+
+
+def test_stage_kernel_table_names_kernels_that_exist_in_the_library():
+    """dynhor_amd/_lib.py:STAGE_KERNELS feeds bench.py's roofline block and scripts/make_traffic_json.py: every name in it must
+    be a kernel of the built code object (the mangled names are registered as strings in the host part of the .so)."""
+    from dynhor_amd import _lib
+    blob = open(_lib.LIB_PATH, "rb").read()
+    names = {k for table in _lib.STAGE_KERNELS.values() for k in table.values()} | set(_lib.HASH_STAGE_KERNELS.values())
+    for k in sorted(names):
+        assert k.encode() in blob, f"{k} is not a kernel of libdynhor_hip.so (stale STAGE_KERNELS entry)"
+    assert set(_lib.STAGE_KERNELS[0]) == set(_lib.STAGE_KERNELS[1]), "both arithmetic modes list the same stages"
+
+
+def test_traffic_tool_rejects_a_profile_that_lacks_a_shipping_kernel(tmp_path):
+    import json
+    import subprocess
+    import sys
+    from dynhor_amd import _lib
+    entry = {"FETCH_SIZE": {"mean_per_dispatch": 1000.0, "dispatches": 3}, "WRITE_SIZE": {"mean_per_dispatch": 500.0, "dispatches": 3}}
+    full = {"prof_pmc2": {k: entry for k in _lib.STAGE_KERNELS[0].values()}, "prof_pmc3": {k: entry for k in _lib.STAGE_KERNELS[0].values()}}
+    src, dst = tmp_path / "pmc.json", tmp_path / "traffic.json"
+    json.dump(full, open(src, "w"))
+    tool = os.path.join(ROOT, "scripts", "make_traffic_json.py")
+    p = subprocess.run([sys.executable, tool, str(src), str(dst)], capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
+    out = json.load(open(dst))
+    assert out["weight_grads_gemm"]["kernel"] == "dw_bf16x3_kernel"
+    assert out["weight_grads_gemm"]["hbm_bytes_per_launch"] == 1000.0 * 1024 * 2 + 500.0 * 1024      # FETCH_SIZE x2 on gfx950
+    stale = {"prof_pmc2": dict(full["prof_pmc2"]), "prof_pmc3": dict(full["prof_pmc3"])}
+    del stale["prof_pmc2"]["sdf_tangent_s_kernel"]                                                  # e.g. a renamed kernel
+    json.dump(stale, open(src, "w"))
+    p = subprocess.run([sys.executable, tool, str(src), str(dst)], capture_output=True, text=True)
+    assert p.returncode != 0 and "sdf_tangent_s_kernel" in (p.stderr + p.stdout)

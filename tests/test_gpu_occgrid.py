@@ -81,17 +81,23 @@ def test_marcher_selects_exactly_the_oracle_samples(B, res, step, cap):
     assert torch.equal(m2.t_start, ref2["t_start"])
 
 
-def test_packed_render_scan_and_adjoint_match_oracle():
+@pytest.mark.parametrize("step,cap", [(0.01, 128), (0.0025, 1024)])
+def test_packed_render_scan_and_adjoint_match_oracle(step, cap):
+    """cap 1024: segments longer than one 128-sample trip of the wave (transmittance / suffix carries across trips)."""
     from dynhor_amd import _lib
     from dynhor_amd.renderer import _p
     L = _lib.lib()
-    B, step = 300, 0.01
+    B = 300
     o, d, near, far, u = _rays(B, seed=7)
     grid = _blob_grid(64, seed=3)
-    m = _hip_march(o, d, near, far, u, grid, step, 128)
+    m = _hip_march(o, d, near, far, u, grid, step, cap)
     N = m.N
+    if cap > 128:
+        assert (m.cnt > 128).any() and (m.cnt > 256).any(), "the case must contain multi-trip rays"
+        ref_m = G.march(o, d, near, far, u, grid, float(torch.tensor(step, dtype=torch.float32)), max_samples=cap)
+        assert torch.equal(m.t_start, ref_m["t_start"]) and torch.equal(m.cnt.long(), ref_m["cnt"])
     g = torch.Generator(device="cpu").manual_seed(1)
-    sdf = (torch.randn(N, generator=g) * 0.05).cuda()
+    sdf = (torch.randn(N, generator=g) * (0.05 if cap == 128 else 0.2) + (0.0 if cap == 128 else 0.15)).cuda()   # long rays: keep T alive
     normals = torch.nn.functional.normalize(torch.randn(N, 3, generator=g), dim=-1).cuda() * (0.7 + 0.6 * torch.rand(N, 1, generator=g).cuda())
     colors = torch.rand(N, 3, generator=g).cuda()
     inv_s = torch.tensor([35.0], device="cuda")
