@@ -1,19 +1,12 @@
 #!/bin/bash
-# one gpurun call: full GPU test suite + every bench line + rocprofv3 profiles (round 2 measurement session)
+# one gpurun call: occgrid tests, same-box A/B of two build variants, smoke(), sampler quality report (round 2)
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-( timeout 2400 python -m pytest tests -m gpu -q > gpurun_out/gputest.log 2>&1; echo "pytest rc $?" >> gpurun_out/gputest.log )
-tail -6 gpurun_out/gputest.log
-timeout 900 python bench.py --steps 100 --warmup 20 > gpurun_out/r02_bench_n1.json 2> gpurun_out/bench_neus.err; tail -c 600 gpurun_out/r02_bench_n1.json
-timeout 600 python bench.py --steps 60 --warmup 10 --arithmetic fp32_mfma --no-cpu-baseline > gpurun_out/r02_bench_n1_fp32_mfma.json 2>/dev/null; tail -c 300 gpurun_out/r02_bench_n1_fp32_mfma.json
-timeout 600 python bench.py --steps 60 --warmup 10 --loss full --no-cpu-baseline > gpurun_out/r02_bench_n1_full_loss.json 2> gpurun_out/bench_full.err; tail -c 300 gpurun_out/r02_bench_n1_full_loss.json; tail -2 gpurun_out/bench_full.err
-timeout 600 python bench.py --family hash --steps 100 --warmup 20 > gpurun_out/r02_bench_n1_hash.json 2>/dev/null; tail -c 700 gpurun_out/r02_bench_n1_hash.json
-timeout 600 python bench.py --family hash --hash-sampler occgrid --steps 100 --warmup 40 > gpurun_out/r02_bench_n1_hash_occgrid.json 2> gpurun_out/bench_occ.err; tail -c 900 gpurun_out/r02_bench_n1_hash_occgrid.json; tail -2 gpurun_out/bench_occ.err
-timeout 300 python scripts/host_overhead.py > gpurun_out/host_overhead_neus.log 2>&1; tail -1 gpurun_out/host_overhead_neus.log
-timeout 300 python scripts/host_overhead.py hash > gpurun_out/host_overhead_hash.log 2>&1; tail -1 gpurun_out/host_overhead_hash.log
-bash scripts/prof.sh > gpurun_out/prof_sh.log 2>&1; tail -3 gpurun_out/prof_sh.log
-mkdir -p gpurun_out/neus_prof; cp gpurun_out/prof_summary.json gpurun_out/neus_prof/ 2>/dev/null; cp gpurun_out/keep/*kernel_stats.csv gpurun_out/neus_prof/ 2>/dev/null
-bash scripts/prof.sh --family hash > gpurun_out/prof_sh_hash.log 2>&1
-mkdir -p gpurun_out/hash_prof; cp gpurun_out/prof_summary.json gpurun_out/hash_prof/ 2>/dev/null; cp gpurun_out/keep/*kernel_stats.csv gpurun_out/hash_prof/ 2>/dev/null
-ls gpurun_out/neus_prof gpurun_out/hash_prof
+python -m pytest tests/test_gpu_occgrid.py -q 2>&1 | tail -8
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
+for lib in "" "--lib dynhor_amd/libdynhor_hip_nt.so" "--lib dynhor_amd/libdynhor_hip_epi2.so" "" "--lib dynhor_amd/libdynhor_hip_nt.so" "--lib dynhor_amd/libdynhor_hip_epi2.so"; do
+  echo "== ab_stage $lib"; timeout 300 python scripts/ab_stage.py $lib --reps 24 2>&1 | grep -E "sdf_tangent|sdf_backward|weight_grads_gemm" | sed 's/mean_ms.*//'
+done
+timeout 900 python scripts/psnr_parity.py --family hash --mode hip_occgrid_vs_hierarchical --seeds 11,22,33,44 --out gpurun_out/psnr_r02_hash_occgrid_vs_hierarchical.json > gpurun_out/psnr_occ.log 2>&1
+tail -1 gpurun_out/psnr_occ.log | cut -c1-1300

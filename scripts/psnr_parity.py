@@ -14,6 +14,7 @@ handful of low-resolution frames cannot resolve 0.1 dB.  This script therefore
       hip_noise_floor     the HIP path vs itself with initial weights perturbed by 1e-7 relative (chaos only: no kernel differs)
       oracle_noise_floor  the oracle vs itself, same perturbation
       hip_scatter         (hash family) shipping table scatter vs the unmerged per-evaluation scatter
+      hip_occgrid_vs_hierarchical  (hash family) occupancy-grid marching vs the NeuS sampler: a quality report, not parity
   * --lockstep K: the HIP arm takes the oracle's weights and Adam state every K iterations; per segment it reports the loss
     difference on the first step (pure kernel error), its growth over the segment (chaos) and the SIGNED mean difference
     (a kernel bias would show as a non-zero mean).
@@ -32,12 +33,12 @@ LOSS_W = (0.1, 0.1, 0.05)          # eikonal, mask, mono-normal (the bench confi
 LOG = sys.stdout                    # bench.py --psnr points this at stderr
 
 
-def make_runner(family, weight_seed, batch, frames, res, dev, tag):
+def make_runner(family, weight_seed, batch, frames, res, dev, tag, hash_sampler="hierarchical"):
     conf = {"seq_name": "psnr_parity", "exp_name": tag,
             "data_info": {"synthetic": {"n_frames": frames, "H": res, "W": res, "seed": 4321}},
             "train": {"batch_size": batch, "normal_weight": LOSS_W[2], "report_freq": 10 ** 9, "save_freq": 10 ** 9,
                       "val_freq": 0, "end_iter": END_ITER, "warm_up_end": WARM_UP, "anneal_end": ANNEAL_END, "seed": weight_seed},
-            "model": {"family": family}}
+            "model": {"family": family, "hash_renderer": {"sampler": hash_sampler}}}
     return Runner(conf=conf, device=dev, exp_root="/tmp/dynhor_psnr")
 
 
@@ -150,13 +151,15 @@ def oracle_render_psnr(arm, ds, it, frames, level):
 
 ARM_NAMES = {"hip_vs_oracle": ("hip", "oracle_gpu_eager"), "oracle_noise_floor": ("oracle_perturbed_1e-7", "oracle"),
              "hip_vs_hip_f32": ("hip_split_bf16", "hip_fp32_mfma"), "hip_noise_floor": ("hip_perturbed_1e-7", "hip"),
-             "hip_scatter": ("hip_scatter_merged", "hip_scatter_per_evaluation")}
+             "hip_scatter": ("hip_scatter_merged", "hip_scatter_per_evaluation"),
+             "hip_occgrid_vs_hierarchical": ("hip_occgrid_sampler", "hip_hierarchical_sampler")}
 
 
 def run_seed(args, seed, dev):
     wseed = 1000 + seed
     tag = f"{args.family}_{args.mode}_{seed}"
-    r_a = make_runner(args.family, wseed, args.batch, args.frames, args.res, dev, tag + "_a")
+    r_a = make_runner(args.family, wseed, args.batch, args.frames, args.res, dev, tag + "_a",
+                      hash_sampler="occgrid" if args.mode == "hip_occgrid_vs_hierarchical" else "hierarchical")
     ds = r_a.dataset
     scratch = None
     mode = args.mode
@@ -178,6 +181,8 @@ def run_seed(args, seed, dev):
             A, B = HipArm(r_a), HipArm(r_b); A.perturb(1e-7, 5)
         elif mode == "hip_scatter":
             A, B = HipArm(r_a, scatter_mode=0), HipArm(r_b, scatter_mode=2)
+        elif mode == "hip_occgrid_vs_hierarchical":      # a QUALITY report of the two samplers (hash family), not a parity claim
+            A, B = HipArm(r_a), HipArm(r_b)
         else:
             raise ValueError(mode)
     fp = schedules.FramePermutation(ds.n_images, 4321 + seed)
