@@ -180,6 +180,28 @@ __device__ __forceinline__ void dw_body_lds(const DwJob& J, int64_t t0, int64_t 
 constexpr int DWP_TILE = 3 * 1024;                 // bytes of one tile's three pieces (64 lanes x 16 B each)
 constexpr int DWP_BUF = 16 * DWP_TILE;             // one k-pair: A tiles 0..7, B tiles 8..15
 
+// One half of a k-pair for the NB == 8 shape, program order written out (the chain kernels' scheme, tile16.h gemm_rows_s):
+// 24 MFMAs product-major over the 2 x 2 accumulators of this half, each issued at raised wave priority, and after every
+// second one a third of the split of one pair of the tile this wave publishes for the NEXT k-pair; the three piece writes
+// follow the last MFMA.
+template <int I, int JB>
+__device__ __forceinline__ void dw_half_steps(f32x16 (&acc)[2][4], const Bf3 (&a)[2], const Bf3 (&b)[2], U3 (&pc)[MT],
+                                              const RawA& raw, SplitState& st) {
+    if constexpr (I < 24) {
+        constexpr int pa[6] = {2, 1, 0, 1, 0, 0}, pb[6] = {0, 1, 2, 0, 1, 0};
+        constexpr int p = I / 4, ii = (I % 4) / 2, j = I % 2;
+        __builtin_amdgcn_s_setprio(1);
+        acc[ii][JB + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ii].p[pa[p]], b[j].p[pb[p]], acc[ii][JB + j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (I % 2 == 1) {
+            split_step<I / 2>(pc, raw, st);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        dw_half_steps<I + 1, JB>(acc, a, b, pc, raw, st);
+    }
+}
+
 template <int NB>
 __device__ __forceinline__ void dw_body_pieces(const DwJob& J, int64_t t0, int64_t t1, float* __restrict__ out, int wave,
                                                int lane, char* lds) {
@@ -255,6 +277,29 @@ __device__ __forceinline__ void dw_body_pieces(const DwJob& J, int64_t t0, int64
         // would end the scheduling region: after the last pair this writes wrapped-around data into the idle buffer, which
         // the next job's prologue overwrites behind a barrier.
         auto step = [&](int par, Raw& nxt) {
+            if constexpr (NB == 8) {
+                Bf3 a[2], b[2];
+                U3 pc[MT];
+                RawA raw;
+                SplitState st;
+                char* wbase = lds + (par ^ 1) * DWP_BUF + lane * 16;
+                DH_UNROLL for (int ii = 0; ii < 2; ++ii) a[ii] = piece(par, (wave >> 1) * 2 + ii);
+                DH_UNROLL for (int j = 0; j < 2; ++j) b[j] = piece(par, 8 + (wave & 1) * 4 + j);
+                raw.lo[0] = nxt.a0; raw.hi[0] = nxt.a1;
+                __builtin_amdgcn_sched_barrier(0);
+                dw_half_steps<0, 0>(acc, a, b, pc, raw, st);
+                DH_UNROLL for (int p = 0; p < 3; ++p) *reinterpret_cast<u32x4*>(wbase + wave * DWP_TILE + p * 1024) = pc[0].p[p];
+                DH_UNROLL for (int j = 0; j < 2; ++j) b[j] = piece(par, 8 + (wave & 1) * 4 + 2 + j);
+                raw.lo[0] = nxt.b0; raw.hi[0] = nxt.b1;
+                __builtin_amdgcn_sched_barrier(0);
+                dw_half_steps<0, 2>(acc, a, b, pc, raw, st);
+                DH_UNROLL for (int p = 0; p < 3; ++p) *reinterpret_cast<u32x4*>(wbase + (8 + wave) * DWP_TILE + p * 1024) = pc[0].p[p];
+                __builtin_amdgcn_sched_barrier(0);
+                load(nxt);
+                __builtin_amdgcn_sched_barrier(0);
+                __syncthreads();
+                return;
+            }
             Bf3 a[NA], b[H];
             DH_UNROLL for (int ii = 0; ii < NA; ++ii) a[ii] = piece(par, (NB == 8) ? ((wave >> 1) * 2 + ii) : wave);
             DH_UNROLL for (int j = 0; j < H; ++j) b[j] = piece(par, 8 + ((NB == 8) ? ((wave & 1) * 4 + j) : j));

@@ -17,6 +17,7 @@ def main():
     ap.add_argument("--lib", type=str, default=None)
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--out", type=str, default=None)
+    ap.add_argument("--blocks", type=int, default=512, help="workgroups that wrote stamps (a -DDH_GRID_DIV=2 build: 256)")
     ap.add_argument("--stamps", action="store_true", help="the library is a -DDH_STAMPS build: dump per-phase cycle stamps")
     args = ap.parse_args()
     from dynhor_amd import _lib
@@ -89,7 +90,7 @@ def main():
             fn.restype = ctypes.c_int
             fn.argtypes = [ctypes.c_void_p, ctypes.c_longlong]
             assert fn(ctypes.cast(buf, ctypes.c_void_p), n) == 0
-            a = np.frombuffer(buf, dtype=np.uint64).reshape(512, 4, 2, 10, 8).astype(np.float64)
+            a = np.frombuffer(buf, dtype=np.uint64).reshape(512, 4, 2, 10, 8).astype(np.float64)[:args.blocks]
             d = {}
             nl = 8
             # per layer (1..6: steady layers), phase durations in cycles, averaged over blocks / waves / the two recorded iterations
@@ -108,6 +109,12 @@ def main():
             # (start of layer 3) mod (mean layer time) over all workgroups
             ph = np.mod(st3 - st3.min(), d["layer_total"]["mean"]) / d["layer_total"]["mean"]
             d["layer3_phase_hist10"] = np.histogram(ph, bins=10, range=(0, 1))[0].tolist()
+            if args.blocks == 512:
+                # the two workgroups of a CU are b and b + 256 (scripts/micro/hwid_probe.hip): their phase offset, as a
+                # fraction of the layer time, at the start of layer 3 of both recorded iterations
+                for itn in (0, 1):
+                    dl = np.mod(a[256:, 0, itn, 3, 0] - a[:256, 0, itn, 3, 0], d["layer_total"]["mean"]) / d["layer_total"]["mean"]
+                    d["cu_pair_phase_hist10_it%d" % itn] = np.histogram(dl, bins=10, range=(0, 1))[0].tolist()
             out[key] = d
             print(key, json.dumps(d, indent=1), flush=True)
         res["stamps"] = out
