@@ -170,10 +170,10 @@ __global__ __launch_bounds__(256, 2) void sdf_grad_kernel(SdfPtrs P, const float
 }
 
 // K2b on the split-bf16 core (same saved tiles and outputs as sdf_grad_kernel; the small ge / saux image stays fp32)
-__global__ __launch_bounds__(256, 1) void sdf_grad16_kernel(Sdf16Ptrs P, const float* __restrict__ pts, int64_t npts,
+__global__ __launch_bounds__(256, 2) void sdf_grad_s_kernel(Sdf16Ptrs P, const float* __restrict__ pts, int64_t npts,
                                                            const float* __restrict__ act, float* __restrict__ asave,
                                                            float* __restrict__ normals, int save, float* __restrict__ gesave) {
-    __shared__ __attribute__((aligned(16))) __bf16 smain[3 * P_MAIN];
+    __shared__ __attribute__((aligned(16))) float smain[TM * LDX];
     __shared__ __attribute__((aligned(16))) float saux[TM * LDA];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int64_t ntiles = (npts + TM - 1) / TM;
@@ -187,29 +187,32 @@ __global__ __launch_bounds__(256, 1) void sdf_grad16_kernel(Sdf16Ptrs P, const f
             acc_load_native(acc, act + ((int64_t)7 * ntiles + tile) * TILE_F, wave, lane);
             acc_map(acc, [&](int, int t, int, float h) { float s, em; softplus_deriv_from_h(h, s, em); return (t ? w1 : w0) * s; });
             if (save) acc_store_native(acc, asave + ((int64_t)7 * ntiles + tile) * TILE_F, wave, lane);
-            acc_to_lds16(acc, smain, wave, lane);
+            acc_to_lds(acc, smain, wave, lane);
             __syncthreads();
         }
         for (int l = 7; l >= 1; --l) {
             acc_zero(acc);
-            TileRegs hreg;                                                              // act[l-1] in flight under the GEMM
-            tile_prefetch(hreg, act + ((int64_t)(l - 1) * ntiles + tile) * TILE_F, wave, lane);
-            gemm16_rows(acc, smain, P_MAIN, LDB, 16, P.rev16[l], wave, lane);        // u_l = a_l W_l
-            if (l == 4) gemm16_auxout(ge, smain, 16, P.revaux16[4], wave, lane);      // skip path -> ge
+            gemm_rows_s(acc, smain, LDX, 16, P.rev16[l], wave, lane);                 // u_l = a_l W_l
+            if (l == 4) gemm_auxout_s(ge, smain, 16, P.revaux16[4], wave, lane);      // skip path -> ge
             // a_{l-1} = u_l * sigma'(z_{l-1})   (sigma' from act[l-1] == input of layer l)
-            DH_UNROLL for (int m = 0; m < MT; ++m)
+            const f32x4* hp = reinterpret_cast<const f32x4*>(act + ((int64_t)(l - 1) * ntiles + tile) * TILE_F) + (size_t)wave * MT * 8 * 64 + lane;
+            DH_UNROLL for (int m = 0; m < MT; ++m) {
                 DH_UNROLL for (int t = 0; t < 2; ++t)
-                    DH_UNROLL for (int r4 = 0; r4 < 4; ++r4)
+                    DH_UNROLL for (int r4 = 0; r4 < 4; ++r4) {
+                        const f32x4 h = hp[((m * 2 + t) * 4 + r4) * 64];
                         DH_UNROLL for (int rr = 0; rr < 4; ++rr) {
-                            float s, em; softplus_deriv_from_h(hreg.v[m][t][r4][rr], s, em);
+                            float s, em; softplus_deriv_from_h(h[rr], s, em);
                             acc[m][t][4 * r4 + rr] *= s;
                         }
+                    }
+                __builtin_amdgcn_sched_barrier(0);     // bound live registers: one m-slab (8 float4) in flight
+            }
             if (save) acc_store_native(acc, asave + ((int64_t)(l - 1) * ntiles + tile) * TILE_F, wave, lane);
             __syncthreads();
-            acc_to_lds16(acc, smain, wave, lane);
+            acc_to_lds(acc, smain, wave, lane);
             __syncthreads();
         }
-        gemm16_auxout(ge, smain, 16, P.revaux16[0], wave, lane);                     // ge += a_0 W_0
+        gemm_auxout_s(ge, smain, 16, P.revaux16[0], wave, lane);                     // ge += a_0 W_0
         // ge -> LDS aux image
         DH_UNROLL for (int tt = 0; tt < AUX_NTW; ++tt) {
             const int col = aux_col(wave, tt, lane);
@@ -240,6 +243,7 @@ __global__ __launch_bounds__(256, 1) void sdf_grad16_kernel(Sdf16Ptrs P, const f
         __syncthreads();
     }
 }
+
 
 
 // ------------------------------------------------------------------------------------------------
@@ -452,7 +456,7 @@ int launch_sdf_grad(const float* packed, const float* pts, int64_t npts, const f
                     int save, float* gesave, int grid, hipStream_t stream) {
     // the reverse chain ships in its piece-plane form (one workgroup per CU): 1.68 vs 1.75 ms for split-on-fetch
     if (arith_fp32()) hipLaunchKernelGGL(sdf_grad_kernel, dim3(grid_for(npts, grid)), dim3(256), 0, stream, make_sdf_ptrs(packed), pts, npts, act, asave, normals, save, gesave);
-    else hipLaunchKernelGGL(sdf_grad16_kernel, dim3(grid_for(npts, 256)), dim3(256), 0, stream, make_sdf16_ptrs(packed), pts, npts, act, asave, normals, save, gesave);
+    else hipLaunchKernelGGL(sdf_grad_s_kernel, dim3(grid_for(npts, grid)), dim3(256), 0, stream, make_sdf16_ptrs(packed), pts, npts, act, asave, normals, save, gesave);
     return ok();
 }
 int launch_color_fwd(const float* packed, const float* pts, const float* dirs, int n_per_ray, const float* normals,

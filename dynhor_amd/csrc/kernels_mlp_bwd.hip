@@ -33,9 +33,6 @@ __global__ __launch_bounds__(256, 2) void color_bwd_kernel(ColPtrs C, const floa
     __shared__ __attribute__((aligned(16))) float saux[TM * LDA];     // scratch: craw [128][4]
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int64_t ntiles = (npts + TM - 1) / TM;
-    const int col0 = acc_col(wave, 0, lane), col1 = acc_col(wave, 1, lane);
-    float w4[3][2];
-    DH_UNROLL for (int j = 0; j < 3; ++j) { w4[j][0] = C.w4[j * 256 + col0]; w4[j][1] = C.w4[j * 256 + col1]; }
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         float* tp = tpart + tile * N_TILE_PART * 256;
         if (tid < TM) {
@@ -57,6 +54,9 @@ __global__ __launch_bounds__(256, 2) void color_bwd_kernel(ColPtrs C, const floa
         // lin4: dW4 partials, zbar_3 = (craw W4) * [h4 > 0]
         acc_load_native(acc, cact + ((int64_t)3 * ntiles + tile) * TILE_F, wave, lane);
         {
+            const int col0 = acc_col(wave, 0, lane), col1 = acc_col(wave, 1, lane);
+            float w4[3][2];              // re-read per tile (L1/L2 hits): six registers not held across the GEMMs
+            DH_UNROLL for (int j = 0; j < 3; ++j) { w4[j][0] = C.w4[j * 256 + col0]; w4[j][1] = C.w4[j * 256 + col1]; }
             float dw[3][2] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
             DH_UNROLL for (int m = 0; m < MT; ++m)
                 DH_UNROLL for (int r = 0; r < 16; ++r) {
@@ -124,20 +124,17 @@ __global__ __launch_bounds__(256, 2) void color_bwd_kernel(ColPtrs C, const floa
 // adjoints of the sample point (columns 0..2 -> d_pts, WRITTEN) and of the ray direction through the view embedding
 // (columns 3..29 -> d_dirs_pts [npts,3], written; summed per ray by the caller).
 template <bool RAYS>
-__global__ __launch_bounds__(256, 1) void color_bwd16_kernel(Col16Ptrs C, const float* __restrict__ colors,
+__global__ __launch_bounds__(256, 2) void color_bwd_s_kernel(Col16Ptrs C, const float* __restrict__ colors,
                                                             const float* __restrict__ d_colors, int64_t npts,
                                                             const float* __restrict__ cact, float* __restrict__ czbar,
                                                             float* __restrict__ featbar, float* __restrict__ d_normals,
                                                             float* __restrict__ tpart, const float* __restrict__ dirs,
                                                             int n_per_ray, float* __restrict__ d_pts,
                                                             float* __restrict__ d_dirs_pts) {
-    __shared__ __attribute__((aligned(16))) __bf16 smain[3 * P_MAIN];
+    __shared__ __attribute__((aligned(16))) float smain[TM * LDX];
     __shared__ __attribute__((aligned(16))) float saux[TM * LDA];     // scratch: craw [128][4]
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int64_t ntiles = (npts + TM - 1) / TM;
-    const int col0 = acc_col(wave, 0, lane), col1 = acc_col(wave, 1, lane);
-    float w4[3][2];
-    DH_UNROLL for (int j = 0; j < 3; ++j) { w4[j][0] = C.w4[j * 256 + col0]; w4[j][1] = C.w4[j * 256 + col1]; }
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         float* tp = tpart + tile * N_TILE_PART * 256;
         if (tid < TM) {
@@ -159,6 +156,9 @@ __global__ __launch_bounds__(256, 1) void color_bwd16_kernel(Col16Ptrs C, const 
         // lin4: dW4 partials, zbar_3 = (craw W4) * [h4 > 0]
         acc_load_native(acc, cact + ((int64_t)3 * ntiles + tile) * TILE_F, wave, lane);
         {
+            const int col0 = acc_col(wave, 0, lane), col1 = acc_col(wave, 1, lane);
+            float w4[3][2];              // re-read per tile (L1/L2 hits): six registers not held across the GEMMs
+            DH_UNROLL for (int j = 0; j < 3; ++j) { w4[j][0] = C.w4[j * 256 + col0]; w4[j][1] = C.w4[j * 256 + col1]; }
             float dw[3][2] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
             DH_UNROLL for (int m = 0; m < MT; ++m)
                 DH_UNROLL for (int r = 0; r < 16; ++r) {
@@ -179,31 +179,34 @@ __global__ __launch_bounds__(256, 1) void color_bwd16_kernel(Col16Ptrs C, const 
         }
         acc_store_native(acc, czbar + ((int64_t)3 * ntiles + tile) * TILE_F, wave, lane);
         tile_colsum(acc, tp + (TP_COL_B0 + 3) * 256, wave, lane);
-        acc_to_lds16(acc, smain, wave, lane);
+        acc_to_lds(acc, smain, wave, lane);
         __syncthreads();
         for (int l = 3; l >= 1; --l) {
             acc_zero(acc);
-            TileRegs hreg;                                                                   // cact[l-1] in flight under the GEMM
-            tile_prefetch(hreg, cact + ((int64_t)(l - 1) * ntiles + tile) * TILE_F, wave, lane);
-            gemm16_rows(acc, smain, P_MAIN, LDB, 16, C.rev16[l], wave, lane);             // hbar_l = zbar_l W_l
-            DH_UNROLL for (int m = 0; m < MT; ++m)
+            gemm_rows_s(acc, smain, LDX, 16, C.rev16[l], wave, lane);                      // hbar_l = zbar_l W_l
+            const f32x4* hp = reinterpret_cast<const f32x4*>(cact + ((int64_t)(l - 1) * ntiles + tile) * TILE_F) + (size_t)wave * MT * 8 * 64 + lane;
+            DH_UNROLL for (int m = 0; m < MT; ++m) {
                 DH_UNROLL for (int t = 0; t < 2; ++t)
-                    DH_UNROLL for (int r4 = 0; r4 < 4; ++r4)
+                    DH_UNROLL for (int r4 = 0; r4 < 4; ++r4) {
+                        const f32x4 h = hp[((m * 2 + t) * 4 + r4) * 64];
                         DH_UNROLL for (int rr = 0; rr < 4; ++rr)
-                            if (!(hreg.v[m][t][r4][rr] > 0.f)) acc[m][t][4 * r4 + rr] = 0.f;
+                            if (!(h[rr] > 0.f)) acc[m][t][4 * r4 + rr] = 0.f;
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+            }
             acc_store_native(acc, czbar + ((int64_t)(l - 1) * ntiles + tile) * TILE_F, wave, lane);
             tile_colsum(acc, tp + (TP_COL_B0 + l - 1) * 256, wave, lane);
             __syncthreads();
-            acc_to_lds16(acc, smain, wave, lane);
+            acc_to_lds(acc, smain, wave, lane);
             __syncthreads();
         }
         // lin0: featbar = zbar_0 W0[:,33:] ; extras adjoint = zbar_0 W0[:,:33] (only the normal columns 30..32 matter)
         acc_zero(acc);
-        gemm16_rows(acc, smain, P_MAIN, LDB, 16, C.rev16[0], wave, lane);
+        gemm_rows_s(acc, smain, LDX, 16, C.rev16[0], wave, lane);
         acc_store_native(acc, featbar + tile * TILE_F, wave, lane);
         f32x16 a2[AUX_NTW];
         aux_zero(a2);
-        gemm16_auxout(a2, smain, 16, C.revaux16, wave, lane);
+        gemm_auxout_s(a2, smain, 16, C.revaux16, wave, lane);
         DH_UNROLL for (int tt = 0; tt < AUX_NTW; ++tt) {
             const int col = aux_col(wave, tt, lane);
             if (col >= 30 && col < 33) {
@@ -245,6 +248,7 @@ __global__ __launch_bounds__(256, 1) void color_bwd16_kernel(Col16Ptrs C, const 
         __syncthreads();
     }
 }
+
 
 // ------------------------------------------------------------------------------------------------
 // K7a: tangent chain (forward direction) -> t_l, r_l ; colsum(t_8) feeds Wbar_8[0,:]
@@ -609,19 +613,17 @@ static inline int grid_for(int64_t npts, int grid) {
 
 int launch_color_bwd(const float* packed, const float* colors, const float* d_colors, int64_t npts, const float* cact,
                      float* czbar, float* featbar, float* d_normals, float* tpart, int grid, hipStream_t st) {
-    // the colour backward ships in its piece-plane form (one workgroup per CU): 0.97 vs 1.04 ms for split-on-fetch
     if (arith_fp32()) hipLaunchKernelGGL(color_bwd_kernel, dim3(grid_for(npts, grid)), dim3(256), 0, st, make_col_ptrs(packed), colors,
                                          d_colors, npts, cact, czbar, featbar, d_normals, tpart);
-    else hipLaunchKernelGGL(color_bwd16_kernel<false>, dim3(grid_for(npts, 256)), dim3(256), 0, st, make_col16_ptrs(packed), colors,
+    else hipLaunchKernelGGL(color_bwd_s_kernel<false>, dim3(grid_for(npts, grid)), dim3(256), 0, st, make_col16_ptrs(packed), colors,
                             d_colors, npts, cact, czbar, featbar, d_normals, tpart, nullptr, 1, nullptr, nullptr);
     return ok();
 }
 int launch_color_bwd_rays(const float* packed, const float* colors, const float* d_colors, const float* dirs, int n_per_ray,
                           int64_t npts, const float* cact, float* czbar, float* featbar, float* d_normals, float* tpart,
                           float* d_pts, float* d_dirs_pts, int grid, hipStream_t st) {
-    (void)grid;
     if (arith_fp32()) return -2;          // pose refinement ships in the split-bf16 arithmetic only
-    hipLaunchKernelGGL(color_bwd16_kernel<true>, dim3(grid_for(npts, 256)), dim3(256), 0, st, make_col16_ptrs(packed), colors,
+    hipLaunchKernelGGL(color_bwd_s_kernel<true>, dim3(grid_for(npts, grid)), dim3(256), 0, st, make_col16_ptrs(packed), colors,
                        d_colors, npts, cact, czbar, featbar, d_normals, tpart, dirs, n_per_ray, d_pts, d_dirs_pts);
     return ok();
 }

@@ -5,13 +5,10 @@
 // k-step instead of 8 x 64 for v_mfma_f32_32x32x2_f32.  The accumulator layout of the two instructions is the same
 // 32 x 32 fp32 tile, so epilogues, native saved tiles and the dW kernels are unchanged.
 //
-// Two ways of feeding the A operand (both in this file; the faster one per kernel ships):
-//   * split-on-fetch (gemm_rows_s / gemm_auxout_s): the LDS image stays tile.h's fp32 image (two workgroups per CU) and
-//     each wave splits its A fragments as it reads them;
-//   * piece planes (gemm16_rows / gemm16_auxout / acc_to_lds16): three bf16 planes [TM x 256], row stride LDB = 264
-//     (528 B: 16 lanes x 16 B cover all 64 banks); the split happens once, in the epilogue that writes the image
-//     (one workgroup per CU).  Ships for the reverse chain and the colour backward, whose epilogue inputs are
-//     prefetched into registers under the GEMM (tile_prefetch).
+// The A operand is fed split-on-fetch (gemm_rows_s / gemm_auxout_s): the LDS image stays tile.h's fp32 image (two
+// workgroups per CU) and each wave splits its A fragments as it reads them.  (A piece-plane form -- three bf16 planes in LDS,
+// split once in the epilogue, one workgroup per CU -- shipped for two kernels until the GEMM core below got its pinned order
+// and MFMA priority; it is in git history, its measurements in DESIGN.md section 3.)
 // Packed weights (pack.hip): bf16x8 index ((kc*NT + nt)*3 + piece)*64 + lane holds
 //   M[k = 16 kc + 8 (lane>>5) + s][n = 32 nt + (lane&31)], s = 0..7.
 #pragma once
@@ -22,8 +19,6 @@ namespace dh {
 typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 bf16x8;
 struct Bf3 { bf16x8 p[3]; };
 
-constexpr int LDB = 264;             // bf16 row stride of a main piece plane
-constexpr int P_MAIN = TM * LDB;     // elements per main piece plane
 constexpr int AUX_KC = 3;            // k-chunks of the aux image: 48 / 16
 
 __device__ __forceinline__ void split_f32(float v, __bf16& h1, __bf16& h2, __bf16& h3) {
@@ -75,89 +70,6 @@ __device__ __forceinline__ f32x16 mfma6(const Bf3& a, const Bf3& b, f32x16 c) {
     c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p[0], b.p[1], c, 0, 0, 0);
     c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p[0], b.p[0], c, 0, 0, 0);
     return c;
-}
-
-// acc[m][t] += X[TM x 16 nkc] * M (NT = 8).  xs: piece-0 plane in LDS (planes pstride elements apart, row stride ld).
-// Operands of k-chunk kc+1 are issued before the MFMAs of kc (order pinned with sched_barrier, as in tile.h gemm_rows).
-__device__ __forceinline__ void gemm16_rows(f32x16 (&acc)[MT][2], const __bf16* xs, const int pstride, const int ld,
-                                            const int nkc, const bf16x8* __restrict__ wp, const int wave, const int lane) {
-    const __bf16* xrow = xs + (lane & 31) * ld + 8 * (lane >> 5);
-    const bf16x8* wl = wp + (2 * wave) * 3 * 64 + lane;
-    Bf3 a0[MT], b0[2], a1[MT], b1[2];
-    auto fetch = [&](Bf3 (&a)[MT], Bf3 (&b)[2], int kc) {
-        DH_UNROLL for (int t = 0; t < 2; ++t)
-            DH_UNROLL for (int p = 0; p < 3; ++p) b[t].p[p] = wl[((kc * 8 + t) * 3 + p) * 64];
-        DH_UNROLL for (int m = 0; m < MT; ++m)
-            DH_UNROLL for (int p = 0; p < 3; ++p)
-                a[m].p[p] = *reinterpret_cast<const bf16x8*>(xrow + p * pstride + m * 32 * ld + kc * 16);
-    };
-    auto mul = [&](const Bf3 (&a)[MT], const Bf3 (&b)[2]) {
-        DH_UNROLL for (int m = 0; m < MT; ++m)
-            DH_UNROLL for (int t = 0; t < 2; ++t) acc[m][t] = mfma6(a[m], b[t], acc[m][t]);
-    };
-    fetch(a0, b0, 0);
-    _Pragma("unroll 1") for (int kc = 0; kc < nkc; kc += 2) {
-        fetch(a1, b1, (kc + 1 < nkc) ? kc + 1 : kc);
-        __builtin_amdgcn_sched_barrier(0);
-        mul(a0, b0);
-        __builtin_amdgcn_sched_barrier(0);
-        if (kc + 1 < nkc) {
-            fetch(a0, b0, (kc + 2 < nkc) ? kc + 2 : kc + 1);
-            __builtin_amdgcn_sched_barrier(0);
-            mul(a1, b1);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    }
-}
-
-// accumulators -> the three piece planes of the LDS main image
-__device__ __forceinline__ void acc_to_lds16(const f32x16 (&acc)[MT][2], __bf16* xs, int wave, int lane) {
-    DH_UNROLL for (int m = 0; m < MT; ++m)
-        DH_UNROLL for (int t = 0; t < 2; ++t) {
-            __bf16* base = xs + (m * 32 + 4 * (lane >> 5)) * LDB + acc_col(wave, t, lane);
-            DH_UNROLL for (int r = 0; r < 16; ++r) {
-                __bf16 h1, h2, h3;
-                split_f32(acc[m][t][r], h1, h2, h3);
-                __bf16* e = base + ((r & 3) + 8 * (r >> 2)) * LDB;
-                e[0] = h1; e[P_MAIN] = h2; e[2 * P_MAIN] = h3;
-            }
-        }
-}
-
-// acc2[.] += X[rows of this wave's m-tile][16 nkc] * M (NT = 2): the 64-wide "aux" output (tile.h gemm_auxout)
-__device__ __forceinline__ void gemm16_auxout(f32x16 (&acc2)[AUX_NTW], const __bf16* xs, const int nkc,
-                                              const bf16x8* __restrict__ wp, const int wave, const int lane) {
-    const __bf16* xrow = xs + (32 * aux_mtile(wave) + (lane & 31)) * LDB + 8 * (lane >> 5);
-    const bf16x8* wl = wp + aux_ntile(wave, 0) * 3 * 64 + lane;
-    auto fetch = [&](Bf3& a, Bf3 (&b)[AUX_NTW], int kc) {
-        DH_UNROLL for (int t = 0; t < AUX_NTW; ++t)
-            DH_UNROLL for (int p = 0; p < 3; ++p) b[t].p[p] = wl[((kc * 2 + t) * 3 + p) * 64];
-        DH_UNROLL for (int p = 0; p < 3; ++p) a.p[p] = *reinterpret_cast<const bf16x8*>(xrow + p * P_MAIN + kc * 16);
-    };
-    Bf3 a0, a1, b0[AUX_NTW], b1[AUX_NTW];
-    fetch(a0, b0, 0);
-    _Pragma("unroll 1") for (int kc = 0; kc < nkc; kc += 2) {
-        fetch(a1, b1, (kc + 1 < nkc) ? kc + 1 : kc);
-        __builtin_amdgcn_sched_barrier(0);
-        DH_UNROLL for (int t = 0; t < AUX_NTW; ++t) acc2[t] = mfma6(a0, b0[t], acc2[t]);
-        __builtin_amdgcn_sched_barrier(0);
-        if (kc + 1 < nkc) {
-            fetch(a0, b0, (kc + 2 < nkc) ? kc + 2 : kc + 1);
-            __builtin_amdgcn_sched_barrier(0);
-            DH_UNROLL for (int t = 0; t < AUX_NTW; ++t) acc2[t] = mfma6(a1, b1[t], acc2[t]);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    }
-}
-
-// A saved native tile as registers (same element order as the accumulators): issued BEFORE a GEMM so its HBM latency sits
-// under the MFMAs -- with one workgroup per CU nothing else would hide it.
-struct TileRegs { f32x4 v[MT][2][4]; };
-__device__ __forceinline__ void tile_prefetch(TileRegs& t, const float* __restrict__ tile, int wave, int lane) {
-    const f32x4* p = reinterpret_cast<const f32x4*>(tile) + (size_t)wave * MT * 8 * 64 + lane;
-    DH_UNROLL for (int m = 0; m < MT; ++m)
-        DH_UNROLL for (int tt = 0; tt < 2; ++tt)
-            DH_UNROLL for (int r4 = 0; r4 < 4; ++r4) t.v[m][tt][r4] = p[((m * 2 + tt) * 4 + r4) * 64];
 }
 
 // ---------------------------------------------------------------- split-on-fetch form (the shipping chain kernels)
