@@ -124,7 +124,7 @@ __global__ __launch_bounds__(256, 2) void sdf_grad_kernel(SdfPtrs P, const float
             DH_UNROLL for (int m = 0; m < MT; ++m) {
                 DH_UNROLL for (int t = 0; t < 2; ++t)
                     DH_UNROLL for (int r4 = 0; r4 < 4; ++r4) {
-                        const f32x4 h = hp[((m * 2 + t) * 4 + r4) * 64];
+                        const f32x4 h = DH_TILE_LD(hp + ((m * 2 + t) * 4 + r4) * 64);
                         DH_UNROLL for (int rr = 0; rr < 4; ++rr) {
                             float s, em; softplus_deriv_from_h(h[rr], s, em);
                             acc[m][t][4 * r4 + rr] *= s;
@@ -199,7 +199,7 @@ __global__ __launch_bounds__(256, 2) void sdf_grad_s_kernel(Sdf16Ptrs P, const f
             DH_UNROLL for (int m = 0; m < MT; ++m) {
                 DH_UNROLL for (int t = 0; t < 2; ++t)
                     DH_UNROLL for (int r4 = 0; r4 < 4; ++r4) {
-                        const f32x4 h = hp[((m * 2 + t) * 4 + r4) * 64];
+                        const f32x4 h = DH_TILE_LD(hp + ((m * 2 + t) * 4 + r4) * 64);
                         DH_UNROLL for (int rr = 0; rr < 4; ++rr) {
                             float s, em; softplus_deriv_from_h(h[rr], s, em);
                             acc[m][t][4 * r4 + rr] *= s;

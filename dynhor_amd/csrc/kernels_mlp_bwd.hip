@@ -88,7 +88,7 @@ __global__ __launch_bounds__(256, 2) void color_bwd_kernel(ColPtrs C, const floa
             DH_UNROLL for (int m = 0; m < MT; ++m) {
                 DH_UNROLL for (int t = 0; t < 2; ++t)
                     DH_UNROLL for (int r4 = 0; r4 < 4; ++r4) {
-                        const f32x4 h = hp[((m * 2 + t) * 4 + r4) * 64];
+                        const f32x4 h = DH_TILE_LD(hp + ((m * 2 + t) * 4 + r4) * 64);
                         DH_UNROLL for (int rr = 0; rr < 4; ++rr)
                             if (!(h[rr] > 0.f)) acc[m][t][4 * r4 + rr] = 0.f;
                     }
@@ -188,7 +188,7 @@ __global__ __launch_bounds__(256, 2) void color_bwd_s_kernel(Col16Ptrs C, const 
             DH_UNROLL for (int m = 0; m < MT; ++m) {
                 DH_UNROLL for (int t = 0; t < 2; ++t)
                     DH_UNROLL for (int r4 = 0; r4 < 4; ++r4) {
-                        const f32x4 h = hp[((m * 2 + t) * 4 + r4) * 64];
+                        const f32x4 h = DH_TILE_LD(hp + ((m * 2 + t) * 4 + r4) * 64);
                         DH_UNROLL for (int rr = 0; rr < 4; ++rr)
                             if (!(h[rr] > 0.f)) acc[m][t][4 * r4 + rr] = 0.f;
                     }
@@ -458,7 +458,7 @@ __global__ __launch_bounds__(256, 2) void sdf_tangent_s_kernel(Sdf16Ptrs P, cons
                 DH_UNROLL for (int t = 0; t < 2; ++t)
                     DH_UNROLL for (int r4 = 0; r4 < 4; ++r4) {
                         const int idx = ((m * 2 + t) * 4 + r4) * 64;
-                        const f32x4 h = hp[idx], a = ap[idx];
+                        const f32x4 h = DH_TILE_LD(hp + idx), a = DH_TILE_LD(ap + idx);
                         f32x4 rv;
                         DH_UNROLL for (int rr = 0; rr < 4; ++rr) {
                             float s, em; softplus_deriv_from_h(h[rr], s, em);
@@ -466,7 +466,7 @@ __global__ __launch_bounds__(256, 2) void sdf_tangent_s_kernel(Sdf16Ptrs P, cons
                             rv[rr] = ab * a[rr] * (SOFTPLUS_BETA * em);
                             acc[m][t][4 * r4 + rr] = s * ab;
                         }
-                        rp[idx] = rv;
+                        DH_TILE_ST(rp + idx, rv);
                     }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -541,7 +541,7 @@ __global__ __launch_bounds__(256, 2) void sdf_bwd_s_kernel(Sdf16Ptrs P, const fl
                 DH_UNROLL for (int t = 0; t < 2; ++t)
                     DH_UNROLL for (int r4 = 0; r4 < 4; ++r4) {
                         const int idx = ((m * 2 + t) * 4 + r4) * 64;
-                        const f32x4 h = hp[idx], rv = rp[idx];
+                        const f32x4 h = DH_TILE_LD(hp + idx), rv = DH_TILE_LD(rp + idx);
                         DH_UNROLL for (int rr = 0; rr < 4; ++rr) {
                             float s, em; softplus_deriv_from_h(h[rr], s, em);
                             if (l == 7) {
