@@ -1,12 +1,10 @@
 #!/bin/bash
-# one gpurun call: occgrid tests, same-box A/B of two build variants, smoke(), sampler quality report (round 2)
+# one gpurun call (round 2, after the GEMM-core change): profiles of the headline bench + the driver-visible bench lines
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-python -m pytest tests/test_gpu_occgrid.py -q 2>&1 | tail -8
-python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
-for lib in "" "--lib dynhor_amd/libdynhor_hip_nt.so" "--lib dynhor_amd/libdynhor_hip_epi2.so" "" "--lib dynhor_amd/libdynhor_hip_nt.so" "--lib dynhor_amd/libdynhor_hip_epi2.so"; do
-  echo "== ab_stage $lib"; timeout 300 python scripts/ab_stage.py $lib --reps 24 2>&1 | grep -E "sdf_tangent|sdf_backward|weight_grads_gemm" | sed 's/mean_ms.*//'
-done
-timeout 900 python scripts/psnr_parity.py --family hash --mode hip_occgrid_vs_hierarchical --seeds 11,22,33,44 --out gpurun_out/psnr_r02_hash_occgrid_vs_hierarchical.json > gpurun_out/psnr_occ.log 2>&1
-tail -1 gpurun_out/psnr_occ.log | cut -c1-1300
+bash scripts/prof.sh > gpurun_out/prof.log 2>&1
+python bench.py --steps 100 --warmup 20 > gpurun_out/bench_n1.json 2> gpurun_out/bench_n1.err
+python bench.py --steps 100 --warmup 20 --arithmetic fp32_mfma --no-cpu-baseline > gpurun_out/bench_n1_fp32_mfma.json 2> gpurun_out/bench_n1_fp32.err
+python bench.py --steps 100 --warmup 20 --loss full --no-cpu-baseline > gpurun_out/bench_n1_full_loss.json 2> gpurun_out/bench_n1_full.err
+tail -c 300 gpurun_out/bench_n1.json; tail -5 gpurun_out/prof_summary.log
