@@ -363,16 +363,22 @@ __global__ __launch_bounds__(512, 2) void dw_lds_kernel(DwJobs jobs, int64_t nti
     }
 }
 
-// red[e] = sum_g slabs[g*gstride + e]
+// red[e] = sum_g slabs[g*gstride + e].  Eight independent partial sums (slab g goes to partial g % 8, combined pairwise in a fixed
+// order: deterministic) keep eight 16-B loads in flight per lane; the slabs are read once: non-temporal.
 __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slabs, int64_t gstride, int G, float* __restrict__ red) {
     const int64_t e = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
     if (e >= gstride) return;
-    f32x4 s = {0.f, 0.f, 0.f, 0.f};
-    for (int g = 0; g < G; ++g) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(slabs + (int64_t)g * gstride + e);
-        s[0] += v[0]; s[1] += v[1]; s[2] += v[2]; s[3] += v[3];
+    f32x4 s[8];
+    DH_UNROLL for (int k = 0; k < 8; ++k) s[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float* p = slabs + e;
+    int g = 0;
+    for (; g + 8 <= G; g += 8) {
+        f32x4 v[8];
+        DH_UNROLL for (int k = 0; k < 8; ++k) v[k] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p + (int64_t)(g + k) * gstride));
+        DH_UNROLL for (int k = 0; k < 8; ++k) s[k] += v[k];
     }
-    *reinterpret_cast<f32x4*>(red + e) = s;
+    for (; g < G; ++g) s[g & 7] += *reinterpret_cast<const f32x4*>(p + (int64_t)g * gstride);
+    *reinterpret_cast<f32x4*>(red + e) = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
 }
 
 // ---------------------------------------------------------------- per-tile partial sums -> [S][N_TILE_PART][256]
