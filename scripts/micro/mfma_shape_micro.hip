@@ -100,8 +100,9 @@ __device__ __forceinline__ void gemm16(v4f (&acc)[4][4], const float* xs, const 
     }
 }
 
-template <int SHAPE>
-__global__ __launch_bounds__(256, 2) void k(const bf16x8* __restrict__ wp, float* out, int layers, int tiles) {
+// STORE: 1 = the layer's output tile also goes to HBM (non-temporal, as the training forward saves it)
+template <int SHAPE, int STORE>
+__global__ __launch_bounds__(256, 2) void k(const bf16x8* __restrict__ wp, float* out, float* __restrict__ tiles_out, int layers, int tiles) {
     __shared__ __attribute__((aligned(16))) float X[TM * LDX];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     for (int i = tid; i < TM * LDX; i += 256) {
@@ -117,6 +118,7 @@ __global__ __launch_bounds__(256, 2) void k(const bf16x8* __restrict__ wp, float
                 f32x16 acc[MT][2];
                 acc_zero(acc);
                 gemm_rows_s(acc, X, LDX, 16, wlay, wave, lane);
+                if (STORE) acc_store_native(acc, tiles_out + ((size_t)(blockIdx.x * tiles + tl) * 8 + (l % 8)) * TILE_F, wave, lane);
                 __syncthreads();
                 DH_UNROLL for (int m = 0; m < MT; ++m)
                     DH_UNROLL for (int t = 0; t < 2; ++t)
@@ -144,14 +146,14 @@ __global__ __launch_bounds__(256, 2) void k(const bf16x8* __restrict__ wp, float
     out[blockIdx.x * 256 + tid] = sum;
 }
 
-template <int SHAPE>
-void run(const char* name, const bf16x8* wp, float* out, int grid) {
+template <int SHAPE, int STORE>
+void run(const char* name, const bf16x8* wp, float* out, float* tiles_out, int grid) {
     const int layers = 8, tiles = 16, reps = 40;          // ~60 ms per arm: long enough for the clock to settle
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
-    for (int i = 0; i < 5; ++i) hipLaunchKernelGGL((k<SHAPE>), dim3(grid), dim3(256), 0, 0, wp, out, layers, tiles);
+    for (int i = 0; i < 5; ++i) hipLaunchKernelGGL((k<SHAPE, STORE>), dim3(grid), dim3(256), 0, 0, wp, out, tiles_out, layers, tiles);
     hipDeviceSynchronize();
     hipEventRecord(a);
-    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((k<SHAPE>), dim3(grid), dim3(256), 0, 0, wp, out, layers, tiles);
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((k<SHAPE, STORE>), dim3(grid), dim3(256), 0, 0, wp, out, tiles_out, layers, tiles);
     hipEventRecord(b); hipEventSynchronize(b);
     float ms; hipEventElapsedTime(&ms, a, b); ms /= reps;
     const double flop = 2.0 * TM * 256 * 256 * layers * tiles * grid;
@@ -172,9 +174,12 @@ int main() {
     hipMemcpy(wp, h.data(), h.size() * 2, hipMemcpyHostToDevice);
     const int grid = 512;
     hipMalloc(&out, (size_t)grid * 256 * 4);
+    float* tiles_out;
+    hipMalloc(&tiles_out, (size_t)grid * 16 * 8 * TILE_F * 4);      // 4.3 GB: every (workgroup, tile, layer) its own 64 KB tile
     for (int round = 0; round < 3; ++round) {
-        run<32>("32x32x16 (tile16.h core)", wp, out, grid);
-        run<16>("16x16x32", wp, out, grid);
+        run<32, 0>("32x32x16 (tile16.h core)", wp, out, tiles_out, grid);
+        run<16, 0>("16x16x32", wp, out, tiles_out, grid);
+        run<32, 1>("32x32x16 + tile store to HBM", wp, out, tiles_out, grid);
     }
     return 0;
 }
