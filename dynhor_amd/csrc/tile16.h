@@ -28,9 +28,10 @@ __device__ __forceinline__ void split_f32(float v, __bf16& h1, __bf16& h2, __bf1
     h3 = (__bf16)(r1 - (float)h2);
 }
 
-// 8 fp32 (two f32x4) -> three bf16x8 pieces, written pair-wise so that every step is one packed instruction: per pair
-// 3 v_cvt_pk_bf16_f32 + 4 unpack (shift / and) + 2 v_pk_add_f32 = 4.5 vector ops per value (the element-wise form left
-// the pairing to the SLP vectoriser, which got 5.8 per value in the chain kernels' loops).  Same values as split_f32.
+// 8 fp32 (two f32x4) -> three bf16x8 pieces, written pair-wise: per pair 3 v_cvt_pk_bf16_f32 + 4 unpack (shift / and) + 2
+// subtractions of a float pair (one v_pk_add_f32 each, which the compiler turns back into two v_add_f32 where it sits in an
+// MFMA's shadow: packed fp32 ops do not issue beside the matrix pipe) = 4.5 - 5.5 vector ops per value; the element-wise form
+// left the pairing to the SLP vectoriser, which got 5.8 with a third of the conversions unpaired.  Same values as split_f32.
 typedef __attribute__((__vector_size__(2 * sizeof(__bf16)))) __bf16 bf16x2;
 typedef __attribute__((__vector_size__(2 * sizeof(float)))) float f32x2;
 typedef __attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned u32x4;
