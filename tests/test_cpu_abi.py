@@ -124,3 +124,31 @@ def test_traffic_tool_rejects_a_profile_that_lacks_a_shipping_kernel(tmp_path):
     json.dump(stale, open(src, "w"))
     p = subprocess.run([sys.executable, tool, str(src), str(dst)], capture_output=True, text=True)
     assert p.returncode != 0 and "sdf_tangent_s_kernel" in (p.stderr + p.stdout)
+
+
+def test_committed_profiles_name_the_shipping_kernels():
+    """profiles/pmc_traffic.json, the rocprofv3 kernel stats and the headline bench line must be OF the kernels that ship
+    (round 1 committed a traffic table of kernels that no longer existed)."""
+    import csv
+    import json
+    import re
+    from dynhor_amd import _lib
+    ship = _lib.STAGE_KERNELS[_lib.ARITH_SPLIT_BF16]
+    traffic = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+    for stage, e in traffic.items():
+        assert ship.get(stage) == e["kernel"], (stage, e["kernel"], ship.get(stage))
+    names = set()
+    for r in csv.DictReader(open(os.path.join(ROOT, "profiles", "r02_kernel_stats.csv"))):
+        names.add(re.sub(r"[<(].*", "", re.sub(r"^dh::", "", re.sub(r"^void ", "", r["Name"]))))
+    missing = sorted(set(ship.values()) - names)
+    assert not missing, f"profiles/r02_kernel_stats.csv lacks shipping kernels {missing}"
+    line = json.loads(open(os.path.join(ROOT, "profiles", "r02_bench_n1.json")).read().strip().split("\n")[-1])
+    assert line["roofline"]["kernel"] == ship[line["roofline"]["stage"]]
+    for stage, v in line["kernels"].items():
+        if "kernel" in v:
+            assert v["kernel"] == ship[stage], (stage, v["kernel"])
+    table = os.path.join(ROOT, "scripts", "kernel_table.py")
+    import subprocess
+    import sys
+    p = subprocess.run([sys.executable, table], capture_output=True, text=True)
+    assert p.returncode == 0 and "dw_bf16x3_kernel" in p.stdout, p.stderr
