@@ -116,20 +116,38 @@ def main():
     ap.add_argument("--force-dist", action="store_true", help="TEST ONLY: initialise the process group even for one rank")
     args = ap.parse_args()
 
+    from dynhor_amd import launch
+    if args.gpus > 1 and not launch.launched_by_torchrun():
+        # `python bench.py --gpus N`: nobody started the ranks for us, so start them -- as CHILD processes, before anything in
+        # this process touches the GPU (the parent makes no HIP call at all); rank 0's JSON line reaches our stdout unchanged
+        # and we leave with the ranks' exit code.  Under `python -m torch.distributed.run ... bench.py --gpus N` (the
+        # driver's form) WORLD_SIZE is set and this branch is not taken.
+        if not args.share_gpu and torch.cuda.device_count() < args.gpus:      # device_count() does not initialise the GPU
+            print(f"bench.py: --gpus {args.gpus} but only {torch.cuda.device_count()} GPU(s) are visible on this node",
+                  file=sys.stderr, flush=True)
+            sys.exit(2)
+        sys.exit(launch.spawn_ranks(os.path.abspath(__file__), sys.argv[1:], args.gpus))
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but the launcher set WORLD_SIZE={world}; pass the same N to both", file=sys.stderr,
+              flush=True)
+        sys.exit(2)
     if args.share_gpu:
         local_rank = 0
     use_dist = world > 1 or args.force_dist
     if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if not launch.launched_by_torchrun():          # --force-dist with one self-started rank: a private rendezvous
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(launch.free_port()), RANK="0", WORLD_SIZE="1",
+                              LOCAL_RANK="0")
         torch.cuda.set_device(local_rank)
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
         else:
             dist.init_process_group(args.backend)
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
     device = torch.device(f"cuda:{local_rank}")
     torch.cuda.set_device(device)
 
@@ -176,7 +194,7 @@ def main():
     if use_dist:
         # self-diagnosis for the first real multi-GPU run: what the process group reports, and the cost of the one collective
         # on this path in isolation (the flat gradient bucket; 20 back-to-back all-reduces, HIP events)
-        g = runner.store.grad_flat.clone()
+        g = runner.store.grad_bucket()           # the very buffer the training loop reduces (same registered address)
         for _ in range(3):
             dist.all_reduce(g)
         torch.cuda.synchronize()
@@ -195,7 +213,8 @@ def main():
         except Exception:
             pass
         comm = {"backend": dist.get_backend(), "nranks": dist.get_world_size(), "rccl_version": nccl_ver,
-                "bucket_bytes": g.numel() * 4, "allreduce_only_ms": round(float(t.item()), 4),
+                "bucket_bytes": g.numel() * 4, "bucket_persistent": runner.store.grad_flat.data_ptr() == g.data_ptr(),
+                "allreduce_only_ms": round(float(t.item()), 4),
                 "allreduce_frac_of_step": round(float(t.item()) / (dt / args.steps * 1e3), 4),
                 "collectives_per_step": 1}
     if args.check_sync and world > 1:

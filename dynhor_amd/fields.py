@@ -117,6 +117,7 @@ class ParamStore:
         self.packed = torch.empty(packed_floats, device=self.device, dtype=torch.float32)
         self._packed_version = None
         self.grad_flat = None
+        self._grad_bucket = None
         self.exp_avg = torch.zeros_like(self.flat)
         self.exp_avg_sq = torch.zeros_like(self.flat)
         self.step_count = 0
@@ -143,6 +144,15 @@ class ParamStore:
 
     def params(self):
         return [p for p, _, _ in self.slices]
+
+    def grad_bucket(self) -> torch.Tensor:
+        """The ONE persistent flat gradient buffer of the fused training step: the data-parallel all-reduce always sees the
+        same device address (RCCL registers a buffer once instead of once per iteration) and the hot loop allocates nothing
+        of the gradient's size.  The autograd path (render() + loss.backward()) keeps allocating a fresh vector per backward,
+        because autograd may keep views of it alive as the parameters' .grad."""
+        if self._grad_bucket is None:
+            self._grad_bucket = torch.empty(self.n, device=self.device, dtype=torch.float32)
+        return self._grad_bucket
 
     def bump(self):
         """Call after any write to ``flat`` that bypasses torch (the fused Adam kernel)."""

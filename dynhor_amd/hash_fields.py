@@ -271,7 +271,7 @@ class HashNeuSRenderer(NeuSRenderer):
                                                _p(s.inv_s), s.car, m.step, _p(s.bg), B, _p(m.off), _p(m.cnt), _p(d_color),
                                                _p(d_wsum), _NULLP, _NULLP, _p(d_nmap), _p(eik_coef), _p(d_sdf), _p(d_normals),
                                                _p(d_colors), _p(d_inv_s), _lib.stream()))
-        grad = torch.zeros(st.n, device=dev)
+        grad = st.grad_bucket().zero_()
         if N > 0:
             d_feat = torch.empty(N, 13, device=dev)
             T("hash_color_backward", L.dh_hash_color_backward, _p(st.packed), _p(s.feat), _p(s.normals), _p(m.dirs), _p(d_colors),

@@ -274,8 +274,9 @@ class NeuSRenderer:
         return s
 
     @torch.no_grad()
-    def _backward_core(self, s, d_color, d_wsum, d_weights, d_gradients, d_nmap, eik_coef, d_sdf_out=None):
-        """Adjoint of _forward_core: returns the flat parameter gradient (also kept as store.grad_flat)."""
+    def _backward_core(self, s, d_color, d_wsum, d_weights, d_gradients, d_nmap, eik_coef, d_sdf_out=None, persistent=False):
+        """Adjoint of _forward_core: returns the flat parameter gradient (also kept as store.grad_flat).  persistent: write it
+        into the store's one long-lived bucket (the fused training step: same address every iteration for the all-reduce)."""
         L = _lib.lib()
         st = self.store
         if s.infer_only:
@@ -305,7 +306,7 @@ class NeuSRenderer:
                                             _p(d_normals), _p(d_colors), _p(d_inv_s), _lib.stream()))
         if d_sdf_out is not None:
             d_sdf = (d_sdf + d_sdf_out.reshape(-1)).contiguous()
-        grad = torch.empty(st.n, device=dev)
+        grad = st.grad_bucket() if persistent else torch.empty(st.n, device=dev)
         self._net_backward(s, d_sdf, d_normals, d_colors, grad)
         # variance: inv_s = clip(exp(10 v), 1e-6, 1e6)
         raw = torch.exp(st.flat[st.var_off] * 10.0)
@@ -394,7 +395,7 @@ class NeuSRenderer:
                                       _p(d_weights), _lib.stream()))
             stats[0] += cstats[3]
             self.last_corr_stats, self.last_corr_residual_px = cstats, resid
-        self._backward_core(s, d_color, d_wsum, d_weights, None, d_nmap, eik_coef)
+        self._backward_core(s, d_color, d_wsum, d_weights, None, d_nmap, eik_coef, persistent=True)
         self.last_state = s
         if ray_grads:
             d_R = None

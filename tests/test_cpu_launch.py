@@ -1,0 +1,69 @@
+"""CPU: the one-node launcher (dynhor_amd/launch.py) -- `python bench.py --gpus N` / `python -m dynhor_amd.run --gpus N`
+start their own ranks when WORLD_SIZE is unset (VERDICT r2 missing #1).  Here: command form, a real world-2 gloo launch of a
+tiny target through spawn_ranks, exit-code relay, and bench.py's parent path never touching a GPU (there is none here)."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+TARGET = '''
+import json, os, sys
+import torch, torch.distributed as dist
+dist.init_process_group("gloo")
+t = torch.tensor([float(dist.get_rank() + 1)])
+dist.all_reduce(t)
+if "--fail-rank-1" in sys.argv and dist.get_rank() == 1:
+    sys.exit(7)
+if dist.get_rank() == 0:
+    print(json.dumps({"sum": t.item(), "world": dist.get_world_size(), "argv": sys.argv[1:]}), flush=True)
+dist.destroy_process_group()
+'''
+
+
+def test_rank_command_form():
+    from dynhor_amd import launch
+    cmd = launch.rank_command("/x/bench.py", ["--gpus", "8", "--steps", "5"], 8, port=29511)
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=8" in cmd and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29511"
+    assert cmd[-5:] == ["/x/bench.py", "--gpus", "8", "--steps", "5"]
+    cmd = launch.rank_command("dynhor_amd.run", ["--gpus", "2"], 2, port=1, module=True)
+    assert cmd[-4:] == ["-m", "dynhor_amd.run", "--gpus", "2"]
+
+
+def _spawn(tmp_path, extra):
+    target = tmp_path / "target.py"
+    target.write_text(TARGET)
+    code = ("import sys; sys.path.insert(0, %r); from dynhor_amd import launch; "
+            "sys.exit(launch.spawn_ranks(%r, %r, 2, timeout=240))" % (ROOT, str(target), ["--tag", "x"] + extra))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    return subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env)
+
+
+def test_spawn_ranks_runs_world_2_and_relays_rank0_stdout(tmp_path):
+    p = _spawn(tmp_path, [])
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    out = json.loads(lines[0])
+    assert out == {"sum": 3.0, "world": 2, "argv": ["--tag", "x"]}
+
+
+def test_spawn_ranks_relays_a_failing_rank(tmp_path):
+    p = _spawn(tmp_path, ["--fail-rank-1"])
+    assert p.returncode != 0
+
+
+def test_bench_parent_refuses_more_ranks_than_gpus_without_touching_one():
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert p.returncode == 2 and "GPU(s) are visible" in p.stderr and "AssertionError" not in p.stderr
+
+
+def test_bench_rejects_mismatched_world_size():
+    env = dict(os.environ, WORLD_SIZE="4", RANK="0", LOCAL_RANK="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True,
+                       timeout=300, env=env)
+    assert p.returncode == 2 and "WORLD_SIZE=4" in p.stderr

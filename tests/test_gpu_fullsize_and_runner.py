@@ -130,7 +130,7 @@ def _free_port():
     return port
 
 
-def test_two_rank_data_parallel_on_one_gpu():
+def test_two_rank_data_parallel_on_one_gpu_under_torchrun():
     """Whole DP flow (frame sharding, flat-gradient all-reduce, identical Adam step) with 2 processes sharing cuda:0 over
     gloo -- the same code path the 8-GPU RCCL run takes, minus the transport."""
     import subprocess

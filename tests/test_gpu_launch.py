@@ -1,0 +1,67 @@
+"""GPU: the multi-GPU entry points as the driver calls them (VERDICT r2 missing #1 / next #1).
+  * RCCL executes the path's one collective at least once: `bench.py --gpus 1 --force-dist --backend nccl`.
+  * `python bench.py --gpus 2` with NO torchrun on the command line starts its own two ranks (gloo, both on cuda:0).
+  * `python -m dynhor_amd.run --gpus 2` does the same for the Runner CLI."""
+import json
+import math
+import os
+import subprocess
+import sys
+
+import pytest
+import yaml
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _clean_env():
+    return {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+
+
+def _run(cmd, timeout=420):
+    try:
+        p = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=_clean_env(), cwd=ROOT)
+    except subprocess.TimeoutExpired as e:
+        pytest.fail(f"{' '.join(cmd[1:4])} did not finish in {timeout} s: " + str(e.stdout)[-1500:] + str(e.stderr)[-1500:])
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    return p
+
+
+def test_single_rank_rccl_allreduce_runs():
+    p = _run([sys.executable, "bench.py", "--gpus", "1", "--force-dist", "--backend", "nccl", "--steps", "3", "--warmup", "1",
+              "--frames", "8", "--no-cpu-baseline"])
+    out = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    comm = out["comm"]
+    assert comm["backend"] == "nccl" and comm["nranks"] == 1
+    assert comm["rccl_version"] and all(c.isdigit() or c == "." for c in comm["rccl_version"]), comm
+    assert math.isfinite(comm["allreduce_only_ms"]) and comm["allreduce_only_ms"] >= 0.0
+    assert comm["bucket_bytes"] == 802491 * 4 and comm["bucket_persistent"] is True
+    assert out["n_gpus"] == 1 and out["value"] > 0 and math.isfinite(out["final_stats"]["loss"])
+
+
+def test_bench_starts_its_own_two_ranks():
+    """The driver's command form: no torch.distributed.run on the command line."""
+    p = _run([sys.executable, "bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1", "--frames", "8", "--backend", "gloo",
+              "--share-gpu", "--check-sync", "--no-cpu-baseline"])
+    assert "check-sync ok" in p.stdout
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, "exactly one JSON line (rank 0's) must reach the parent's stdout"
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["parallelism"] == "dp2" and out["value"] > 0
+    assert out["comm"]["nranks"] == 2 and out["comm"]["bucket_persistent"] is True
+
+
+def test_runner_cli_starts_its_own_two_ranks(tmp_path):
+    conf = {"seq_name": "launch_test", "exp_name": "dp2",
+            "data_info": {"synthetic": {"n_frames": 4, "H": 64, "W": 64, "seed": 5}},
+            "train": {"batch_size": 256, "end_iter": 4, "report_freq": 2, "save_freq": 4, "val_freq": 0, "normal_weight": 0.05}}
+    cpath = tmp_path / "c.yaml"
+    cpath.write_text(yaml.safe_dump(conf))
+    p = _run([sys.executable, "-m", "dynhor_amd.run", "--config_path", str(cpath), "--gpus", "2", "--backend", "gloo",
+              "--share-gpu", "--exp_root", str(tmp_path / "exps")])
+    assert "trained to iteration 4 on 2 rank(s)" in p.stdout
+    exp = tmp_path / "exps" / "launch_test" / "dp2"
+    assert (exp / "checkpoints" / "ckpt_000004.pth").exists()
+    recs = [json.loads(l) for l in (exp / "scalars.jsonl").read_text().splitlines()]
+    assert [r["iter"] for r in recs] == [2, 4] and all(math.isfinite(r["Loss/loss"]) for r in recs)
