@@ -120,6 +120,7 @@ class Runner:
         self.ray_gen.manual_seed(tr["ray_seed"] * 1000003 + self.rank)
         self.frame_perm = schedules.FramePermutation(self.dataset.n_images, tr["ray_seed"])   # same on every rank
         self.scalars = []
+        self._board = None
         if is_continue:
             ck_dir = os.path.join(self.base_exp_dir, "checkpoints")
             ck = sorted(f for f in os.listdir(ck_dir) if f.endswith(".pth")) if os.path.isdir(ck_dir) else []
@@ -219,6 +220,15 @@ class Runner:
             self.scalars.append(rec)
             with open(os.path.join(self.base_exp_dir, "scalars.jsonl"), "a") as f:
                 f.write(json.dumps(rec) + "\n")
+            # the reference's logger: one scalar per key per step to a SummaryWriter under <exp>/board
+            # (ObjTracker/run.py:125-127, jointopt.py:151-153)
+            if self._board is None:
+                from .tb_events import make_writer
+                self._board = make_writer(os.path.join(self.base_exp_dir, "board"))
+            for k, v in rec.items():
+                if k != "iter":
+                    self._board.add_scalar(k, v, self.iter_step)
+            self._board.flush()
         return rec
 
     @torch.no_grad()

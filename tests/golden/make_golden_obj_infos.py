@@ -38,6 +38,20 @@ def main():
         data = {"R": obj_rot_np[i], "T": obj_trans_np[i], "K": camintr}
         path_id = image_paths[i].split("/")[-1][:-4]
         np.savez(os.path.join(dst, "{}.npz".format(path_id)), **data)
+    # one more sequence folder whose files carry `obj_scale`, the optional key ObjTracker/vis.py:48-52 reads back
+    # (`obj_v_trans = (obj_scale * obj_verts_can) @ R.T + T`): same R / K, T = obj_scale * (the T above), so that a reader
+    # that honours the key recovers the SAME canonical cameras and one that ignores it is off by the factor.  Frame 0015 has no
+    # file: vis.py:44 skips frames without a pose.
+    dst_s = os.path.join(os.path.dirname(os.path.abspath(__file__)), "obj_infos_scaled")
+    os.makedirs(dst_s, exist_ok=True)
+    obj_scales = [2.0, 0.5, None, 1.25]
+    for i in range(len(image_paths)):
+        if obj_scales[i] is None:
+            continue
+        data = {"R": obj_rot_np[i], "T": obj_trans_np[i] * np.float32(obj_scales[i]), "K": camintr,
+                "obj_scale": np.float32(obj_scales[i])}
+        path_id = image_paths[i].split("/")[-1][:-4]
+        np.savez(os.path.join(dst_s, "{}.npz".format(path_id)), **data)
     np.savez(os.path.join(dst, "_inputs.npz"), rotations_object=rotations_object.numpy(), translations_object=translations_object.numpy(),
              height=height, width=width)
     print("wrote", dst, sorted(os.listdir(dst)))

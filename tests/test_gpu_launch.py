@@ -65,3 +65,10 @@ def test_runner_cli_starts_its_own_two_ranks(tmp_path):
     assert (exp / "checkpoints" / "ckpt_000004.pth").exists()
     recs = [json.loads(l) for l in (exp / "scalars.jsonl").read_text().splitlines()]
     assert [r["iter"] for r in recs] == [2, 4] and all(math.isfinite(r["Loss/loss"]) for r in recs)
+    # the reference's logger (run.py:127, jointopt.py:151-153): one scalar per key per step in <exp>/board
+    import glob
+    from dynhor_amd import tb_events
+    ev = glob.glob(str(exp / "board" / "events.out.tfevents.*"))
+    assert len(ev) == 1, "rank 0 alone writes the board"
+    sc = tb_events.read_scalars(ev[0])
+    assert [(st, v) for st, t, v in sc if t == "Loss/loss"] == [(r["iter"], pytest.approx(r["Loss/loss"], rel=1e-6)) for r in recs]
