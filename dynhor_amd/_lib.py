@@ -49,11 +49,11 @@ SIGNATURES = {
     "dh_hash_pack_weights": (_i32, [_vp, _vp, _vp]),
     "dh_hash_workspace_floats": (_i32, [_i64, ctypes.POINTER(_i64), ctypes.POINTER(_i64)]),
     "dh_hash_sdf_nograd": (_i32, [_vp, _vp, _vp, _i64, _f32, _vp, _vp]),
-    "dh_hash_geo_forward": (_i32, [_vp, _vp, _vp, _i64, _f32, _f32, _vp, _i32, _vp, _vp, _vp, _vp]),
-    "dh_hash_color_forward": (_i32, [_vp, _vp, _vp, _vp, _i32, _i64, _vp, _vp]),
-    "dh_hash_color_backward": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i64, _vp, _vp, _vp, _vp]),
-    "dh_hash_geo_backward": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _f32, _f32, _vp, _vp]),
-    "dh_hash_weight_grads": (_i32, [_vp, _vp, _i64, _vp, _vp, _vp]),
+    "dh_hash_geo_forward": (_i32, [_vp, _vp, _vp, _i64, _f32, _f32, _vp, _i32, _vp, _vp, _vp, _vp, _vp]),
+    "dh_hash_color_forward": (_i32, [_vp, _vp, _vp, _vp, _i32, _i64, _vp, _vp, _vp]),
+    "dh_hash_color_backward": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i64, _vp, _vp, _vp, _vp, _vp]),
+    "dh_hash_geo_backward": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _f32, _f32, _vp, _vp, _vp]),
+    "dh_hash_weight_grads": (_i32, [_vp, _vp, _i64, _vp, _vp, _vp, _vp]),
     "dh_gen_rays": (_i32, [_vp] * 6 + [_i32, _i32, _i32, _i32, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),
     "dh_coarse_samples": (_i32, [_vp] * 5 + [_i64, _i32, _vp, _vp, _vp]),
     "dh_upsample_step": (_i32, [_vp] * 4 + [_i64, _i32, _i32, _f32, _vp, _vp, _vp]),
@@ -63,11 +63,11 @@ SIGNATURES = {
     "dh_render_scan_bwd": (_i32, [_vp] * 7 + [_f32, _f32, _vp, _i64, _i32] + [_vp] * 11),
     "dh_render_scan_bwd_rays": (_i32, [_vp] * 7 + [_f32, _f32, _vp, _i64, _i32] + [_vp] * 12),
     "dh_march_count": (_i32, [_vp] * 6 + [_i32, _f32, _f32, _f32, _i32, _i64, _vp, _vp]),
-    "dh_march_emit": (_i32, [_vp] * 6 + [_i32, _f32, _f32, _f32, _i32, _i64] + [_vp] * 6),
+    "dh_march_emit": (_i32, [_vp] * 6 + [_i32, _f32, _f32, _f32, _i32, _i64] + [_vp] * 7),
     "dh_render_scan_fwd_packed": (_i32, [_vp] * 7 + [_f32, _f32, _vp, _i64] + [_vp] * 11),
     "dh_render_scan_bwd_packed": (_i32, [_vp] * 7 + [_f32, _f32, _vp, _i64] + [_vp] * 13),
     "dh_neus_loss": (_i32, [_vp] * 6 + [_i64, _f32, _f32, _f32] + [_vp] * 6),
-    "dh_corr_loss": (_i32, [_vp] * 7 + [_i32, _vp, _i64, _i32, _f32, _f32, _f32, _vp, _vp, _vp, _vp]),
+    "dh_corr_loss": (_i32, [_vp] * 7 + [_i32, _vp, _i64, _i32, _f32, _f32, _f32, _vp, _vp, _vp, _vp, _vp]),
 }
 
 
@@ -109,6 +109,8 @@ STAGE_KERNELS = {
                       "sdf_nograd_fine": "sdf_nograd_kernel"},
 }
 HASH_STAGE_KERNELS = {"hash_weight_grads": "hash_table_bwd_kernel"}
+# every kernel one C-ABI stage of the hash family launches (scripts/make_traffic_json.py sums their counters)
+HASH_STAGE_LAUNCHES = {"hash_weight_grads": ["small_dw_kernel", "small_dw_reduce_kernel", "hash_fold_kernel", "hash_table_bwd_kernel"]}
 
 
 def set_arithmetic(mode: int):

@@ -297,13 +297,14 @@ int dh_march_count(const float* rays_o, const float* rays_d, const float* near, 
 
 int dh_march_emit(const float* rays_o, const float* rays_d, const float* near, const float* far, const float* u,
                   const uint8_t* occupancy, int res, float radius, float step, float half_step, int max_samples, int64_t B,
-                  const int64_t* off, float* t_start, float* pts, float* dirs_pts, int32_t* ray_idx, void* stream) {
+                  const int64_t* off, const int32_t* keep, float* t_start, float* pts, float* dirs_pts, int32_t* ray_idx,
+                  void* stream) {
     if (B < 0 || res <= 0 || !(radius > 0.f) || !(step > 0.f) || max_samples <= 0) return DH_ERR_BAD_ARG;
     if (max_samples > 1024) return DH_ERR_UNSUPPORTED;
     if (B == 0) return DH_OK;
     if (!rays_o || !rays_d || !near || !far || !occupancy || !off || !t_start || !pts || !dirs_pts || !ray_idx) return DH_ERR_BAD_ARG;
-    return launch_march_emit(rays_o, rays_d, near, far, u, occupancy, res, radius, step, half_step, max_samples, B, off, t_start,
-                             pts, dirs_pts, ray_idx, static_cast<hipStream_t>(stream));
+    return launch_march_emit(rays_o, rays_d, near, far, u, occupancy, res, radius, step, half_step, max_samples, B, off, keep,
+                             t_start, pts, dirs_pts, ray_idx, static_cast<hipStream_t>(stream));
 }
 
 int dh_render_scan_fwd_packed(const float* rays_o, const float* rays_d, const float* t_start, const float* sdf, const float* normals,
@@ -357,12 +358,13 @@ int dh_neus_loss(const float* color, const float* weight_sum, const float* norma
 
 int dh_corr_loss(const float* rays_o, const float* rays_d, const float* z, const float* weights, const float* corr,
                  const float* R_all, const float* T_all, int n_frames, const float* K, int64_t B, int n, float sample_dist,
-                 float delta_px, float corr_weight, float* stats, float* residual_px, float* d_weights, void* stream) {
+                 float delta_px, float corr_weight, float* stats, float* residual_px, float* d_weights, float* pose_adjoints,
+                 void* stream) {
     if (B <= 0 || n <= 0 || n_frames <= 0 || !(delta_px > 0.f)) return DH_ERR_BAD_ARG;
     if (!rays_o || !rays_d || !z || !weights || !corr || !R_all || !T_all || !K || !stats || !residual_px || !d_weights)
         return DH_ERR_BAD_ARG;
     return launch_corr_loss(rays_o, rays_d, z, weights, corr, R_all, T_all, n_frames, K, B, n, sample_dist, delta_px, corr_weight,
-                            stats, residual_px, d_weights, static_cast<hipStream_t>(stream));
+                            stats, residual_px, d_weights, pose_adjoints, static_cast<hipStream_t>(stream));
 }
 
 int64_t dh_hashgrid_entries(void) { return hashgrid_entries(); }
@@ -427,46 +429,47 @@ int dh_hash_sdf_nograd(const float* params, const float* packed, const float* pt
 }
 
 int dh_hash_geo_forward(const float* params, const float* packed, const float* pts, int64_t n, float radius, float eps,
-                        float* ws, int save, float* sdf, float* feature, float* gradient, void* stream) {
-    if (n < 0 || !(radius > 0.f) || !(eps > 0.f)) return DH_ERR_BAD_ARG;
+                        float* ws, int save, float* sdf, float* feature, float* gradient, const int64_t* n_active, void* stream) {
+    if (n < 0 || !(radius > 0.f) || !(eps > 0.f) || (n_active && n % 8)) return DH_ERR_BAD_ARG;
     if (n == 0) return DH_OK;
     if (!params || !packed || !pts || !ws || !sdf || !feature || !gradient || !al16(params) || !al16(packed) || !al16(ws))
         return DH_ERR_BAD_ARG;
-    return launch_hash_geo_fwd(params, packed, pts, n, radius, eps, ws, save, sdf, feature, gradient,
+    return launch_hash_geo_fwd(params, packed, pts, n, radius, eps, ws, save, sdf, feature, gradient, n_active,
                                static_cast<hipStream_t>(stream));
 }
 
 int dh_hash_color_forward(const float* packed, const float* feature, const float* normals, const float* dirs,
-                          int n_per_ray, int64_t n, float* color, void* stream) {
+                          int n_per_ray, int64_t n, float* color, const int64_t* n_active, void* stream) {
     if (n < 0 || n_per_ray <= 0 || n % n_per_ray) return DH_ERR_BAD_ARG;
     if (n == 0) return DH_OK;
     if (!packed || !feature || !normals || !dirs || !color || !al16(packed)) return DH_ERR_BAD_ARG;
-    return launch_sh_color_fwd(packed, feature, normals, dirs, n_per_ray, n, color, static_cast<hipStream_t>(stream));
+    return launch_sh_color_fwd(packed, feature, normals, dirs, n_per_ray, n, color, n_active, static_cast<hipStream_t>(stream));
 }
 
 int dh_hash_color_backward(const float* packed, const float* feature, const float* normals, const float* dirs,
                            const float* d_color, int n_per_ray, int64_t n, float* ws, float* d_feature, float* d_normals,
-                           void* stream) {
-    if (n <= 0 || n_per_ray <= 0 || n % n_per_ray) return DH_ERR_BAD_ARG;
+                           const int64_t* n_active, void* stream) {
+    if (n <= 0 || n_per_ray <= 0 || n % n_per_ray || (n_active && n % 8)) return DH_ERR_BAD_ARG;
     if (!packed || !feature || !normals || !dirs || !d_color || !ws || !d_feature || !d_normals || !al16(packed) || !al16(ws))
         return DH_ERR_BAD_ARG;
-    return launch_sh_color_bwd(packed, feature, normals, dirs, d_color, n_per_ray, n, ws, d_feature, d_normals,
+    return launch_sh_color_bwd(packed, feature, normals, dirs, d_color, n_per_ray, n, ws, d_feature, d_normals, n_active,
                                static_cast<hipStream_t>(stream));
 }
 
 int dh_hash_geo_backward(const float* params, const float* packed, const float* pts, const float* d_sdf,
                          const float* d_feature, const float* d_normals, int64_t n, float radius, float eps, float* ws,
-                         void* stream) {
-    if (n <= 0 || !(radius > 0.f) || !(eps > 0.f)) return DH_ERR_BAD_ARG;
+                         const int64_t* n_active, void* stream) {
+    if (n <= 0 || !(radius > 0.f) || !(eps > 0.f) || (n_active && n % 8)) return DH_ERR_BAD_ARG;
     if (!params || !packed || !pts || !d_sdf || !d_feature || !d_normals || !ws || !al16(params) || !al16(packed) || !al16(ws))
         return DH_ERR_BAD_ARG;
-    return launch_hash_geo_bwd(params, packed, pts, d_sdf, d_feature, d_normals, n, radius, eps, ws,
+    return launch_hash_geo_bwd(params, packed, pts, d_sdf, d_feature, d_normals, n, radius, eps, ws, n_active,
                                static_cast<hipStream_t>(stream));
 }
 
-int dh_hash_weight_grads(const float* params, const float* packed, int64_t n, float* ws, float* grad, void* stream) {
-    if (n <= 0 || !params || !packed || !ws || !grad || !al16(ws)) return DH_ERR_BAD_ARG;
-    return launch_hash_weight_grads(params, packed, n, ws, grad, static_cast<hipStream_t>(stream));
+int dh_hash_weight_grads(const float* params, const float* packed, int64_t n, float* ws, float* grad, const int64_t* n_active,
+                         void* stream) {
+    if (n <= 0 || !params || !packed || !ws || !grad || !al16(ws) || (n_active && n % 8)) return DH_ERR_BAD_ARG;
+    return launch_hash_weight_grads(params, packed, n, ws, grad, n_active, static_cast<hipStream_t>(stream));
 }
 
 }  // extern "C"

@@ -174,13 +174,23 @@ __device__ __forceinline__ void encode7_point(const HashLevels& H, const float2*
     }
 }
 
+// Packed rays (occupancy-grid sampler): the number of samples of an iteration is known only on the device.  The launches are
+// sized and the workspace is laid out for a host-known CAPACITY n; `n_act` (device pointer, may be null) holds how many of the
+// n rows are real -- threads past it leave, so nothing waits for a device -> host read of the count.
+__device__ __forceinline__ int64_t active_rows(const int64_t* __restrict__ n_act, int64_t n) {
+    if (!n_act) return n;
+    const int64_t a = *n_act;
+    return a < n ? (a < 0 ? 0 : a) : n;
+}
+
 // levels l_base + blockIdx.y, gathers from global memory (one thread per point)
 __global__ __launch_bounds__(256) void hash_encode7_kernel(HashLevels H, const float* __restrict__ table,
                                                            const float* __restrict__ pts, int64_t n, float radius, float eps,
-                                                           float* __restrict__ gin, int64_t lde, int l_base) {
+                                                           float* __restrict__ gin, int64_t lde, int l_base,
+                                                           const int64_t* __restrict__ n_act) {
     const int l = l_base + blockIdx.y;
     const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (p >= n) return;
+    if (p >= active_rows(n_act, n)) return;
     encode7_point(H, reinterpret_cast<const float2*>(table) + H.offset[l], l, p, pts, n, radius, eps, gin, lde);
 }
 
@@ -213,11 +223,13 @@ __global__ __launch_bounds__(256) void hash_geo_mlp_fwd_kernel(const float* __re
                                                                int64_t n, float radius, float eps,
                                                                const float* __restrict__ gin, int64_t lde,
                                                                float* __restrict__ sdf, float* __restrict__ feat,
-                                                               float* __restrict__ grad) {
+                                                               float* __restrict__ grad, const int64_t* __restrict__ n_act) {
     __shared__ __attribute__((aligned(16))) float W[HP_WEIGHTS + 4];
-    stage_weights(W, hp);
     const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (p >= n) return;
+    const int64_t na = active_rows(n_act, n);
+    if ((int64_t)blockIdx.x * 256 >= na) return;          // the whole workgroup is past the end: skip the weight staging too
+    stage_weights(W, hp);
+    if (p >= na) return;
     const float x[3] = {pts[p * 3], pts[p * 3 + 1], pts[p * 3 + 2]};
     float in[36], out[HM_GOUT];
     load_geo_input(gin, lde, p, x, radius, in);
@@ -255,11 +267,14 @@ __device__ __forceinline__ void sh4_eval(const float (&d)[3], float (&y)[16]) {
 
 __global__ __launch_bounds__(256) void sh_color_fwd_kernel(const float* __restrict__ hp, const float* __restrict__ feat,
                                                            const float* __restrict__ normals, const float* __restrict__ dirs,
-                                                           int n_per_ray, int64_t n, float* __restrict__ color) {
+                                                           int n_per_ray, int64_t n, float* __restrict__ color,
+                                                           const int64_t* __restrict__ n_act) {
     __shared__ __attribute__((aligned(16))) float W[HP_WEIGHTS + 4];
-    stage_weights(W, hp);
     const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (p >= n) return;
+    const int64_t na = active_rows(n_act, n);
+    if ((int64_t)blockIdx.x * 256 >= na) return;
+    stage_weights(W, hp);
+    if (p >= na) return;
     float in[HM_CIN];
     DH_UNROLL for (int c = 0; c < HM_FEAT; ++c) in[c] = feat[p * HM_FEAT + c];
     const int64_t ray = p / n_per_ray;
@@ -337,11 +352,13 @@ __global__ __launch_bounds__(256) void sh_color_bwd_kernel(const float* __restri
                                                            const float* __restrict__ normals, const float* __restrict__ dirs,
                                                            const float* __restrict__ d_color, int n_per_ray, int64_t n,
                                                            float* __restrict__ ws, HashWs O, float* __restrict__ d_feat,
-                                                           float* __restrict__ d_normals) {
+                                                           float* __restrict__ d_normals, const int64_t* __restrict__ n_act) {
     __shared__ __attribute__((aligned(16))) float W[HP_WEIGHTS + 4];
-    stage_weights(W, hp);
     const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (p >= n) return;
+    const int64_t na = active_rows(n_act, n);
+    if ((int64_t)blockIdx.x * 256 >= na) return;
+    stage_weights(W, hp);
+    if (p >= na) return;
     float in[HM_CIN];
     DH_UNROLL for (int c = 0; c < HM_FEAT; ++c) in[c] = feat[p * HM_FEAT + c];
     const int64_t ray = p / n_per_ray;
@@ -429,11 +446,14 @@ __global__ __launch_bounds__(256) void sh_color_bwd_kernel(const float* __restri
 __global__ __launch_bounds__(256) void hash_geo_bwd_kernel(const float* __restrict__ hp, const float* __restrict__ pts,
                                                            const float* __restrict__ d_sdf, const float* __restrict__ d_feat,
                                                            const float* __restrict__ d_grad, int64_t n, float radius,
-                                                           float eps, float* __restrict__ ws, HashWs O) {
+                                                           float eps, float* __restrict__ ws, HashWs O,
+                                                           const int64_t* __restrict__ n_act) {
     __shared__ __attribute__((aligned(16))) float W[HP_WEIGHTS + 4];
-    stage_weights(W, hp);
     const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (p >= n) return;
+    const int64_t na = active_rows(n_act, n);
+    if ((int64_t)blockIdx.x * 256 >= na) return;
+    stage_weights(W, hp);
+    if (p >= na) return;
     const float x[3] = {pts[p * 3], pts[p * 3 + 1], pts[p * 3 + 2]};
     for (int e = 0; e < HW_E; ++e) {
         float xe[3] = {x[0], x[1], x[2]};
@@ -501,13 +521,15 @@ __global__ __launch_bounds__(256) void hash_geo_bwd_kernel(const float* __restri
 // 24.9 ms -> see DESIGN.md for the measured ladder.  dh_hash_set_scatter_mode(1 / 2) switches (b) / (a) off for ablation.
 template <int MODE>   // 0: both merges; 1: no lane-run merge; 2: no evaluation merge (ablation / debugging)
 __global__ __launch_bounds__(256) void hash_table_bwd_kernel(HashLevels H, const float* __restrict__ ws, HashWs O, int64_t n,
-                                                             float* __restrict__ d_table) {
+                                                             float* __restrict__ d_table, const int64_t* __restrict__ n_act) {
     const int l = blockIdx.y;
     const int lane = threadIdx.x & 63;
     const int64_t p = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 2;
     const int dx = (threadIdx.x >> 1) & 1, f = threadIdx.x & 1;
-    const bool valid = p < n;
-    const int64_t pc = valid ? p : n - 1;
+    const int64_t na = active_rows(n_act, n);              // rows are laid out for the capacity n, na of them are real
+    if ((int64_t)blockIdx.x * 64 >= na) return;            // workgroup-uniform: no sample of this block exists
+    const bool valid = p < na;
+    const int64_t pc = valid ? p : na - 1;
     const float* X = ws + O.x01;
     const float* D = ws + O.din + (int64_t)l * HW_E * n * 2 + f;          // feature f of the level-major float2 rows
     float* T = d_table + f;
@@ -603,17 +625,21 @@ __global__ __launch_bounds__(256) void hash_table_bwd_kernel(HashLevels H, const
 // lanes cover one feature's 256 B), staged in LDS (row stride 65: the operand reads of a 32-lane half hit 32 banks), and
 // each wave accumulates one 32x32 quadrant of dW with fp32 MFMA 32x32x2; the next tile's global loads are in flight
 // while the current one is multiplied.
-struct SmallDwJob { int64_t a, b; int M, K; int64_t rows, ld; };
+// rows = blocks x blk: `blocks` evaluations of `blk` (= capacity) rows each, of which the first n_act (device count) are real
+struct SmallDwJob { int64_t a, b; int M, K; int64_t rows, ld, blk; };
 struct SmallDwJobs { SmallDwJob j[HW_JOBS]; };
 constexpr int DWT = 64, DWS = DWT + 1;
 
-__global__ __launch_bounds__(256) void small_dw_kernel(const float* __restrict__ ws, SmallDwJobs J, float* __restrict__ slabs) {
+__global__ __launch_bounds__(256) void small_dw_kernel(const float* __restrict__ ws, SmallDwJobs J, float* __restrict__ slabs,
+                                                       const int64_t* __restrict__ n_act) {
     __shared__ float At[64 * DWS], Bt[64 * DWS];
     const SmallDwJob job = J.j[blockIdx.y];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 31, kk = lane >> 5;
     const int mt = wave >> 1, kt = wave & 1;
     const int64_t per = ((job.rows + HW_SLABS - 1) / HW_SLABS + DWT - 1) / DWT * DWT;
     const int64_t r0 = (int64_t)blockIdx.x * per, r1 = r0 + per < job.rows ? r0 + per : job.rows;
+    const int64_t na = active_rows(n_act, job.blk);      // packed rays: rows [e blk + na, (e + 1) blk) of every evaluation e are stale
+    const bool ragged = na < job.blk;
     const int lf = tid >> 4, lc = tid & 15;              // loader: features lf + 16 q, rows 4 lc .. 4 lc + 3 of the tile
     const float* A = ws + job.a;
     const float* B = ws + job.b;
@@ -622,8 +648,18 @@ __global__ __launch_bounds__(256) void small_dw_kernel(const float* __restrict__
     float cs[4] = {0.f, 0.f, 0.f, 0.f};
     f32x4 ra[4], rb[4];
     const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+    auto tile_dead = [&](int64_t rt) {                   // wholly inside one block's stale rows (workgroup-uniform)
+        if (!ragged) return false;
+        const int64_t e0 = rt / job.blk, e1 = (rt + DWT - 1) / job.blk;
+        return e0 == e1 && rt - e0 * job.blk >= na;
+    };
     auto load = [&](int64_t rt) {
         const int64_t r = rt + 4 * lc;
+        if (tile_dead(rt)) {                             // nothing of this tile exists: no memory traffic either
+            DH_UNROLL for (int q = 0; q < 4; ++q) { ra[q] = z4; rb[q] = z4; }
+            return;
+        }
+        const int64_t rin = ragged ? r % job.blk : 0;    // blk is a multiple of 4 (API contract), so the 4 rows share a block
         DH_UNROLL for (int q = 0; q < 4; ++q) {
             const int f = lf + 16 * q;
             ra[q] = (f < job.M && r < r1) ? *reinterpret_cast<const f32x4*>(A + (int64_t)f * job.ld + r) : z4;
@@ -631,11 +667,18 @@ __global__ __launch_bounds__(256) void small_dw_kernel(const float* __restrict__
             if (r + 4 > r1) {                            // ragged tail: rows past the end hold garbage
                 DH_UNROLL for (int u = 0; u < 4; ++u) if (r + u >= r1) { ra[q][u] = 0.f; rb[q][u] = 0.f; }
             }
+            if (ragged) {                                // rows past the device-side count: not written this iteration
+                DH_UNROLL for (int u = 0; u < 4; ++u) if (rin + u >= na) { ra[q][u] = 0.f; rb[q][u] = 0.f; }
+            }
         }
     };
     if (r0 < r1) load(r0);
     const bool active = mt * 32 < job.M && kt * 32 < job.K;          // wave-uniform
     for (int64_t rt = r0; rt < r1; rt += DWT) {
+        if (tile_dead(rt)) {                             // its (zero) registers were loaded by the previous trip: replace them
+            if (rt + DWT < r1) load(rt + DWT);
+            continue;
+        }
         __syncthreads();                                 // the previous tile's readers are done
         DH_UNROLL for (int q = 0; q < 4; ++q) {
             const int f = lf + 16 * q;
@@ -720,19 +763,20 @@ int launch_hash_sdf_nograd(const float* params, const float* hp, const float* pt
     return ok();
 }
 int launch_hash_geo_fwd(const float* params, const float* hp, const float* pts, int64_t n, float radius, float eps,
-                        float* ws, int save, float* sdf, float* feat, float* grad, hipStream_t st) {
+                        float* ws, int save, float* sdf, float* feat, float* grad, const int64_t* n_act, hipStream_t st) {
     const HashWs O = make_hash_ws(n);
     float* gin = save ? ws + O.gin : ws;               // forward-only callers hand over just the GIN rows
     const unsigned nb = (unsigned)((n + 255) / 256);
     hipLaunchKernelGGL(hash_encode7_kernel, dim3(nb, HG_L), dim3(256), 0, st, hashgrid_levels(), params + hash_param_off().table, pts,
-                       n, radius, eps, gin, O.lde, 0);
-    hipLaunchKernelGGL(hash_geo_mlp_fwd_kernel, dim3(nb), dim3(256), 0, st, hp, pts, n, radius, eps, gin, O.lde, sdf, feat, grad);
+                       n, radius, eps, gin, O.lde, 0, n_act);
+    hipLaunchKernelGGL(hash_geo_mlp_fwd_kernel, dim3(nb), dim3(256), 0, st, hp, pts, n, radius, eps, gin, O.lde, sdf, feat, grad,
+                       n_act);
     return ok();
 }
 int launch_sh_color_fwd(const float* hp, const float* feat, const float* normals, const float* dirs, int n_per_ray,
-                        int64_t n, float* color, hipStream_t st) {
+                        int64_t n, float* color, const int64_t* n_act, hipStream_t st) {
     hipLaunchKernelGGL(sh_color_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, hp, feat, normals, dirs,
-                       n_per_ray, n, color);
+                       n_per_ray, n, color, n_act);
     return ok();
 }
 
@@ -744,43 +788,46 @@ int64_t hash_workspace_floats(int64_t n) { return make_hash_ws(n).total + (int64
 int64_t hash_infer_workspace_floats(int64_t n) { return make_hash_ws(n).lde * 36; }
 
 int launch_sh_color_bwd(const float* hp, const float* feat, const float* normals, const float* dirs, const float* d_color,
-                        int n_per_ray, int64_t n, float* ws, float* d_feat, float* d_normals, hipStream_t st) {
+                        int n_per_ray, int64_t n, float* ws, float* d_feat, float* d_normals, const int64_t* n_act,
+                        hipStream_t st) {
     hipLaunchKernelGGL(sh_color_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, hp, feat, normals, dirs,
-                       d_color, n_per_ray, n, ws, make_hash_ws(n), d_feat, d_normals);
+                       d_color, n_per_ray, n, ws, make_hash_ws(n), d_feat, d_normals, n_act);
     return ok();
 }
 
 int launch_hash_geo_bwd(const float* params, const float* hp, const float* pts, const float* d_sdf, const float* d_feat,
-                        const float* d_grad, int64_t n, float radius, float eps, float* ws, hipStream_t st) {
+                        const float* d_grad, int64_t n, float radius, float eps, float* ws, const int64_t* n_act,
+                        hipStream_t st) {
     (void)params;
     hipLaunchKernelGGL(hash_geo_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, hp, pts, d_sdf, d_feat,
-                       d_grad, n, radius, eps, ws, make_hash_ws(n));
+                       d_grad, n, radius, eps, ws, make_hash_ws(n), n_act);
     return ok();
 }
 
 // all parameter gradients of the hash family from the rows the two kernels above left in ws: grad [hash_num_params]
-int launch_hash_weight_grads(const float* params, const float* hp, int64_t n, float* ws, float* grad, hipStream_t st) {
+int launch_hash_weight_grads(const float* params, const float* hp, int64_t n, float* ws, float* grad, const int64_t* n_act,
+                             hipStream_t st) {
     const HashWs O = make_hash_ws(n);
     const HashParamOff P = hash_param_off();
     const int64_t en = (int64_t)HW_E * n;
     SmallDwJobs J;
-    J.j[0] = {O.da, O.gin, 64, 36, en, O.lde};         // geometry lin0 (ones column -> bias)
-    J.j[1] = {O.dout, O.hh, HM_GOUT, 64, en, O.lde};   // geometry lin1
-    J.j[2] = {O.dz1, O.cin, 64, 32, n, O.ldn};         // colour lin0
-    J.j[3] = {O.dz2, O.h1, 64, 64, n, O.ldn};          // colour lin1
-    J.j[4] = {O.d_o, O.h2, 3, 64, n, O.ldn};           // colour lin2
+    J.j[0] = {O.da, O.gin, 64, 36, en, O.lde, n};         // geometry lin0 (ones column -> bias)
+    J.j[1] = {O.dout, O.hh, HM_GOUT, 64, en, O.lde, n};   // geometry lin1
+    J.j[2] = {O.dz1, O.cin, 64, 32, n, O.ldn, n};         // colour lin0
+    J.j[3] = {O.dz2, O.h1, 64, 64, n, O.ldn, n};          // colour lin1
+    J.j[4] = {O.d_o, O.h2, 3, 64, n, O.ldn, n};           // colour lin2
     float* slabs = ws + O.slabs;
     float* dwsum = ws + O.total;
-    hipLaunchKernelGGL(small_dw_kernel, dim3(HW_SLABS, HW_JOBS), dim3(256), 0, st, ws, J, slabs);
+    hipLaunchKernelGGL(small_dw_kernel, dim3(HW_SLABS, HW_JOBS), dim3(256), 0, st, ws, J, slabs, n_act);
     hipLaunchKernelGGL(small_dw_reduce_kernel, dim3((HW_DW_FLOATS + 255) / 256, HW_JOBS), dim3(256), 0, st, slabs, dwsum);
     hipLaunchKernelGGL(hash_fold_kernel, dim3(64, HW_JOBS), dim3(64), 0, st, params, hp, dwsum, P, grad);
     // table: scatter the encoding adjoint of all E n evaluations
     if (hipMemsetAsync(grad + P.table, 0, (size_t)hashgrid_entries() * 2 * sizeof(float), st) != hipSuccess) return -3;
     const int mode = hash_scatter_mode();      // dh_hash_set_scatter_mode: 0 shipping, 1 / 2 ablations (test / diagnosis only)
     const dim3 grid((unsigned)((4 * n + 255) / 256), HG_L);
-    if (mode == 1) hipLaunchKernelGGL(hash_table_bwd_kernel<1>, grid, dim3(256), 0, st, hashgrid_levels(), ws, O, n, grad + P.table);
-    else if (mode == 2) hipLaunchKernelGGL(hash_table_bwd_kernel<2>, grid, dim3(256), 0, st, hashgrid_levels(), ws, O, n, grad + P.table);
-    else hipLaunchKernelGGL(hash_table_bwd_kernel<0>, grid, dim3(256), 0, st, hashgrid_levels(), ws, O, n, grad + P.table);
+    if (mode == 1) hipLaunchKernelGGL(hash_table_bwd_kernel<1>, grid, dim3(256), 0, st, hashgrid_levels(), ws, O, n, grad + P.table, n_act);
+    else if (mode == 2) hipLaunchKernelGGL(hash_table_bwd_kernel<2>, grid, dim3(256), 0, st, hashgrid_levels(), ws, O, n, grad + P.table, n_act);
+    else hipLaunchKernelGGL(hash_table_bwd_kernel<0>, grid, dim3(256), 0, st, hashgrid_levels(), ws, O, n, grad + P.table, n_act);
     return ok();
 }
 

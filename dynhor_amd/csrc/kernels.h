@@ -51,14 +51,15 @@ int launch_march_count(const float* o, const float* d, const float* near, const 
                        hipStream_t st);
 int launch_march_emit(const float* o, const float* d, const float* near, const float* far, const float* u, const uint8_t* occ,
                       int res, float radius, float step, float half_step, int max_samples, int64_t B, const int64_t* off,
-                      float* t_start, float* pts, float* dirs_pts, int32_t* ray_idx, hipStream_t st);
+                      const int32_t* keep, float* t_start, float* pts, float* dirs_pts, int32_t* ray_idx, hipStream_t st);
 int launch_loss(const float* color, const float* wsum, const float* nmap, const float* eik, const float* rays,
                 const float* R, int64_t B, float igr_w, float mask_w, float normal_w, float* stats, float* d_color,
                 float* d_wsum, float* d_nmap, float* eik_coef, hipStream_t st);
 
 int launch_corr_loss(const float* rays_o, const float* rays_d, const float* z, const float* weights, const float* corr,
                      const float* R_all, const float* T_all, int n_frames, const float* K, int64_t B, int n, float sample_dist,
-                     float delta_px, float corr_w, float* stats, float* residual_px, float* d_weights, hipStream_t st);
+                     float delta_px, float corr_w, float* stats, float* residual_px, float* d_weights, float* pose_adj,
+                     hipStream_t st);
 
 // backward chains (kernels_mlp_bwd.hip) and weight gradients (dw.hip)
 int launch_color_bwd(const float* packed, const float* colors, const float* d_colors, int64_t npts, const float* cact,
@@ -96,13 +97,14 @@ int launch_hash_sdf_nograd(const float* params, const float* hp, const float* pt
                            hipStream_t st);
 int64_t hash_infer_workspace_floats(int64_t n);
 int launch_hash_geo_fwd(const float* params, const float* hp, const float* pts, int64_t n, float radius, float eps,
-                        float* ws, int save, float* sdf, float* feat, float* grad, hipStream_t st);
+                        float* ws, int save, float* sdf, float* feat, float* grad, const int64_t* n_act, hipStream_t st);
 int launch_sh_color_fwd(const float* hp, const float* feat, const float* normals, const float* dirs, int n_per_ray,
-                        int64_t n, float* color, hipStream_t st);
+                        int64_t n, float* color, const int64_t* n_act, hipStream_t st);
 int launch_sh_color_bwd(const float* hp, const float* feat, const float* normals, const float* dirs, const float* d_color,
-                        int n_per_ray, int64_t n, float* ws, float* d_feat, float* d_normals, hipStream_t st);
+                        int n_per_ray, int64_t n, float* ws, float* d_feat, float* d_normals, const int64_t* n_act, hipStream_t st);
 int launch_hash_geo_bwd(const float* params, const float* hp, const float* pts, const float* d_sdf, const float* d_feat,
-                        const float* d_grad, int64_t n, float radius, float eps, float* ws, hipStream_t st);
-int launch_hash_weight_grads(const float* params, const float* hp, int64_t n, float* ws, float* grad, hipStream_t st);
+                        const float* d_grad, int64_t n, float radius, float eps, float* ws, const int64_t* n_act, hipStream_t st);
+int launch_hash_weight_grads(const float* params, const float* hp, int64_t n, float* ws, float* grad, const int64_t* n_act,
+                             hipStream_t st);
 
 }  // namespace dh

@@ -24,11 +24,14 @@ enum : int { TP_SDF_B0 = 0, TP_SDF_B8 = 8, TP_W8ROW0_T = 9, TP_W8ROW0_S = 10, TP
 // ------------------------------------------------------------------------------------------------
 // K6: RenderingNetwork backward.  d_colors is wrt the post-sigmoid colour.
 // ------------------------------------------------------------------------------------------------
+template <bool RAYS>      // RAYS (pose refinement): as color_bwd_s_kernel<true> below -- the second arithmetic covers it too
 __global__ __launch_bounds__(256, 2) void color_bwd_kernel(ColPtrs C, const float* __restrict__ colors,
                                                             const float* __restrict__ d_colors, int64_t npts,
                                                             const float* __restrict__ cact, float* __restrict__ czbar,
                                                             float* __restrict__ featbar, float* __restrict__ d_normals,
-                                                            float* __restrict__ tpart) {
+                                                            float* __restrict__ tpart, const float* __restrict__ dirs,
+                                                            int n_per_ray, float* __restrict__ d_pts,
+                                                            float* __restrict__ d_dirs_pts) {
     __shared__ __attribute__((aligned(16))) float smain[TM * LDX];
     __shared__ __attribute__((aligned(16))) float saux[TM * LDA];     // scratch: craw [128][4]
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -113,6 +116,35 @@ __global__ __launch_bounds__(256, 2) void color_bwd_kernel(ColPtrs C, const floa
                 DH_UNROLL for (int r = 0; r < 16; ++r) {
                     const int64_t gp = tile * TM + aux_row(wave, r, lane);
                     if (gp < npts) d_normals[gp * 3 + (col - 30)] += a2[tt][r];
+                }
+            }
+        }
+        if (RAYS) {
+            // a2 columns 0..32 -> LDS (the craw scratch in saux is dead by now), then one thread per point
+            __syncthreads();
+            DH_UNROLL for (int tt = 0; tt < AUX_NTW; ++tt) {
+                const int col = aux_col(wave, tt, lane);
+                if (col < CAUX) {
+                    DH_UNROLL for (int r = 0; r < 16; ++r) saux[aux_row(wave, r, lane) * LDA + col] = a2[tt][r];
+                }
+            }
+            __syncthreads();
+            if (tid < TM) {
+                const int64_t gp = tile * TM + tid;
+                if (gp < npts) {
+                    const float* row = saux + tid * LDA;
+                    const int64_t ray = gp / n_per_ray;
+                    DH_UNROLL for (int c = 0; c < 3; ++c) {
+                        d_pts[gp * 3 + c] = row[c];
+                        const float dv = dirs[ray * 3 + c];
+                        float v = row[3 + c];
+                        DH_UNROLL for (int kf = 0; kf < 4; ++kf) {
+                            const float f = (float)(1 << kf);
+                            float sn, co; sincosf(dv * f, &sn, &co);
+                            v += f * (co * row[6 + 6 * kf + c] - sn * row[6 + 6 * kf + 3 + c]);
+                        }
+                        d_dirs_pts[gp * 3 + c] = v;
+                    }
                 }
             }
         }
@@ -329,10 +361,13 @@ __global__ __launch_bounds__(256, 2) void sdf_tangent_kernel(SdfPtrs P, const fl
 // ------------------------------------------------------------------------------------------------
 // K7b: backward chain -> zbar_l (l = 7..0), bias-gradient partials, Wbar_8[0,:] partial
 // ------------------------------------------------------------------------------------------------
+template <bool RAYS>      // RAYS (pose refinement): as sdf_bwd_s_kernel<true> below
 __global__ __launch_bounds__(256, 2) void sdf_bwd_kernel(SdfPtrs P, const float* __restrict__ d_sdf, int64_t npts,
                                                           const float* __restrict__ act, const float* __restrict__ rsave,
                                                           const float* __restrict__ featbar, float* __restrict__ zbar,
-                                                          float* __restrict__ tpart) {
+                                                          float* __restrict__ tpart, const float* __restrict__ pts,
+                                                          const float* __restrict__ d_normals, const float* __restrict__ gesave,
+                                                          float* __restrict__ d_pts) {
     __shared__ __attribute__((aligned(16))) float smain[TM * LDX];
     __shared__ __attribute__((aligned(16))) float saux[TM * LDA];     // scratch: sdfbar [128]
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -345,6 +380,8 @@ __global__ __launch_bounds__(256, 2) void sdf_bwd_kernel(SdfPtrs P, const float*
             saux[tid] = gp < npts ? d_sdf[gp] : 0.f;
         }
         f32x16 acc[MT][2];
+        f32x16 eb[AUX_NTW];
+        if (RAYS) aux_zero(eb);
         acc_load_native(acc, featbar + tile * TILE_F, wave, lane);
         tile_colsum(acc, tp + TP_SDF_B8 * 256, wave, lane);
         acc_to_lds(acc, smain, wave, lane);
@@ -399,9 +436,40 @@ __global__ __launch_bounds__(256, 2) void sdf_bwd_kernel(SdfPtrs P, const float*
                 __syncthreads();
                 acc_to_lds(acc, smain, wave, lane);
                 __syncthreads();
+                if (RAYS && l == 4) gemm_auxout(eb, smain, 32, P.rev_aux[4], wave, lane);         // skip path -> ebar
                 acc_zero(acc);
                 gemm_rows(acc, smain, LDX, 32, P.rev_main[l], wave, lane, pre);     // hbar_l = zbar_l W_l
                 if (l > 1) pre = gemm_b_prefetch(P.rev_main[l - 1], wave, lane);
+            } else if (RAYS) {
+                __syncthreads();
+                acc_to_lds(acc, smain, wave, lane);                                 // zbar_0
+                __syncthreads();
+                gemm_auxout(eb, smain, 32, P.rev_aux[0], wave, lane);               // ebar += zbar_0 W_0
+                DH_UNROLL for (int tt = 0; tt < AUX_NTW; ++tt) {
+                    const int col = aux_col(wave, tt, lane);
+                    if (col < AUXW) {
+                        DH_UNROLL for (int r = 0; r < 16; ++r) saux[aux_row(wave, r, lane) * LDA + col] = eb[tt][r];
+                    }
+                }
+                __syncthreads();
+                if (tid < TM) {
+                    const int64_t gp = tile * TM + tid;
+                    if (gp < npts) {
+                        const float* e = saux + tid * LDA;
+                        const float* ge = gesave + gp * 40;
+                        DH_UNROLL for (int c = 0; c < 3; ++c) {
+                            const float x = pts[gp * 3 + c], nb = d_normals[gp * 3 + c];
+                            float v = e[c], dn = 0.f;
+                            DH_UNROLL for (int k = 0; k < 6; ++k) {
+                                const float f = (float)(1 << k);
+                                float sn, co; sincosf(x * f, &sn, &co);
+                                v += f * (co * e[3 + 6 * k + c] - sn * e[3 + 6 * k + 3 + c]);
+                                dn -= f * f * (sn * ge[3 + 6 * k + c] + co * ge[3 + 6 * k + 3 + c]);
+                            }
+                            d_pts[gp * 3 + c] += v + nb * dn;
+                        }
+                    }
+                }
             }
         }
         __syncthreads();
@@ -613,8 +681,8 @@ static inline int grid_for(int64_t npts, int grid) {
 
 int launch_color_bwd(const float* packed, const float* colors, const float* d_colors, int64_t npts, const float* cact,
                      float* czbar, float* featbar, float* d_normals, float* tpart, int grid, hipStream_t st) {
-    if (arith_fp32()) hipLaunchKernelGGL(color_bwd_kernel, dim3(grid_for(npts, grid)), dim3(256), 0, st, make_col_ptrs(packed), colors,
-                                         d_colors, npts, cact, czbar, featbar, d_normals, tpart);
+    if (arith_fp32()) hipLaunchKernelGGL(color_bwd_kernel<false>, dim3(grid_for(npts, grid)), dim3(256), 0, st, make_col_ptrs(packed), colors,
+                                         d_colors, npts, cact, czbar, featbar, d_normals, tpart, nullptr, 1, nullptr, nullptr);
     else hipLaunchKernelGGL(color_bwd_s_kernel<false>, dim3(grid_for(npts, grid)), dim3(256), 0, st, make_col16_ptrs(packed), colors,
                             d_colors, npts, cact, czbar, featbar, d_normals, tpart, nullptr, 1, nullptr, nullptr);
     return ok();
@@ -622,9 +690,10 @@ int launch_color_bwd(const float* packed, const float* colors, const float* d_co
 int launch_color_bwd_rays(const float* packed, const float* colors, const float* d_colors, const float* dirs, int n_per_ray,
                           int64_t npts, const float* cact, float* czbar, float* featbar, float* d_normals, float* tpart,
                           float* d_pts, float* d_dirs_pts, int grid, hipStream_t st) {
-    if (arith_fp32()) return -2;          // pose refinement ships in the split-bf16 arithmetic only
-    hipLaunchKernelGGL(color_bwd_s_kernel<true>, dim3(grid_for(npts, grid)), dim3(256), 0, st, make_col16_ptrs(packed), colors,
-                       d_colors, npts, cact, czbar, featbar, d_normals, tpart, dirs, n_per_ray, d_pts, d_dirs_pts);
+    if (arith_fp32()) hipLaunchKernelGGL(color_bwd_kernel<true>, dim3(grid_for(npts, grid)), dim3(256), 0, st, make_col_ptrs(packed), colors,
+                                         d_colors, npts, cact, czbar, featbar, d_normals, tpart, dirs, n_per_ray, d_pts, d_dirs_pts);
+    else hipLaunchKernelGGL(color_bwd_s_kernel<true>, dim3(grid_for(npts, grid)), dim3(256), 0, st, make_col16_ptrs(packed), colors,
+                            d_colors, npts, cact, czbar, featbar, d_normals, tpart, dirs, n_per_ray, d_pts, d_dirs_pts);
     return ok();
 }
 int launch_sdf_tangent(const float* packed, const float* pts, const float* d_normals, int64_t npts, const float* act,
@@ -637,8 +706,8 @@ int launch_sdf_tangent(const float* packed, const float* pts, const float* d_nor
 }
 int launch_sdf_bwd(const float* packed, const float* d_sdf, int64_t npts, const float* act, const float* rsave,
                    const float* featbar, float* zbar, float* tpart, int grid, hipStream_t st) {
-    if (arith_fp32()) hipLaunchKernelGGL(sdf_bwd_kernel, dim3(grid_for(npts, grid)), dim3(256), 0, st, make_sdf_ptrs(packed), d_sdf, npts,
-                                         act, rsave, featbar, zbar, tpart);
+    if (arith_fp32()) hipLaunchKernelGGL(sdf_bwd_kernel<false>, dim3(grid_for(npts, grid)), dim3(256), 0, st, make_sdf_ptrs(packed), d_sdf, npts,
+                                         act, rsave, featbar, zbar, tpart, nullptr, nullptr, nullptr, nullptr);
     else hipLaunchKernelGGL(sdf_bwd_s_kernel<false>, dim3(grid_for(npts, grid)), dim3(256), 0, st, make_sdf16_ptrs(packed), d_sdf, npts,
                             act, rsave, featbar, zbar, tpart, nullptr, nullptr, nullptr, nullptr);
     return ok();
@@ -646,9 +715,10 @@ int launch_sdf_bwd(const float* packed, const float* d_sdf, int64_t npts, const 
 int launch_sdf_bwd_rays(const float* packed, const float* d_sdf, const float* pts, const float* d_normals, int64_t npts,
                         const float* act, const float* rsave, const float* featbar, const float* gesave, float* zbar,
                         float* tpart, float* d_pts, int grid, hipStream_t st) {
-    if (arith_fp32()) return -2;
-    hipLaunchKernelGGL(sdf_bwd_s_kernel<true>, dim3(grid_for(npts, grid)), dim3(256), 0, st, make_sdf16_ptrs(packed), d_sdf, npts, act,
-                       rsave, featbar, zbar, tpart, pts, d_normals, gesave, d_pts);
+    if (arith_fp32()) hipLaunchKernelGGL(sdf_bwd_kernel<true>, dim3(grid_for(npts, grid)), dim3(256), 0, st, make_sdf_ptrs(packed), d_sdf, npts,
+                                         act, rsave, featbar, zbar, tpart, pts, d_normals, gesave, d_pts);
+    else hipLaunchKernelGGL(sdf_bwd_s_kernel<true>, dim3(grid_for(npts, grid)), dim3(256), 0, st, make_sdf16_ptrs(packed), d_sdf, npts, act,
+                            rsave, featbar, zbar, tpart, pts, d_normals, gesave, d_pts);
     return ok();
 }
 

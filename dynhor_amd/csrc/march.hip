@@ -53,6 +53,7 @@ __global__ __launch_bounds__(256) void march_kernel(const float* __restrict__ ra
                                                     const float* __restrict__ u, const uint8_t* __restrict__ occ, int res,
                                                     float inv2r, float step, float half_step, int max_samples, int64_t B,
                                                     int32_t* __restrict__ cnt, const int64_t* __restrict__ off,
+                                                    const int32_t* __restrict__ keep,
                                                     float* __restrict__ t_start, float* __restrict__ pts,
                                                     float* __restrict__ dirs_pts, int32_t* __restrict__ ray_idx) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -65,6 +66,7 @@ __global__ __launch_bounds__(256) void march_kernel(const float* __restrict__ ra
     // steps can only qualify while t_k + step <= far: an upper bound on k (one spare trip covers fp32 rounding)
     const int kmax = (int)ceilf((r.far - r.near) / step) + 1;
     const int64_t base = EMIT ? off[ray] : 0;
+    if (EMIT && keep) { const int kp = keep[ray]; max_samples = kp < max_samples ? (kp < 0 ? 0 : kp) : max_samples; }   // wave-uniform
     int c = 0;
     for (int k0 = 0; k0 < kmax && c < max_samples; k0 += 64) {
         float t0, x[3];
@@ -89,14 +91,15 @@ int launch_march_count(const float* o, const float* d, const float* near, const 
                        int res, float radius, float step, float half_step, int max_samples, int64_t B, int32_t* cnt,
                        hipStream_t st) {
     hipLaunchKernelGGL(march_kernel<false>, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, st, o, d, near, far, u, occ, res,
-                       (float)(0.5 / (double)radius), step, half_step, max_samples, B, cnt, nullptr, nullptr, nullptr, nullptr, nullptr);
+                       (float)(0.5 / (double)radius), step, half_step, max_samples, B, cnt, nullptr, nullptr, nullptr, nullptr, nullptr,
+                       nullptr);
     return ok();
 }
 int launch_march_emit(const float* o, const float* d, const float* near, const float* far, const float* u, const uint8_t* occ,
                       int res, float radius, float step, float half_step, int max_samples, int64_t B, const int64_t* off,
-                      float* t_start, float* pts, float* dirs_pts, int32_t* ray_idx, hipStream_t st) {
+                      const int32_t* keep, float* t_start, float* pts, float* dirs_pts, int32_t* ray_idx, hipStream_t st) {
     hipLaunchKernelGGL(march_kernel<true>, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, st, o, d, near, far, u, occ, res,
-                       (float)(0.5 / (double)radius), step, half_step, max_samples, B, nullptr, off, t_start, pts, dirs_pts, ray_idx);
+                       (float)(0.5 / (double)radius), step, half_step, max_samples, B, nullptr, off, keep, t_start, pts, dirs_pts, ray_idx);
     return ok();
 }
 

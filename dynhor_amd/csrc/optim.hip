@@ -106,7 +106,8 @@ __global__ __launch_bounds__(1024) void corr_loss_kernel(const float* __restrict
                                                          const float* __restrict__ T_all, int n_frames,
                                                          const float* __restrict__ K, int64_t B, int n, float sample_dist,
                                                          float delta_px, float corr_w, float* __restrict__ stats,
-                                                         float* __restrict__ residual_px, float* __restrict__ d_weights) {
+                                                         float* __restrict__ residual_px, float* __restrict__ d_weights,
+                                                         float* __restrict__ pose_adj) {
     __shared__ float s_red[16];
     const int tid = threadIdx.x;
     const float fx = K[0], fy = K[4], cx = K[2], cy = K[5];
@@ -114,8 +115,14 @@ __global__ __launch_bounds__(1024) void corr_loss_kernel(const float* __restrict
     float a_cv = 0.f, a_l = 0.f, a_r = 0.f;
     for (int64_t b = tid; b < B; b += blockDim.x) {
         const float conf = corr[b * 4 + 2];
-        float dt = 0.f, res = 0.f;
+        float dt = 0.f;
+        // a match that cannot be evaluated (no partner frame, point behind the partner camera) is a GROSS failure, not a perfect
+        // one: its residual is +inf so that the outlier vote counts it against its frame pair; certainty-0 rays
+        // (no match at all) report 0
+        float res = 0.f;
+        float dy[3] = {0.f, 0.f, 0.f}, dx[3] = {0.f, 0.f, 0.f}, depth_out = 0.f;
         const int j = (int)corr[b * 4 + 3];
+        if (conf > 0.f) res = __builtin_inff();
         if (conf > 0.f && j >= 0 && j < n_frames) {
             float depth = 0.f;
             const float* zr = z + b * n;
@@ -144,10 +151,23 @@ __global__ __launch_bounds__(1024) void corr_loss_kernel(const float* __restrict
                 const float drho = sres <= delta ? ep / (fx * fx * delta) : ep / (en * fx);
                 a_cv += conf; a_l += conf * rho; a_r += conf * en;
                 dt = conf * drho;
+                if (pose_adj) {
+                    // d rho / d y (y = R_j x + T_j): kappa (eu d pu + ev d pv); d rho / d x = R_j^T (d rho / d y)
+                    const float kappa = conf * (sres <= delta ? 1.f / (fx * fx * delta) : 1.f / (en * fx));
+                    dy[0] = kappa * eu * fx * iz;
+                    dy[1] = kappa * ev * fy * iz;
+                    dy[2] = -kappa * (eu * fx * y[0] + ev * fy * y[1]) * iz * iz;
+                    DH_UNROLL for (int c = 0; c < 3; ++c) dx[c] = Rj[c] * dy[0] + Rj[3 + c] * dy[1] + Rj[6 + c] * dy[2];
+                }
             }
+            depth_out = depth;
         }
         residual_px[b] = res;
         d_weights[b * n] = dt;          // parked in the ray's first slot until the normaliser is known
+        if (pose_adj) {                 // [B,7] = d_x(3), d_y(3), t^ ; un-normalised until the second pass
+            float* pa = pose_adj + b * 7;
+            pa[0] = dx[0]; pa[1] = dx[1]; pa[2] = dx[2]; pa[3] = dy[0]; pa[4] = dy[1]; pa[5] = dy[2]; pa[6] = depth_out;
+        }
     }
     const float cv = block_sum(a_cv, s_red), ls = block_sum(a_l, s_red), rs = block_sum(a_r, s_red);
     const float inv = corr_w / (cv + 1e-5f);
@@ -166,6 +186,8 @@ __global__ __launch_bounds__(1024) void corr_loss_kernel(const float* __restrict
         }
         __syncthreads();
     }
+    if (pose_adj)
+        for (int64_t e = tid; e < B * 7; e += blockDim.x) if (e % 7 != 6) pose_adj[e] *= inv;
     if (tid == 0) {
         stats[0] = ls / (cv + 1e-5f);            // L_corr (unweighted)
         stats[1] = cv;                           // sum of certainties of the valid matches
@@ -184,9 +206,10 @@ int launch_loss(const float* color, const float* wsum, const float* nmap, const 
 
 int launch_corr_loss(const float* rays_o, const float* rays_d, const float* z, const float* weights, const float* corr,
                      const float* R_all, const float* T_all, int n_frames, const float* K, int64_t B, int n, float sample_dist,
-                     float delta_px, float corr_w, float* stats, float* residual_px, float* d_weights, hipStream_t st) {
+                     float delta_px, float corr_w, float* stats, float* residual_px, float* d_weights, float* pose_adj,
+                     hipStream_t st) {
     hipLaunchKernelGGL(corr_loss_kernel, dim3(1), dim3(1024), 0, st, rays_o, rays_d, z, weights, corr, R_all, T_all, n_frames, K, B, n,
-                       sample_dist, delta_px, corr_w, stats, residual_px, d_weights);
+                       sample_dist, delta_px, corr_w, stats, residual_px, d_weights, pose_adj);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 

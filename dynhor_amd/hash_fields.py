@@ -108,6 +108,7 @@ class OccupancyGrid:
         self.device = torch.device(device)
         self.occ = torch.zeros(self.res ** 3, device=self.device)
         self.binary = torch.ones(self.res ** 3, dtype=torch.uint8, device=self.device)       # all occupied until the first update
+        self.updates = 0
         ax = torch.arange(self.res, device=self.device, dtype=torch.float32)
         ix, iy, iz = torch.meshgrid(ax, ax, ax, indexing="ij")
         self._idx = torch.stack([ix, iy, iz], -1).reshape(-1, 3)
@@ -125,7 +126,19 @@ class OccupancyGrid:
         alpha = ((prev - nxt + 1e-5) / (prev + 1e-5)).clip(0.0, 1.0)
         self.occ = torch.maximum(self.occ * self.decay, alpha)
         self.binary = (self.occ > torch.clamp(self.occ.mean(), max=self.thre)).to(torch.uint8).contiguous()
+        self.updates += 1
+
+    def occupied_fraction(self) -> float:
+        """Share of occupied cells (a device -> host read: diagnostics only, never on the training path)."""
         return float(self.binary.float().mean())
+
+    def state_dict(self):
+        return {"occ": self.occ.clone(), "updates": self.updates}
+
+    def load_state_dict(self, sd):
+        self.occ = sd["occ"].to(self.device, torch.float32).reshape(-1).clone()
+        self.updates = int(sd["updates"])
+        self.binary = (self.occ > torch.clamp(self.occ.mean(), max=self.thre)).to(torch.uint8).contiguous()
 
 
 class HashNeuSRenderer(NeuSRenderer):
@@ -137,24 +150,32 @@ class HashNeuSRenderer(NeuSRenderer):
 
     def __init__(self, nerf, sdf_network: HashSDFNetwork, deviation_network: SingleVarianceNetwork,
                  color_network: SHRenderingNetwork, *args, sampler="hierarchical", march_samples_per_ray=512, grid_res=128,
-                 grid_update_every=16, max_samples=128, **kwargs):
+                 grid_update_every=16, max_samples=128, max_samples_per_ray=1024, **kwargs):
         if not isinstance(sdf_network, HashSDFNetwork) or not isinstance(color_network, SHRenderingNetwork):
             raise TypeError("HashNeuSRenderer needs HashSDFNetwork + SHRenderingNetwork")
         if sampler not in ("hierarchical", "occgrid"):
             raise ValueError("sampler must be 'hierarchical' or 'occgrid'")
-        if not 0 < max_samples <= 1024:
-            raise ValueError("the packed render scan handles at most 1024 samples per ray")
+        if not 0 < max_samples <= 1024 or not max_samples <= max_samples_per_ray <= 1024:
+            raise ValueError("the packed render scan handles at most 1024 samples per ray (max_samples <= max_samples_per_ray <= 1024)")
         super().__init__(nerf, sdf_network, deviation_network, color_network, *args, **kwargs)
         self.radius = sdf_network.radius
         self.fd_eps = sdf_network.fd_eps
         self.sampler = sampler
+        # packed-ray budget: the sample buffers of a batch of B rays hold B * max_samples samples (a fixed capacity, so nothing on
+        # the training path waits for a device -> host read of the count); a single ray may keep up to max_samples_per_ray of
+        # them.  The per-ray cap of an iteration is the largest of (1024, 512, 256, 128, ..., max_samples) <= max_samples_per_ray
+        # whose total fits the capacity -- chosen on the device; max_samples itself always fits.
         self.max_samples = int(max_samples)
+        self.max_samples_per_ray = int(max_samples_per_ray)
+        self._cap_ladder = sorted({c for c in (1024, 512, 256, 128, 64, 32) if self.max_samples < c <= self.max_samples_per_ray}
+                                  | {self.max_samples}, reverse=True)
+        self._packed_buf = {}
         # instant-nsr-pl: render_step_size = 1.732 * 2 * radius / num_samples_per_ray
         self.march_step = 1.732 * 2.0 * self.radius / float(march_samples_per_ray)
         self.grid_update_every = int(grid_update_every)
         self.grid = OccupancyGrid(grid_res, self.radius, device=self.store.device) if sampler == "occgrid" else None
         self._march_iter = 0
-        self.last_march = None
+        self._last_march = None
 
     def _make_store(self, sdf_network, deviation_network, color_network, device):
         return HashParamStore(sdf_network, deviation_network, color_network, device)
@@ -175,56 +196,75 @@ class HashNeuSRenderer(NeuSRenderer):
         P = s.B * s.n
         s.feat = torch.empty(P, 13, device=s.pts.device)
         T("hash_geo_forward", L.dh_hash_geo_forward, _p(st.flat), _p(packed), _p(s.pts), P, self.radius, self.fd_eps,
-          _p(s.ws), 0 if s.infer_only else 1, _p(s.sdf), _p(s.feat), _p(s.normals), _lib.stream())
+          _p(s.ws), 0 if s.infer_only else 1, _p(s.sdf), _p(s.feat), _p(s.normals), _NULLP, _lib.stream())
         T("hash_color_forward", L.dh_hash_color_forward, _p(packed), _p(s.feat), _p(s.normals), _p(s.rays_d), s.n, P,
-          _p(s.colors), _lib.stream())
+          _p(s.colors), _NULLP, _lib.stream())
 
     def _net_backward(self, s, d_sdf, d_normals, d_colors, grad):
         L, T, st = _lib.lib(), self.timer, self.store
         P = s.B * s.n
         d_feat = torch.empty(P, 13, device=s.pts.device)
         T("hash_color_backward", L.dh_hash_color_backward, _p(st.packed), _p(s.feat), _p(s.normals), _p(s.rays_d),
-          _p(d_colors), s.n, P, _p(s.ws), _p(d_feat), _p(d_normals), _lib.stream())
+          _p(d_colors), s.n, P, _p(s.ws), _p(d_feat), _p(d_normals), _NULLP, _lib.stream())
         T("hash_geo_backward", L.dh_hash_geo_backward, _p(st.flat), _p(st.packed), _p(s.pts), _p(d_sdf), _p(d_feat),
-          _p(d_normals), P, self.radius, self.fd_eps, _p(s.ws), _lib.stream())
-        T("hash_weight_grads", L.dh_hash_weight_grads, _p(st.flat), _p(st.packed), P, _p(s.ws), _p(grad), _lib.stream())
+          _p(d_normals), P, self.radius, self.fd_eps, _p(s.ws), _NULLP, _lib.stream())
+        T("hash_weight_grads", L.dh_hash_weight_grads, _p(st.flat), _p(st.packed), P, _p(s.ws), _p(grad), _NULLP, _lib.stream())
 
 
     # ------------------------------------------------------------------ occupancy-grid marching path (packed rays)
     @torch.no_grad()
     def update_grid(self, generator=None, jitter=None):
         self.store.ensure_packed()
-        return self.grid.update(lambda p: self.sdf(p), self.store.inv_s(), self.march_step, generator=generator, jitter=jitter)
+        self.grid.update(lambda p: self.sdf(p), self.store.inv_s(), self.march_step, generator=generator, jitter=jitter)
+
+    def _buffers(self, B: int):
+        """Sample buffers of a batch of B rays at the fixed capacity B * max_samples (rounded to 8 rows), allocated once."""
+        buf = self._packed_buf.get(B)
+        if buf is None:
+            from types import SimpleNamespace
+            dev = self.store.device
+            cap = (B * self.max_samples + 7) // 8 * 8
+            z = lambda *shape, dt=torch.float32: torch.zeros(*shape, dtype=dt, device=dev)
+            buf = SimpleNamespace(cap=cap, cnt_raw=z(B, dt=torch.int32), t_start=z(cap), pts=z(cap, 3), dirs=z(cap, 3),
+                                  ray_idx=z(cap, dt=torch.int32), sdf=z(cap), normals=z(cap, 3), colors=z(cap, 3), feat=z(cap, 13),
+                                  weights=z(cap), cdf=z(cap), inside=z(cap), d_sdf=z(cap), d_normals=z(cap, 3), d_colors=z(cap, 3),
+                                  d_feat=z(cap, 13), caps=torch.tensor(self._cap_ladder, dtype=torch.int32, device=dev))
+            if len(self._packed_buf) >= 3:       # training batch, validation chunk, one more: the oldest goes
+                self._packed_buf.pop(next(iter(self._packed_buf)))
+            self._packed_buf[B] = buf
+        return buf
 
     @torch.no_grad()
     def march(self, rays_o, rays_d, near, far, u):
-        """Packed samples of the rays: SimpleNamespace(N, off [B] i64, cnt [B] i32, t_start [N], pts [N,3], dirs [N,3],
-        ray_idx [N]).  One device->host read of the total count (the downstream launches are sized by it)."""
+        """Packed samples of the rays: SimpleNamespace(cap, n_dev [1] i64 (device), off [B] i64, cnt [B] i32, cap_dev (the per-ray
+        cap chosen, device), t_start / pts / dirs / ray_idx at the capacity).  NO device -> host read: the count stays on the
+        device and every later stage takes it as `n_active`."""
         from types import SimpleNamespace
         L = _lib.lib()
         B = rays_o.shape[0]
-        dev = rays_o.device
+        buf = self._buffers(B)
         near = near.contiguous().view(-1); far = far.contiguous().view(-1)
         u = None if u is None else u.contiguous().view(-1)
         step = float(torch.tensor(self.march_step, dtype=torch.float32))
         half = float(torch.tensor(0.5 * self.march_step, dtype=torch.float32))
-        cnt = torch.empty(B, dtype=torch.int32, device=dev)
         g = self.grid
+        top = self._cap_ladder[0]
         _lib.check(L.dh_march_count(_p(rays_o), _p(rays_d), _p(near), _p(far), _p(u), _p(g.binary), g.res, g.radius, step, half,
-                                    self.max_samples, B, _p(cnt), _lib.stream()))
+                                    top, B, _p(buf.cnt_raw), _lib.stream()))
+        # the largest per-ray cap of the ladder whose total fits the capacity (its last rung, max_samples, always does)
+        totals = torch.minimum(buf.cnt_raw[None, :], buf.caps[:, None]).sum(dim=1, dtype=torch.int64)       # [len(ladder)]
+        fits = totals <= buf.cap
+        first = torch.argmax(fits.to(torch.int8)).view(1)                                                    # first rung that fits
+        cap_dev = buf.caps.gather(0, first).view(())     # (indexing with a 0-dim tensor would read it back to the host)
+        cnt = torch.minimum(buf.cnt_raw, cap_dev).contiguous()
         csum = torch.cumsum(cnt, 0, dtype=torch.int64)
         off = (csum - cnt).contiguous()
-        N = int(csum[-1].item())
-        m = SimpleNamespace(N=N, off=off, cnt=cnt, step=step)
-        m.t_start = torch.empty(max(N, 1), device=dev)
-        m.pts = torch.empty(max(N, 1), 3, device=dev)
-        m.dirs = torch.empty(max(N, 1), 3, device=dev)
-        m.ray_idx = torch.empty(max(N, 1), dtype=torch.int32, device=dev)
-        if N > 0:
-            _lib.check(L.dh_march_emit(_p(rays_o), _p(rays_d), _p(near), _p(far), _p(u), _p(g.binary), g.res, g.radius, step, half,
-                                       self.max_samples, B, _p(off), _p(m.t_start), _p(m.pts), _p(m.dirs), _p(m.ray_idx),
-                                       _lib.stream()))
-        return m
+        n_dev = csum[-1:].contiguous()
+        _lib.check(L.dh_march_emit(_p(rays_o), _p(rays_d), _p(near), _p(far), _p(u), _p(g.binary), g.res, g.radius, step, half,
+                                   top, B, _p(off), _p(cnt), _p(buf.t_start), _p(buf.pts), _p(buf.dirs), _p(buf.ray_idx),
+                                   _lib.stream()))
+        return SimpleNamespace(cap=buf.cap, n_dev=n_dev, off=off, cnt=cnt, cnt_raw=buf.cnt_raw, cap_dev=cap_dev, step=step,
+                               t_start=buf.t_start, pts=buf.pts, dirs=buf.dirs, ray_idx=buf.ray_idx, buf=buf)
 
     @torch.no_grad()
     def _forward_packed(self, rays_o, rays_d, m, cos_anneal_ratio, background_rgb, want_nmap, infer_only=False):
@@ -232,22 +272,19 @@ class HashNeuSRenderer(NeuSRenderer):
         L, T, st = _lib.lib(), self.timer, self.store
         packed = st.ensure_packed()
         dev = rays_o.device
-        B, N = rays_o.shape[0], m.N
-        s = SimpleNamespace(B=B, N=N, m=m, car=float(cos_anneal_ratio), bg=background_rgb, rays_o=rays_o, rays_d=rays_d,
+        B, P, buf = rays_o.shape[0], m.cap, m.buf
+        s = SimpleNamespace(B=B, m=m, car=float(cos_anneal_ratio), bg=background_rgb, rays_o=rays_o, rays_d=rays_d,
                             infer_only=infer_only)
-        P = max(N, 1)
         s.ws = self._workspace(P, infer_only)
         self._ws_token += 1
         s.ws_token = self._ws_token
-        s.sdf = torch.zeros(P, device=dev); s.normals = torch.zeros(P, 3, device=dev); s.colors = torch.zeros(P, 3, device=dev)
-        s.feat = torch.zeros(P, 13, device=dev)
-        if N > 0:
-            T("hash_geo_forward", L.dh_hash_geo_forward, _p(st.flat), _p(packed), _p(m.pts), N, self.radius, self.fd_eps,
-              _p(s.ws), 0 if infer_only else 1, _p(s.sdf), _p(s.feat), _p(s.normals), _lib.stream())
-            T("hash_color_forward", L.dh_hash_color_forward, _p(packed), _p(s.feat), _p(s.normals), _p(m.dirs), 1, N,
-              _p(s.colors), _lib.stream())
+        s.sdf, s.normals, s.colors, s.feat = buf.sdf, buf.normals, buf.colors, buf.feat
+        T("hash_geo_forward", L.dh_hash_geo_forward, _p(st.flat), _p(packed), _p(m.pts), P, self.radius, self.fd_eps,
+          _p(s.ws), 0 if infer_only else 1, _p(s.sdf), _p(s.feat), _p(s.normals), _p(m.n_dev), _lib.stream())
+        T("hash_color_forward", L.dh_hash_color_forward, _p(packed), _p(s.feat), _p(s.normals), _p(m.dirs), 1, P,
+          _p(s.colors), _p(m.n_dev), _lib.stream())
         s.inv_s = st.inv_s()
-        s.weights = torch.empty(P, device=dev); s.cdf = torch.empty(P, device=dev); s.inside = torch.empty(P, device=dev)
+        s.weights, s.cdf, s.inside = buf.weights, buf.cdf, buf.inside
         s.color = torch.empty(B, 3, device=dev); s.wsum = torch.empty(B, 1, device=dev); s.wmax = torch.empty(B, 1, device=dev)
         s.eik = torch.empty(B, 2, device=dev)
         s.nmap = torch.empty(B, 3, device=dev) if want_nmap else None
@@ -262,23 +299,20 @@ class HashNeuSRenderer(NeuSRenderer):
         L, T, st = _lib.lib(), self.timer, self.store
         if s.ws_token != self._ws_token:
             raise RuntimeError("workspace was overwritten by a later render before backward()")
-        m, B, N = s.m, s.B, s.N
+        m, B, P, buf = s.m, s.B, s.m.cap, s.m.buf
         dev = s.color.device
-        P = max(N, 1)
-        d_sdf = torch.zeros(P, device=dev); d_normals = torch.zeros(P, 3, device=dev); d_colors = torch.zeros(P, 3, device=dev)
+        d_sdf, d_normals, d_colors, d_feat = buf.d_sdf.zero_(), buf.d_normals.zero_(), buf.d_colors.zero_(), buf.d_feat
         d_inv_s = torch.empty(B, device=dev)
         _lib.check(L.dh_render_scan_bwd_packed(_p(s.rays_o), _p(s.rays_d), _p(m.t_start), _p(s.sdf), _p(s.normals), _p(s.colors),
                                                _p(s.inv_s), s.car, m.step, _p(s.bg), B, _p(m.off), _p(m.cnt), _p(d_color),
                                                _p(d_wsum), _NULLP, _NULLP, _p(d_nmap), _p(eik_coef), _p(d_sdf), _p(d_normals),
                                                _p(d_colors), _p(d_inv_s), _lib.stream()))
-        grad = st.grad_bucket().zero_()
-        if N > 0:
-            d_feat = torch.empty(N, 13, device=dev)
-            T("hash_color_backward", L.dh_hash_color_backward, _p(st.packed), _p(s.feat), _p(s.normals), _p(m.dirs), _p(d_colors),
-              1, N, _p(s.ws), _p(d_feat), _p(d_normals), _lib.stream())
-            T("hash_geo_backward", L.dh_hash_geo_backward, _p(st.flat), _p(st.packed), _p(m.pts), _p(d_sdf), _p(d_feat),
-              _p(d_normals), N, self.radius, self.fd_eps, _p(s.ws), _lib.stream())
-            T("hash_weight_grads", L.dh_hash_weight_grads, _p(st.flat), _p(st.packed), N, _p(s.ws), _p(grad), _lib.stream())
+        grad = st.grad_bucket()
+        T("hash_color_backward", L.dh_hash_color_backward, _p(st.packed), _p(s.feat), _p(s.normals), _p(m.dirs), _p(d_colors),
+          1, P, _p(s.ws), _p(d_feat), _p(d_normals), _p(m.n_dev), _lib.stream())
+        T("hash_geo_backward", L.dh_hash_geo_backward, _p(st.flat), _p(st.packed), _p(m.pts), _p(d_sdf), _p(d_feat),
+          _p(d_normals), P, self.radius, self.fd_eps, _p(s.ws), _p(m.n_dev), _lib.stream())
+        T("hash_weight_grads", L.dh_hash_weight_grads, _p(st.flat), _p(st.packed), P, _p(s.ws), _p(grad), _p(m.n_dev), _lib.stream())
         raw = torch.exp(st.flat[st.var_off] * 10.0)
         passthrough = ((raw >= 1e-6) & (raw <= 1e6)).float()
         grad[st.var_off] = d_inv_s.sum() * 10.0 * raw * passthrough
@@ -315,8 +349,18 @@ class HashNeuSRenderer(NeuSRenderer):
                                   _p(eik_coef), _lib.stream()))
         self._backward_packed(s, d_color, d_wsum, d_nmap, eik_coef)
         self.last_state = s
-        self.last_march = {"samples": m.N, "samples_per_ray": m.N / max(B, 1), "rays_at_cap": int((m.cnt >= self.max_samples).sum())}
+        self._last_march = m
         return stats
+
+    @property
+    def last_march(self):
+        """Statistics of the last marched batch (device -> host reads: call it when reporting, not per iteration)."""
+        m = getattr(self, "_last_march", None)
+        if m is None:
+            return None
+        n, B, cap = int(m.n_dev), int(m.cnt.shape[0]), int(m.cap_dev)
+        return {"samples": n, "samples_per_ray": n / max(B, 1), "capacity": int(m.cap), "per_ray_cap": cap,
+                "rays_at_cap": int((m.cnt_raw >= cap).sum()), "rays_truncated": int((m.cnt_raw > m.cnt).sum())}
 
     @torch.no_grad()
     def render_rays(self, rays_o, rays_d, near, far, cos_anneal_ratio, background_rgb=None, want_nmap=True):
@@ -325,9 +369,21 @@ class HashNeuSRenderer(NeuSRenderer):
             z = self.sample_z(rays_o, rays_d, near, far, perturb_overwrite=0)
             st = self._forward_core(rays_o, rays_d, z, cos_anneal_ratio, background_rgb, want_nmap=want_nmap, infer_only=True)
             return st.color, st.nmap
+        if self.grid.updates == 0:          # a validate-only / mesh run after load_checkpoint: never march through the all-ones grid
+            self.update_grid()
         m = self.march(rays_o, rays_d, near, far, None)
         st = self._forward_packed(rays_o, rays_d, m, cos_anneal_ratio, background_rgb, want_nmap, infer_only=True)
         return st.color, st.nmap
+
+    # occupancy-grid state rides in the checkpoint (Runner adds it under `dynhor_occgrid`): a resumed run keeps the decayed-max
+    # history instead of restarting it, a validate-only run marches through the trained grid
+    def sampler_state_dict(self):
+        return None if self.grid is None else {"grid": self.grid.state_dict(), "march_iter": self._march_iter}
+
+    def load_sampler_state_dict(self, sd):
+        if sd is not None and self.grid is not None:
+            self.grid.load_state_dict(sd["grid"])
+            self._march_iter = int(sd["march_iter"])
 
 
 def build_hash_models(seed=1234, device="cuda"):

@@ -42,14 +42,18 @@ class PoseRefiner(torch.nn.Module):
         o = (-(T @ R)).expand_as(d)
         return o, d, R
 
-    def step(self, o, d, R, d_rays_o, d_rays_d, d_R=None, grad_scale=1.0, allreduce=None):
+    def step(self, o, d, R, d_rays_o, d_rays_d, d_R=None, grad_scale=1.0, allreduce=None, partner=None):
         """Chain the HIP path's per-ray adjoints into the pose parameters and take one Adam step.  `allreduce` (data-parallel
         runs): called on each parameter gradient before the step -- every rank trains a different frame, the sum gives all
-        ranks the same pose update (two tiny [F,3,2] / [F,3] buffers)."""
+        ranks the same pose update (two tiny [F,3,2] / [F,3] buffers).  partner = (d_R_all [F,3,3], d_T_all [F,3]): the
+        correspondence term's gradient w.r.t. EVERY frame's saved pose (it projects into partner frames)."""
         self.opt.zero_grad(set_to_none=True)
         outs, grads = [o, d], [d_rays_o, d_rays_d]
         if d_R is not None:
             outs.append(R); grads.append(d_R)
+        if partner is not None:
+            R_all, T_all = self.poses()
+            outs += [R_all, T_all]; grads += [partner[0], partner[1].reshape(T_all.shape)]
         torch.autograd.backward(outs, grads)
         for p in (self.rot6d, self.trans):
             if allreduce is not None:

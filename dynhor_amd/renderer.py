@@ -61,6 +61,8 @@ class _RenderCoreFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, renderer, rays_o, rays_d, z_vals, cos_anneal_ratio, background_rgb, *params):
         s = renderer._forward_core(rays_o, rays_d, z_vals, cos_anneal_ratio, background_rgb, want_nmap=False)
+        s.eik_sum = s.eik.sum(dim=0)              # the dict API's gradient_error; the fused step's loss kernel reads s.eik itself
+        s.gradient_error = s.eik_sum[0] / (s.eik_sum[1] + 1e-5)
         ctx.set_materialize_grads(False)
         ctx.state = s
         ctx.renderer = renderer
@@ -269,8 +271,6 @@ class NeuSRenderer:
                                         _p(s.inv_s), s.car, s.sample_dist, _p(background_rgb), B, n, _p(s.weights),
                                         _p(s.color), _p(s.wsum), _p(s.wmax), _p(s.cdf), _p(s.inside), _p(s.eik),
                                         _p(s.nmap), _lib.stream()))
-        s.eik_sum = s.eik.sum(dim=0)
-        s.gradient_error = s.eik_sum[0] / (s.eik_sum[1] + 1e-5)
         return s
 
     @torch.no_grad()
@@ -365,7 +365,9 @@ class NeuSRenderer:
         corr_frames = (R_all [F,3,3], T_all [F,3], K [3,3]) adds corr_weight * the dense-correspondence reprojection loss
         (dh_corr_loss); its statistics land in self.last_corr_stats [4] and self.last_corr_residual_px [B].
         ray_grads (pose refinement): additionally leaves d loss / d rays_o, d loss / d rays_d [B,3] (sample depths constant)
-        and the normal loss's direct gradient w.r.t. R in self.last_ray_grads = (d_rays_o, d_rays_d, d_R or None)."""
+        and the normal loss's direct gradient w.r.t. R in self.last_ray_grads = (d_rays_o, d_rays_d, d_R or None); with the
+        correspondence term active as well, self.last_partner_pose_grads = (d_R_all [F,3,3], d_T_all [F,3]) holds its gradient
+        w.r.t. the partner frames' poses (None otherwise)."""
         L = _lib.lib()
         dev = rays.device
         B = rays.shape[0]
@@ -389,10 +391,11 @@ class NeuSRenderer:
             cstats = torch.empty(4, device=dev)
             resid = torch.empty(B, device=dev)
             d_weights = torch.empty(B, s.n, device=dev)
+            pose_adj = torch.empty(B, 7, device=dev) if ray_grads else None
             _lib.check(L.dh_corr_loss(_p(rays_o), _p(rays_d), _p(z_vals), _p(s.weights), _p(corr.contiguous()),
                                       _p(R_all.contiguous()), _p(T_all.contiguous()), int(R_all.shape[0]), _p(K.contiguous()),
                                       B, s.n, s.sample_dist, float(corr_delta_px), float(corr_weight), _p(cstats), _p(resid),
-                                      _p(d_weights), _lib.stream()))
+                                      _p(d_weights), _p(pose_adj), _lib.stream()))
             stats[0] += cstats[3]
             self.last_corr_stats, self.last_corr_residual_px = cstats, resid
         self._backward_core(s, d_color, d_wsum, d_weights, None, d_nmap, eik_coef, persistent=True)
@@ -402,5 +405,18 @@ class NeuSRenderer:
             if normal_weight > 0.0 and Rc is not None:
                 # n_cam = R n_obj enters the normal loss directly: d loss / d R = sum_b (R d_nmap_b) nmap_b^T  (d_nmap = R^T d n_cam)
                 d_R = (d_nmap @ Rc.T).T @ s.nmap
+            self.last_partner_pose_grads = None
+            if corr is not None and corr_weight > 0.0:
+                # the correspondence term also depends on the rays DIRECTLY (x = o + t^ d at fixed t^) and on the partner
+                # frames' poses (y = R_j x + T_j); dh_corr_loss returns those adjoints per ray (without them the pose
+                # gradient of the combined configuration was incomplete)
+                d_x, d_y, t_hat = pose_adj[:, 0:3], pose_adj[:, 3:6], pose_adj[:, 6:7]
+                s.d_rays_o = s.d_rays_o + d_x
+                s.d_rays_d = s.d_rays_d + t_hat * d_x
+                x = rays_o + t_hat * rays_d
+                j = corr[:, 3].long().clamp(0, R_all.shape[0] - 1)
+                d_R_all = torch.zeros_like(R_all).index_add_(0, j, d_y[:, :, None] * x[:, None, :])
+                d_T_all = torch.zeros_like(T_all).index_add_(0, j, d_y)
+                self.last_partner_pose_grads = (d_R_all, d_T_all)
             self.last_ray_grads = (s.d_rays_o, s.d_rays_d, d_R)
         return stats

@@ -179,7 +179,8 @@ class Runner:
             o, d, Rf = self.pose_refiner.rays(frame, px, py, self.dataset.Kinv)
             d_o, d_d, d_R = self.renderer.last_ray_grads
             self.pose_refiner.step(o, d, Rf, d_o, d_d, d_R, grad_scale=1.0 / self.world,
-                                   allreduce=dh_dist.allreduce_sum_ if self.world > 1 else None)
+                                   allreduce=dh_dist.allreduce_sum_ if self.world > 1 else None,
+                                   partner=getattr(self.renderer, "last_partner_pose_grads", None))
             with torch.no_grad():
                 Rn, Tn = self.pose_refiner.poses()
                 self.dataset.R.copy_(Rn); self.dataset.T.copy_(Tn)
@@ -255,8 +256,9 @@ class Runner:
                 dw = torch.empty(B, st.n, device=self.device)
                 _lib.check(_lib.lib().dh_corr_loss(_p(o), _p(d), _p(z), _p(st.weights), _p(corr), _p(R_all), _p(T_all),
                                                   int(R_all.shape[0]), _p(K), B, st.n, st.sample_dist, float(self.corr_delta_px), 1.0,
-                                                  _p(cst), _p(r), _p(dw), _lib.stream()))
-                # rays that render (almost) nothing have no surface estimate yet: leave them un-voted
+                                                  _p(cst), _p(r), _p(dw), None, _lib.stream()))
+                # rays that render (almost) nothing have no surface estimate yet: leave them un-voted (NaN); a match whose point
+                # lands behind the partner camera comes back +inf and votes as an outlier
                 res[s0:s0 + B] = torch.where(st.wsum.view(-1) > 0.5, r, torch.full_like(r, float("nan")))
         self.last_vote = ds.vote_correspondences(res, tau_px=self.corr_vote_tau_px)
         return self.last_vote
@@ -273,6 +275,9 @@ class Runner:
                              "rank": self.rank, "world": self.world}}
         if self.pose_refiner is not None:
             ck["pose_refiner"] = {"model": self.pose_refiner.state_dict(), "optimizer": self.pose_refiner.opt.state_dict()}
+        occ = getattr(self.renderer, "sampler_state_dict", lambda: None)()
+        if occ is not None:
+            ck["dynhor_occgrid"] = occ
         d = os.path.join(self.base_exp_dir, "checkpoints")
         os.makedirs(d, exist_ok=True)
         path = os.path.join(d, "ckpt_{:0>6d}.pth".format(self.iter_step))
@@ -300,6 +305,8 @@ class Runner:
             with torch.no_grad():
                 Rn, Tn = self.pose_refiner.poses()
                 self.dataset.R.copy_(Rn); self.dataset.T.copy_(Tn)
+        if "dynhor_occgrid" in ck and hasattr(self.renderer, "load_sampler_state_dict"):
+            self.renderer.load_sampler_state_dict(ck["dynhor_occgrid"])
         rng = ck.get("dynhor_rng")
         if rng is not None:
             self.frame_perm.load_state_dict(rng["frame_perm"])

@@ -102,7 +102,7 @@ int dh_sdf_backward(const float* packed, const float* d_sdf, int64_t npts, float
  * embedding-gradient vector in ws), then dh_color_backward_rays (WRITES d_pts, d_dirs_pts) -> dh_sdf_tangent ->
  * dh_sdf_backward_rays (ACCUMULATES onto d_pts, incl. the second-order path) -> weight-gradient stages as usual.  The caller
  * reduces per ray: d_rays_o = sum_k d_pts, d_rays_d = sum_k (mid_k d_pts + d_dirs_pts) + dh_render_scan_bwd_rays' d_rays_d;
- * sample depths are treated as constants.  Split-bf16 arithmetic only (DH_ERR_UNSUPPORTED under DH_ARITH_FP32_MFMA). */
+ * sample depths are treated as constants.  Both arithmetic modes (round 3: the fp32-MFMA twins have the same variants). */
 int dh_color_backward_rays(const float* packed, const float* colors, const float* d_colors, const float* dirs, int n_per_ray,
                            int64_t npts, float* ws, float* d_normals, float* d_pts, float* d_dirs_pts, void* stream);
 int dh_sdf_backward_rays(const float* packed, const float* d_sdf, const float* pts, const float* d_normals, int64_t npts,
@@ -183,12 +183,17 @@ int dh_neus_loss(const float* color, const float* weight_sum, const float* norma
  *   frames (reference ObjTracker/run.py:166), K [3,3] row-major (run.py:119-123).
  *   t^ = sum_k weights[r,k] m_k (m = mid-point depths of z as in dh_render_scan_fwd), x = o + t^ d, pi = K (R_j x + T_j),
  *   s = |pi - (u_j,v_j)| / fx, rho = Huber(s; delta_px / fx), L = sum c v rho / (sum c v + 1e-5), v = [depth in camera j > 1e-3].
- * stats[4] = L, sum c v, certainty-weighted mean residual in pixels, corr_weight * L.  residual_px [B] (0 for rays without a
- * valid match) feeds the outlier voting (host side).  d_weights [B,n] = d (corr_weight * L) / d weights, written for EVERY ray
- * (zeros where there is no match): pass it to dh_render_scan_bwd as d_weights. */
+ * stats[4] = L, sum c v, certainty-weighted mean residual in pixels, corr_weight * L.  residual_px [B] feeds the outlier voting
+ * (host side): 0 for rays without a match (certainty 0), +inf for a match that cannot be evaluated (partner frame out of range,
+ * point behind the partner camera: a gross failure that must vote as an outlier).  d_weights [B,n] = d (corr_weight * L) / d
+ * weights, written for EVERY ray (zeros where there is no match): pass it to dh_render_scan_bwd as d_weights.
+ * pose_adjoints (may be null; [B,7], pose refinement together with this term): per ray d (corr_weight L) / d x [3] (x = o + t^ d
+ * with t^ held fixed: the dependence of t^ on the geometry is what d_weights carries), d (corr_weight L) / d y [3] (y = R_j x +
+ * T_j: the partner frame's pose gradient is sum_rays d_y x^T and sum_rays d_y) and t^. */
 int dh_corr_loss(const float* rays_o, const float* rays_d, const float* z, const float* weights, const float* corr,
                  const float* R_all, const float* T_all, int n_frames, const float* K, int64_t B, int n, float sample_dist,
-                 float delta_px, float corr_weight, float* stats, float* residual_px, float* d_weights, void* stream);
+                 float delta_px, float corr_weight, float* stats, float* residual_px, float* d_weights, float* pose_adjoints,
+                 void* stream);
 
 /* ---- occupancy-grid ray marching, packed variable-length rays (BASELINE.json configs[3]) -------
  * The sampler of the instant-nsr-pl variant the reference names as its direction (README.md:11,13; code on an unmounted
@@ -199,13 +204,17 @@ int dh_corr_loss(const float* rays_o, const float* rays_d, const float* z, const
  *   half_step = (float)(0.5 * step) as the caller rounds it (kept separate so host and device agree bit for bit).
  * dh_march_count -> cnt [B]; the caller forms off = exclusive prefix sum (int64) and N = sum cnt, then dh_march_emit writes
  * t_start [N], the mid-point positions pts [N,3], the ray direction per sample dirs_pts [N,3] (pass it as `dirs` with
- * n_per_ray = 1 to the colour stages) and ray_idx [N].  No atomics: the packed order is a pure function of the inputs. */
+ * n_per_ray = 1 to the colour stages) and ray_idx [N].  No atomics: the packed order is a pure function of the inputs.
+ * dh_march_emit's `keep` (device, [B], may be null): ray r emits only its first min(keep[r], max_samples) samples -- the caller
+ * may lower the counts on the device (e.g. a per-ray cap chosen so that the total fits a fixed capacity) between the two calls
+ * without reading them back. */
 int dh_march_count(const float* rays_o, const float* rays_d, const float* near, const float* far, const float* u,
                    const uint8_t* occupancy, int res, float radius, float step, float half_step, int max_samples, int64_t B,
                    int32_t* cnt, void* stream);
 int dh_march_emit(const float* rays_o, const float* rays_d, const float* near, const float* far, const float* u,
                   const uint8_t* occupancy, int res, float radius, float step, float half_step, int max_samples, int64_t B,
-                  const int64_t* off, float* t_start, float* pts, float* dirs_pts, int32_t* ray_idx, void* stream);
+                  const int64_t* off, const int32_t* keep, float* t_start, float* pts, float* dirs_pts, int32_t* ray_idx,
+                  void* stream);
 /* dh_render_scan_fwd / _bwd over packed rays: ray r owns samples [seg_off[r], seg_off[r] + seg_cnt[r]) of the packed arrays
  * (seg_cnt <= 1024: the wave takes 128 samples per trip and carries the transmittance), every interval is `step` long and
  * t_start holds the interval starts; per-sample outputs are packed too. */
@@ -257,12 +266,16 @@ int dh_hash_workspace_floats(int64_t npts, int64_t* infer_floats, int64_t* total
 int dh_hash_sdf_nograd(const float* params, const float* packed, const float* pts, int64_t n, float radius, float* sdf,
                        void* stream);
 /* sdf [n], feature [n,13], finite-difference gradient [n,3].  ws: caller-owned workspace (save = 0: *infer floats; save =
- * 1: *total floats, and the encodings of the 7 evaluations stay in it for the three backward calls below). */
+ * 1: *total floats, and the encodings of the 7 evaluations stay in it for the three backward calls below).
+ * n_active (every stage of this family that takes it; device pointer to ONE int64, may be null): packed rays know their sample
+ * count only on the device.  The caller then sizes buffers, workspace and n for a CAPACITY (a multiple of 8) and passes the
+ * device-resident count: rows >= *n_active are neither read nor written and contribute nothing to any gradient, and no
+ * device -> host read is needed.  All stages of one forward / backward must be given the same n and n_active. */
 int dh_hash_geo_forward(const float* params, const float* packed, const float* pts, int64_t n, float radius, float eps,
-                        float* ws, int save, float* sdf, float* feature, float* gradient, void* stream);
+                        float* ws, int save, float* sdf, float* feature, float* gradient, const int64_t* n_active, void* stream);
 /* colour [n,3]; dirs [n / n_per_ray, 3] */
 int dh_hash_color_forward(const float* packed, const float* feature, const float* normals, const float* dirs,
-                          int n_per_ray, int64_t n, float* color, void* stream);
+                          int n_per_ray, int64_t n, float* color, const int64_t* n_active, void* stream);
 /* Adjoint, three calls in this order on the workspace dh_hash_geo_forward(save = 1) filled:
  *   colour   : d_color [n,3] -> d_feature [n,13] (written) and d_normals [n,3] (ACCUMULATED onto the caller's values)
  *   geometry : d_sdf [n], d_feature, d_normals (= cotangent of the finite-difference gradient)
@@ -270,11 +283,12 @@ int dh_hash_color_forward(const float* packed, const float* feature, const float
  *              atomics: order-dependent in the last bits, unlike the NeuS fp32 path); the variance slot is left untouched */
 int dh_hash_color_backward(const float* packed, const float* feature, const float* normals, const float* dirs,
                            const float* d_color, int n_per_ray, int64_t n, float* ws, float* d_feature, float* d_normals,
-                           void* stream);
+                           const int64_t* n_active, void* stream);
 int dh_hash_geo_backward(const float* params, const float* packed, const float* pts, const float* d_sdf,
                          const float* d_feature, const float* d_normals, int64_t n, float radius, float eps, float* ws,
+                         const int64_t* n_active, void* stream);
+int dh_hash_weight_grads(const float* params, const float* packed, int64_t n, float* ws, float* grad, const int64_t* n_active,
                          void* stream);
-int dh_hash_weight_grads(const float* params, const float* packed, int64_t n, float* ws, float* grad, void* stream);
 /* Diagnosis only (scripts/psnr_parity.py ablations): how dh_hash_weight_grads merges table-gradient adds before they
  * reach memory.  0 (default, shipping) = 7-evaluation blending + ray-run merging + quad-lane packing; 1 = no ray-run
  * merging; 2 = neither (one atomic per evaluation corner, tcnn's scheme).  Same sums up to float-atomic ordering. */

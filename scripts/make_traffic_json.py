@@ -14,6 +14,27 @@ mode = _lib.ARITH_FP32_MFMA if (len(sys.argv) > 3 and sys.argv[3] == "fp32_mfma"
 p = json.load(open(src))
 out = {}
 missing = []
+if len(sys.argv) > 3 and sys.argv[3] == "hash":
+    # hash family (BASELINE.json configs[3]): one C-ABI stage = several kernels (dynhor_amd/_lib.py:HASH_STAGE_LAUNCHES); the
+    # table scatter's WRITE_SIZE is the bytes its float atomics send to memory (exact: one dword per lane, guide section HBM)
+    for stage, kerns in _lib.HASH_STAGE_LAUNCHES.items():
+        tot, parts = 0.0, {}
+        for kern in kerns:
+            if kern not in p.get("prof_pmc2", {}) or kern not in p.get("prof_pmc3", {}):
+                missing.append(kern)
+                continue
+            f = p["prof_pmc2"][kern]["FETCH_SIZE"]["mean_per_dispatch"]
+            w = p["prof_pmc3"][kern]["WRITE_SIZE"]["mean_per_dispatch"]
+            parts[kern] = {"fetch_size_kb_raw": f, "write_size_kb_raw": w, "hbm_bytes_per_launch": f * 1024 * 2 + w * 1024}
+            tot += f * 1024 * 2 + w * 1024
+        out[stage] = {"kernel": _lib.HASH_STAGE_KERNELS[stage], "kernels": parts, "hbm_bytes_per_launch": tot,
+                      "atomic_bytes_per_launch": parts.get(_lib.HASH_STAGE_KERNELS[stage], {}).get("write_size_kb_raw", 0.0) * 1024,
+                      "correction": "FETCH_SIZE x2 (gfx950 16-B/lane streaming reads), WRITE_SIZE x1 (exact for float atomics)"}
+    if missing:
+        sys.exit(f"stale or incomplete PMC profile: no counters for the shipping kernels {missing}")
+    json.dump(out, open(dst, "w"), indent=1)
+    print(json.dumps(out, indent=1))
+    sys.exit(0)
 for stage, kern in _lib.STAGE_KERNELS[mode].items():
     if stage == "sdf_nograd_fine":
         continue          # same kernel as sdf_nograd_coarse; the PMC means are over all its launches

@@ -33,12 +33,15 @@ LOSS_W = (0.1, 0.1, 0.05)          # eikonal, mask, mono-normal (the bench confi
 LOG = sys.stdout                    # bench.py --psnr points this at stderr
 
 
+HASH_RENDERER_EXTRA = {}            # --march-samples / --max-samples (occupancy-grid sampler experiments)
+
+
 def make_runner(family, weight_seed, batch, frames, res, dev, tag, hash_sampler="hierarchical"):
     conf = {"seq_name": "psnr_parity", "exp_name": tag,
             "data_info": {"synthetic": {"n_frames": frames, "H": res, "W": res, "seed": 4321}},
             "train": {"batch_size": batch, "normal_weight": LOSS_W[2], "report_freq": 10 ** 9, "save_freq": 10 ** 9,
                       "val_freq": 0, "end_iter": END_ITER, "warm_up_end": WARM_UP, "anneal_end": ANNEAL_END, "seed": weight_seed},
-            "model": {"family": family, "hash_renderer": {"sampler": hash_sampler}}}
+            "model": {"family": family, "hash_renderer": {"sampler": hash_sampler, **(HASH_RENDERER_EXTRA if hash_sampler == "occgrid" else {})}}}
     return Runner(conf=conf, device=dev, exp_root="/tmp/dynhor_psnr")
 
 
@@ -278,7 +281,13 @@ def run_parity(argv=None):
     ap.add_argument("--lockstep", type=int, default=0)
     ap.add_argument("--cross-check", action="store_true")
     ap.add_argument("--out", type=str, default=None)
+    ap.add_argument("--march-samples", type=int, default=None, help="occgrid sampler: marching steps per cube diagonal (default 512)")
+    ap.add_argument("--max-samples", type=int, default=None, help="occgrid sampler: capacity in samples per ray (default 128)")
     args = ap.parse_args(argv)
+    if args.march_samples:
+        HASH_RENDERER_EXTRA["march_samples_per_ray"] = args.march_samples
+    if args.max_samples:
+        HASH_RENDERER_EXTRA["max_samples"] = args.max_samples
     args.eval_iters = [int(x) for x in args.eval_iters.split(",") if int(x) <= args.iters] or [args.iters]
     args.lr = args.lr if args.lr is not None else (5e-3 if args.family == "hash" else 5e-4)
     dev = torch.device("cuda:0")
@@ -290,9 +299,13 @@ def run_parity(argv=None):
         print(json.dumps({"seed": seed, "window_mean_a": r["window_mean_a"], "window_mean_b": r["window_mean_b"],
                           "window_delta_db": r["window_delta_db"], "final_delta_db": r["final_delta_db"],
                           "elapsed_s": time.time() - t0}), flush=True, file=LOG)
+        if args.out:        # a call cut off by its time limit keeps the seeds that finished
+            part = (args.out if os.path.isabs(args.out) else os.path.join(ROOT, args.out)) + ".partial"
+            os.makedirs(os.path.dirname(part), exist_ok=True)
+            json.dump({"mode": args.mode, "family": args.family, "seeds": recs}, open(part, "w"))
     res = {"family": args.family, "mode": args.mode, "arms": recs[0]["arms"], "iters": args.iters, "batch": args.batch,
            "frames": args.frames, "res": args.res, "lr": args.lr, "eval_iters": args.eval_iters, "eval_level": args.eval_level,
-           "final_level": args.final_level, "lockstep": args.lockstep,
+           "final_level": args.final_level, "lockstep": args.lockstep, "hash_renderer_extra": dict(HASH_RENDERER_EXTRA),
            "protocol": "paired seeds (ray stream + initial weights per seed, shared by both arms); PSNR = masked MSE aggregated over "
                        "ALL frames, rendered by the HIP forward-only path for both arms; window = mean over the eval checkpoints",
            "window_delta": summarize(recs, "window_delta_db"), "final_delta": summarize(recs, "final_delta_db"),

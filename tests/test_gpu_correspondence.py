@@ -44,10 +44,17 @@ def test_corr_loss_kernel_matches_oracle(B, n):
     o, d, z, w, corr, R_all, T_all, K = _random_case(B, n, seed=B + n)
     sd, delta, cw = 2.0 / 64, 4.0, 0.3
     stats = torch.empty(4, device="cuda"); res = torch.empty(B, device="cuda"); dw = torch.empty(B, n, device="cuda")
+    padj = torch.empty(B, 7, device="cuda")
     _lib.check(_lib.lib().dh_corr_loss(_p(o), _p(d), _p(z), _p(w), _p(corr), _p(R_all), _p(T_all), R_all.shape[0], _p(K), B, n,
-                                      sd, delta, cw, _p(stats), _p(res), _p(dw), _lib.stream()))
+                                      sd, delta, cw, _p(stats), _p(res), _p(dw), _p(padj), _lib.stream()))
+    dw0 = torch.empty(B, n, device="cuda"); st0 = torch.empty(4, device="cuda"); rs0 = torch.empty(B, device="cuda")
+    _lib.check(_lib.lib().dh_corr_loss(_p(o), _p(d), _p(z), _p(w), _p(corr), _p(R_all), _p(T_all), R_all.shape[0], _p(K), B, n,
+                                      sd, delta, cw, _p(st0), _p(rs0), _p(dw0), None, _lib.stream()))
+    assert torch.equal(dw0, dw) and torch.equal(st0, stats), "the optional pose adjoints change nothing else"
     w64 = w.double().requires_grad_(True)
-    ref = O.correspondence_loss(w64, z.double(), sd, o.double(), d.double(), corr.double(), R_all.double(), T_all.double(), K.double(), delta)
+    o64, d64 = o.double().requires_grad_(True), d.double().requires_grad_(True)
+    R64, T64 = R_all.double().requires_grad_(True), T_all.double().requires_grad_(True)
+    ref = O.correspondence_loss(w64, z.double(), sd, o64, d64, corr.double(), R64, T64, K.double(), delta)
     (cw * ref["loss"]).backward()
     c = corr[:, 2].double() * ref["valid"]
     assert c.sum().item() > 0 and (ref["valid"] == 0).any(), "the case must contain valid matches and points behind the partner camera"
@@ -58,12 +65,28 @@ def test_corr_loss_kernel_matches_oracle(B, n):
     assert abs(stats[3].item() - cw * ref["loss"].item()) < 2e-5
     live = (c > 0)
     assert (res.double() - ref["residual_px"] * live)[live].abs().max().item() < 2e-2, "residuals in pixels (fp32 projection)"
-    assert (res[~live] == 0).all()
+    nomatch = corr[:, 2] == 0
+    assert (res[nomatch] == 0).all(), "rays without a match report 0"
+    behind = (~live) & (~nomatch)
+    assert behind.any() and torch.isinf(res[behind]).all(), "a match that projects behind the partner camera is +inf (an outlier), not 0"
     gref = w64.grad
     rel = ((dw.double() - gref).norm() / gref.norm()).item()
     print(f"corr loss {stats[0].item():.6f} (oracle {ref['loss'].item():.6f}); d_weights rel err {rel:.2e}")
     assert rel < 2e-4
     assert (dw[corr[:, 2] == 0] == 0).all(), "rays without a match get an exactly-zero adjoint"
+    # pose adjoints (refine_poses + the correspondence term): d / d x, d / d y and t^ per ray
+    # vs the oracle differentiated w.r.t. the rays (at fixed weights) and w.r.t. every frame's pose
+    d_x, d_y, t_hat = padj[:, :3].double(), padj[:, 3:6].double(), padj[:, 6:7].double()
+    assert ((d_x - o64.grad).norm() / o64.grad.norm()).item() < 2e-4
+    assert ((t_hat * d_x - d64.grad).norm() / d64.grad.norm()).item() < 2e-4
+    j = corr[:, 3].long()
+    x = o.double() + t_hat * d.double()
+    dR = torch.zeros_like(R64).index_add_(0, j, d_y[:, :, None] * x[:, None, :])
+    dT = torch.zeros_like(T64).index_add_(0, j, d_y)
+    relR, relT = ((dR - R64.grad).norm() / R64.grad.norm()).item(), ((dT - T64.grad).norm() / T64.grad.norm()).item()
+    print(f"partner-pose adjoints: d_R rel {relR:.2e}, d_T rel {relT:.2e}")
+    assert relR < 2e-4 and relT < 2e-4
+    assert (padj[~live][:, :6] == 0).all()
 
 
 def test_fused_train_step_with_correspondence_term_matches_oracle():

@@ -144,7 +144,7 @@ def test_two_rank_data_parallel_on_one_gpu_under_torchrun():
     except subprocess.TimeoutExpired as e:      # a hang here is a data-parallel regression, not an environment quirk
         pytest.fail("2-process gloo run on a shared GPU did not finish in 300 s: " + str(e.stdout)[-1500:] + str(e.stderr)[-1500:])
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
-    assert "check-sync ok" in p.stdout
+    assert "check-sync ok" in p.stderr
     import json
     line = [l for l in p.stdout.splitlines() if l.startswith("{")][-1]
     out = json.loads(line)

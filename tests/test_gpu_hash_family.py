@@ -102,7 +102,7 @@ def test_color_forward_matches_oracle():
     out = torch.empty(n, 3, device="cuda")
     from dynhor_amd import _lib
     _lib.check(_lib.lib().dh_hash_color_forward(_lib.ptr(p_r.store.ensure_packed()), _lib.ptr(feat), _lib.ptr(nrm),
-                                                _lib.ptr(d), per, n, _lib.ptr(out), _lib.stream()))
+                                                _lib.ptr(d), per, n, _lib.ptr(out), None, _lib.stream()))
     torch.cuda.synchronize()
     err = (out.double() - ref).abs().max().item()
     print("colour err", err)
@@ -231,7 +231,7 @@ def test_bad_arguments_are_rejected():
     assert L.dh_hash_sdf_nograd(_lib.ptr(st.flat), _lib.ptr(st.ensure_packed()), _lib.ptr(x), -1, 1.0, _lib.ptr(out), None) != 0
     assert L.dh_hash_sdf_nograd(_lib.ptr(st.flat), _lib.ptr(st.packed), _lib.ptr(x), 4, 0.0, _lib.ptr(out), None) != 0
     assert L.dh_hash_sdf_nograd(None, _lib.ptr(st.packed), _lib.ptr(x), 4, 1.0, _lib.ptr(out), None) != 0
-    assert L.dh_hash_color_forward(_lib.ptr(st.packed), _lib.ptr(x), _lib.ptr(x), _lib.ptr(x), 3, 4, _lib.ptr(out), None) != 0
+    assert L.dh_hash_color_forward(_lib.ptr(st.packed), _lib.ptr(x), _lib.ptr(x), _lib.ptr(x), 3, 4, _lib.ptr(out), None, None) != 0
     with pytest.raises(TypeError):
         from dynhor_amd.hash_fields import HashNeuSRenderer
         HashNeuSRenderer(None, o_r.sdf_network, o_r.deviation_network, o_r.color_network, n_samples=16, n_importance=16,

@@ -31,7 +31,9 @@ def _run(cmd, timeout=420):
 def test_single_rank_rccl_allreduce_runs():
     p = _run([sys.executable, "bench.py", "--gpus", "1", "--force-dist", "--backend", "nccl", "--steps", "3", "--warmup", "1",
               "--frames", "8", "--no-cpu-baseline"])
-    out = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), "stdout is ONE JSON line (RCCL's version banner must not land in it): " + p.stdout[:400]
+    out = json.loads(lines[0])
     comm = out["comm"]
     assert comm["backend"] == "nccl" and comm["nranks"] == 1
     assert comm["rccl_version"] and all(c.isdigit() or c == "." for c in comm["rccl_version"]), comm
@@ -44,7 +46,7 @@ def test_bench_starts_its_own_two_ranks():
     """The driver's command form: no torch.distributed.run on the command line."""
     p = _run([sys.executable, "bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1", "--frames", "8", "--backend", "gloo",
               "--share-gpu", "--check-sync", "--no-cpu-baseline"])
-    assert "check-sync ok" in p.stdout
+    assert "check-sync ok" in p.stderr
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, "exactly one JSON line (rank 0's) must reach the parent's stdout"
     out = json.loads(lines[0])

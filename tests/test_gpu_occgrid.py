@@ -52,7 +52,7 @@ def _hip_march(o, d, near, far, u, grid, step, max_samples=128):
     m = SimpleNamespace(N=N, off=off, cnt=cnt, step=stepf, t_start=torch.empty(N, device="cuda"), pts=torch.empty(N, 3, device="cuda"),
                         dirs=torch.empty(N, 3, device="cuda"), ray_idx=torch.empty(N, dtype=torch.int32, device="cuda"))
     _lib.check(L.dh_march_emit(_p(o), _p(d), _p(nr), _p(fr), _p(u), _p(binary), grid.res, grid.radius, stepf, half, max_samples, B,
-                               _p(off), _p(m.t_start), _p(m.pts), _p(m.dirs), _p(m.ray_idx), _lib.stream()))
+                               _p(off), None, _p(m.t_start), _p(m.pts), _p(m.dirs), _p(m.ray_idx), _lib.stream()))
     return m
 
 
@@ -167,7 +167,8 @@ def test_fused_training_step_on_packed_rays_matches_oracle(tmp_path):
     o_sdf, o_col, o_var = _oracle_hash_models(r, dev)
     g = torch.Generator(device=dev); g.manual_seed(3)
     jitter = torch.rand(ren.grid.res ** 3, 3, device=dev, generator=g)
-    frac = ren.update_grid(jitter=jitter)
+    ren.update_grid(jitter=jitter)
+    frac = ren.grid.occupied_fraction()
     # the grid the product built == the oracle's update from the same jitter (sdf through the oracle network)
     og = G.OccupancyGrid(res=ren.grid.res, radius=1.0, device=dev)
     with torch.no_grad():
@@ -184,7 +185,13 @@ def test_fused_training_step_on_packed_rays_matches_oracle(tmp_path):
     stats = ren.train_step_core(rays, near, far, ds.R[frame], car, 0.1, 0.1, 0.05, t_rand=u)
     torch.cuda.synchronize()
     m = ren.last_state.m
-    assert m.N > B and ren.last_march["samples"] == m.N
+    lm = ren.last_march
+    N = int(m.n_dev)
+    assert N > B and lm["samples"] == N and lm["capacity"] == B * 128 and lm["per_ray_cap"] in (128, 256, 512, 1024)
+    assert lm["rays_truncated"] == 0 or lm["per_ray_cap"] < 1024
+    # the packed arrays live at the fixed capacity; rows >= N belong to nobody
+    from types import SimpleNamespace
+    m = SimpleNamespace(N=N, pts=m.pts[:N], dirs=m.dirs[:N], ray_idx=m.ray_idx[:N], off=m.off, cnt=m.cnt, step=m.step)
     # oracle on the SAME packed samples (the marcher itself is checked above), fp64 networks
     for mod in (o_sdf, o_col, o_var):
         mod.double(); mod.zero_grad()
@@ -236,10 +243,141 @@ def test_runner_trains_and_validates_with_occupancy_grid_sampler(tmp_path):
         first = first if first is not None else float(s[0])
     assert float(s[0]) < first and torch.isfinite(r.store.flat).all()
     lm = r.renderer.last_march
-    assert 0 < lm["samples_per_ray"] <= 128
+    assert 0 < lm["samples_per_ray"] <= 128 and lm["samples"] <= lm["capacity"]
     occ_frac = float(r.renderer.grid.binary.float().mean())
     assert 0.0 < occ_frac < 0.6, "the grid prunes empty space"
     psnr = r.validate_image(idx=0, resolution_level=2)
     assert psnr == psnr and psnr > 5
     with pytest.raises(ValueError):
         r.renderer.train_step_core(r._last_rays, *r.dataset._last_near_far, r.dataset.R[0], 0.1, ray_grads=True)
+
+
+def test_device_side_count_matches_exact_size_launch():
+    """the packed stages take the sample count from the DEVICE (n_active) on buffers laid out for a fixed
+    capacity.  Same samples through (a) exact-size launches (n = N, n_active = null) and (b) capacity launches (n = cap >
+    N, n_active -> N) with the rows past N poisoned with NaN: identical outputs on the first N rows, identical weight
+    gradients except float-atomic order in the table."""
+    import ctypes
+    from dynhor_amd import _lib
+    from dynhor_amd.hash_fields import HashNeuSRenderer, build_hash_models
+    from dynhor_amd.renderer import _p
+    dev = torch.device("cuda:0")
+    L = _lib.lib()
+    sdf, var, col = build_hash_models(seed=5, device=dev)
+    ren = HashNeuSRenderer(None, sdf, var, col, 64, 64, 0, 4, 1.0, device=dev)
+    g = torch.Generator(device=dev); g.manual_seed(1)
+    with torch.no_grad():
+        sdf.lin0.weight_v.add_(0.05 * torch.randn(sdf.lin0.weight_v.shape, device=dev, generator=g))
+        sdf.encoding.table.add_(0.005 * torch.randn(sdf.encoding.table.shape, device=dev, generator=g))
+    ren.store.bump()
+    st = ren.store
+    packed = st.ensure_packed()
+    N, cap = 1000, 1536                                   # N is not a multiple of 64 (ragged last tile), cap is a multiple of 8
+    pts_n = (torch.rand(N, 3, device=dev, generator=g) * 1.2 - 0.6)
+    dirs_n = torch.nn.functional.normalize(torch.randn(N, 3, device=dev, generator=g), dim=-1)
+    d_sdf_n = torch.randn(N, device=dev, generator=g); d_nrm_n = torch.randn(N, 3, device=dev, generator=g) * 0.1
+    d_col_n = torch.randn(N, 3, device=dev, generator=g)
+
+    def run(n, n_act, poison):
+        ws = torch.full((ren._workspace_need(n, False),), float("nan") if poison else 0.0, device=dev)
+        fill = float("nan") if poison else 0.0
+        pad = lambda t: torch.cat([t, torch.full((n - N,) + t.shape[1:], fill, device=dev)]).contiguous()
+        pts, dirs = pad(pts_n), pad(dirs_n)
+        o_sdf = torch.full((n,), fill, device=dev); o_feat = torch.full((n, 13), fill, device=dev)
+        o_nrm = torch.full((n, 3), fill, device=dev); o_col = torch.full((n, 3), fill, device=dev)
+        na = None if n_act is None else torch.tensor([n_act], dtype=torch.int64, device=dev)
+        _lib.check(L.dh_hash_geo_forward(_p(st.flat), _p(packed), _p(pts), n, 1.0, 1e-3, _p(ws), 1, _p(o_sdf), _p(o_feat), _p(o_nrm),
+                                         _p(na), _lib.stream()))
+        _lib.check(L.dh_hash_color_forward(_p(packed), _p(o_feat), _p(o_nrm), _p(dirs), 1, n, _p(o_col), _p(na), _lib.stream()))
+        d_feat = torch.full((n, 13), fill, device=dev)
+        d_nrm = pad(d_nrm_n)
+        _lib.check(L.dh_hash_color_backward(_p(packed), _p(o_feat), _p(o_nrm), _p(dirs), _p(pad(d_col_n)), 1, n, _p(ws), _p(d_feat),
+                                            _p(d_nrm), _p(na), _lib.stream()))
+        _lib.check(L.dh_hash_geo_backward(_p(st.flat), _p(packed), _p(pts), _p(pad(d_sdf_n)), _p(d_feat), _p(d_nrm), n, 1.0, 1e-3,
+                                          _p(ws), _p(na), _lib.stream()))
+        grad = torch.zeros(st.n, device=dev)
+        _lib.check(L.dh_hash_weight_grads(_p(st.flat), _p(packed), n, _p(ws), _p(grad), _p(na), _lib.stream()))
+        torch.cuda.synchronize()
+        return o_sdf[:N], o_feat[:N], o_nrm[:N], o_col[:N], d_feat[:N], grad
+
+    a = run(N, None, poison=False)
+    b = run(cap, N, poison=True)
+    for x, y, name in zip(a[:5], b[:5], ("sdf", "feature", "normal", "colour", "d_feature")):
+        assert torch.equal(x, y), name
+    ga, gb = a[5], b[5]
+    assert torch.isfinite(gb).all(), "no stale (NaN) row may reach a gradient"
+    (_, off0, cnt0) = st.slices[0]
+    # the slab partition of the weight-gradient reduction follows the row count, so the two launches sum their ~7,000 fp32
+    # terms per entry in different orders: a few 1e-5 relative is fp32 accumulation noise on these O(1) random cotangents (the
+    # gradients themselves are checked against the fp64 oracle in test_fused_training_step_on_packed_rays_matches_oracle)
+    rel_mlp = ((ga[off0 + cnt0:].double() - gb[off0 + cnt0:].double()).norm() / ga[off0 + cnt0:].double().norm()).item()
+    rel = ((ga[:cnt0].double() - gb[:cnt0].double()).norm() / ga[:cnt0].double().norm()).item()
+    print(f"capacity launch vs exact-size launch: MLP gradients rel {rel_mlp:.2e}, table gradient rel {rel:.2e} (summation order only)")
+    assert rel_mlp < 1e-4, rel_mlp
+    assert rel < 1e-5, f"table gradient (float atomics: order only) {rel}"
+    b2 = run(cap, N, poison=True)
+    assert torch.equal(b[5][off0 + cnt0:], b2[5][off0 + cnt0:]), "same launch shape -> the MLP gradients are bitwise reproducible"
+    # n_active = 0: nothing runs, gradients of the MLPs are zero
+    c = run(cap, 0, poison=True)
+    assert torch.isfinite(c[5]).all() and float(c[5][off0 + cnt0:].abs().sum()) == 0.0 and float(c[5][:cnt0].abs().sum()) == 0.0
+    # capacity must be a multiple of 8 when a device count is given
+    na = torch.tensor([5], dtype=torch.int64, device=dev)
+    x = torch.zeros(1004 * 13, device=dev)
+    assert L.dh_hash_color_backward(_p(packed), _p(x), _p(x), _p(x), _p(x), 1, 1004, _p(x), _p(x), _p(x), _p(na), _lib.stream()) != 0
+    assert L.dh_hash_weight_grads(_p(st.flat), _p(packed), 1004, _p(x), _p(x), _p(na), _lib.stream()) != 0
+
+
+def test_adaptive_per_ray_cap_and_no_host_sync_in_the_step(tmp_path):
+    """The per-ray cap is the largest ladder rung whose total fits the fixed capacity, chosen on the device; marching with it
+    equals the oracle's marcher at that cap; the training step never reads the count back."""
+    r = _occ_runner(tmp_path)
+    ren = r.renderer
+    ds = r.dataset
+    dev = r.device
+    g = torch.Generator(device=dev); g.manual_seed(9)
+    for _ in range(20):
+        r.train_iteration()
+    B = 777
+    rays = ds.gen_random_rays_at(1, B, generator=g)
+    near, far = ds._last_near_far
+    u = torch.rand(B, 1, device=dev, generator=g)
+    o, d = rays[:, :3].contiguous(), rays[:, 3:6].contiguous()
+    m = ren.march(o, d, near, far, u)
+    cap = int(m.cap_dev)
+    assert cap in ren._cap_ladder and int(m.n_dev) <= m.cap == (B * ren.max_samples + 7) // 8 * 8
+    # a larger rung (if any) would not have fitted
+    idx = ren._cap_ladder.index(cap)
+    if idx > 0:
+        assert int(torch.minimum(m.cnt_raw, torch.tensor(ren._cap_ladder[idx - 1], device=dev)).sum()) > m.cap
+    og = G.OccupancyGrid(res=ren.grid.res, radius=1.0, device=dev)
+    og.binary = ren.grid.binary.bool()
+    ref = G.march(o, d, near, far, u.view(-1), og, float(m.step), max_samples=cap)
+    N = int(m.n_dev)
+    assert torch.equal(m.cnt.long(), ref["cnt"]) and torch.equal(m.off, ref["off"]) and N == ref["t_start"].shape[0]
+    assert torch.equal(m.t_start[:N], ref["t_start"]) and torch.equal(m.ray_idx[:N].long(), ref["ray_idx"])
+    # the training step of either sampler never waits for the device: PyTorch's own synchronisation detector stays silent
+    r.train_iteration()
+    torch.cuda.synchronize()
+    torch.cuda.set_sync_debug_mode("error")
+    try:
+        for _ in range(3):
+            r.train_iteration()
+    finally:
+        torch.cuda.set_sync_debug_mode("default")
+    assert r.renderer.last_march["samples"] > 0          # the statistics are available afterwards (this read does synchronise)
+
+
+def test_neus_training_step_never_synchronises(tmp_path):
+    from dynhor_amd.runner import Runner
+    conf = {"seq_name": "nosync", "exp_name": "e", "data_info": {"synthetic": {"n_frames": 4, "H": 64, "W": 64, "seed": 3}},
+            "train": {"batch_size": 256, "normal_weight": 0.05, "report_freq": 10 ** 9, "save_freq": 10 ** 9, "val_freq": 0}}
+    r = Runner(conf=conf, device="cuda:0", exp_root=str(tmp_path))
+    for _ in range(2):
+        r.train_iteration()
+    torch.cuda.synchronize()
+    torch.cuda.set_sync_debug_mode("error")
+    try:
+        for _ in range(3):
+            r.train_iteration()
+    finally:
+        torch.cuda.set_sync_debug_mode("default")
