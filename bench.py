@@ -248,6 +248,8 @@ def main():
     if saved_stdout is not None:
         torch.cuda.synchronize()
         sys.stdout.flush()
+        import ctypes
+        ctypes.CDLL(None).fflush(None)          # RCCL printf()s into libc's stdout buffer: empty it while fd 1 still is stderr
         os.dup2(saved_stdout, 1)
         os.close(saved_stdout)
     if args.check_sync and world > 1:

@@ -359,7 +359,6 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(const float* __restrict
                                                          float* __restrict__ d_normals, float* __restrict__ d_colors,
                                                          float* __restrict__ d_inv_s, float* __restrict__ d_rays_d,
                                                          const int64_t* __restrict__ seg_off, const int32_t* __restrict__ seg_cnt) {
-    __shared__ float s_tin[4][RENDER_MAX_CHUNKS], s_q[4][RENDER_MAX_CHUNKS];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int64_t ray = (int64_t)blockIdx.x * 4 + wave;
     if (ray >= B) return;
@@ -368,6 +367,9 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(const float* __restrict
     if (packed) n = min(seg_cnt[ray], 128 * RENDER_MAX_CHUNKS);
     const float inv_s = inv_s_p[0];
     const float ec = eik_coef[0];
+    // per-trip carries of the first sweep live in REGISTERS (lane ch holds trip ch's entry transmittance and q total, read back
+    // by __shfl): the waves of a workgroup leave / iterate divergently, so an LDS hand-off could not be fenced by a barrier
+    float c_tin = 1.f, c_q = 0.f;
     float o[3], d[3], dC[3];
     DH_UNROLL for (int c = 0; c < 3; ++c) { o[c] = rays_o[ray * 3 + c]; d[c] = rays_d[ray * 3 + c]; dC[c] = d_color[ray * 3 + c]; }
     float dN[3] = {0.f, 0.f, 0.f};
@@ -398,7 +400,7 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(const float* __restrict
             const float excl = T_in * wave_excl_prod(P.tA * P.tB, lane);
             const float q = (P.v0 ? P.wb0 * P.A.alpha * excl : 0.f) + (P.v1 ? P.wb1 * P.Bq.alpha * excl * P.tA : 0.f);
             const float qs = wave_sum(q);
-            if (lane == 0) { s_tin[wave][ch] = T_in; s_q[wave][ch] = qs; }
+            if (lane == ch) { c_tin = T_in; c_q = qs; }         // T_in and qs are wave-uniform
             T_in = __shfl(excl * P.tA * P.tB, 63);
         }
     }
@@ -427,8 +429,8 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(const float* __restrict
         const RenderPair P = load_pair(ch * 128);
         float T_in = 1.f, q_after = 0.f;
         if (nchunks > 1) {
-            T_in = s_tin[wave][ch];
-            for (int k = ch + 1; k < nchunks; ++k) q_after += s_q[wave][k];
+            T_in = __shfl(c_tin, ch);
+            for (int k = ch + 1; k < nchunks; ++k) q_after += __shfl(c_q, k);
         }
         const float excl = T_in * wave_excl_prod(P.tA * P.tB, lane);
         const float T0 = excl, T1 = excl * P.tA;

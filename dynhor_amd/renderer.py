@@ -85,7 +85,7 @@ class _RenderCoreFn(torch.autograd.Function):
 class NeuSRenderer:
     def __init__(self, nerf, sdf_network: SDFNetwork, deviation_network: SingleVarianceNetwork,
                  color_network: RenderingNetwork, n_samples, n_importance, n_outside, up_sample_steps, perturb,
-                 store: ParamStore | None = None, device="cuda"):
+                 store: ParamStore | None = None, device="cuda", arithmetic: int | None = None):
         if n_outside != 0:
             raise ValueError("n_outside > 0 (NeRF++ background) is out of scope with masks (SURVEY.md App. A.5)")
         if n_importance % max(up_sample_steps, 1) != 0:
@@ -106,6 +106,10 @@ class NeuSRenderer:
         self._ws = None
         self._ws_token = 0
         self.timer = StageTimer()
+        # dh_set_arithmetic is a host-side word of the library, read when a stage is LAUNCHED.  A renderer constructed with an
+        # explicit arithmetic (_lib.ARITH_SPLIT_BF16 / ARITH_FP32_MFMA) sets the word before each of its stage groups, so two
+        # renderers of one process can run different arithmetics (single-threaded hosts; None = leave the word alone).
+        self.arithmetic = arithmetic
 
     def _make_store(self, sdf_network, deviation_network, color_network, device):
         return ParamStore(sdf_network, deviation_network, color_network, device)
@@ -124,13 +128,19 @@ class NeuSRenderer:
 
     # ------------------------------------------------------------------ network stages (the model-family hooks;
     # hash_fields.HashNeuSRenderer overrides these three + _workspace_need)
+    def _select_arithmetic(self):
+        if self.arithmetic is not None and _lib.get_arithmetic() != self.arithmetic:
+            _lib.set_arithmetic(self.arithmetic)
+
     def _net_sdf_nograd(self, tag, pts, n, out):
+        self._select_arithmetic()
         self.timer(tag, _lib.lib().dh_sdf_nograd, _p(self.store.packed), _p(pts), n, _p(out), _lib.stream())
 
     def _net_forward(self, s, packed):
         """pts [P,3] -> s.sdf, s.normals (d sdf / d x), s.colors; saves what _net_backward needs in s.ws."""
         L, T = _lib.lib(), self.timer
         P = s.B * s.n
+        self._select_arithmetic()
         T("sdf_forward", L.dh_sdf_forward, _p(packed), _p(s.pts), P, _p(s.ws), _p(s.sdf), _lib.stream())
         save = 0 if s.infer_only else (2 if getattr(s, "ray_grads", False) else 1)
         T("sdf_gradient", L.dh_sdf_gradient, _p(packed), _p(s.pts), P, _p(s.ws), _p(s.normals), save, _lib.stream())
@@ -142,6 +152,7 @@ class NeuSRenderer:
         also leaves s.d_pts [P,3] (d loss / d sample point) and s.d_dirs_pts [P,3] (d loss / d ray direction per point)."""
         L, T, st = _lib.lib(), self.timer, self.store
         P = s.B * s.n
+        self._select_arithmetic()
         if getattr(s, "ray_grads", False):
             s.d_pts = torch.empty(P, 3, device=s.pts.device)
             s.d_dirs_pts = torch.empty(P, 3, device=s.pts.device)

@@ -35,7 +35,9 @@ DEFAULT_CONF = {
               # per-frame pose refinement: 6-D rotation + translation per frame, rotation at 10x lr
               "refine_poses": False, "pose_lr": 1e-4, "pose_rot_lr_mult": 10.0, "pose_start_iter": 0},
     # family "neus": the 8x256 / 4x256 fp32 MLPs (BASELINE.json configs[1]); "hash": hash-grid + shallow MLPs (configs[3])
-    "model": {"family": "neus", "sdf_network": {}, "variance_network": {"init_val": 0.3}, "rendering_network": {},
+    # arithmetic: null (leave the library's word alone), "split_bf16" (shipping) or "fp32_mfma" (the native fp32-MFMA twins) for THIS
+    # Runner's renderer -- two Runners of one process may differ
+    "model": {"family": "neus", "arithmetic": None, "sdf_network": {}, "variance_network": {"init_val": 0.3}, "rendering_network": {},
               "hash_sdf_network": {}, "sh_rendering_network": {},
               # hash family only: sampler "hierarchical" (NeuS 64+64) or "occgrid" (instant-nsr-pl occupancy-grid marching)
               "hash_renderer": {"sampler": "hierarchical", "march_samples_per_ray": 512, "grid_res": 128, "grid_update_every": 16,
@@ -108,7 +110,11 @@ class Runner:
             self.deviation_network = SingleVarianceNetwork(**self.conf["model"]["variance_network"])
         self.nerf_outside = None
         self.store = store_cls(self.sdf_network, self.deviation_network, self.color_network, self.device)
-        extra = self.conf["model"]["hash_renderer"] if family == "hash" else {}
+        extra = dict(self.conf["model"]["hash_renderer"]) if family == "hash" else {}
+        ar = self.conf["model"].get("arithmetic")
+        if ar is not None:
+            from . import _lib
+            extra["arithmetic"] = {"split_bf16": _lib.ARITH_SPLIT_BF16, "fp32_mfma": _lib.ARITH_FP32_MFMA}[ar]
         self.renderer = renderer_cls(self.nerf_outside, self.sdf_network, self.deviation_network, self.color_network,
                                      store=self.store, device=self.device, **self.conf["model"]["neus_renderer"], **extra)
         self.pose_refiner = None

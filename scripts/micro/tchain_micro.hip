@@ -76,6 +76,9 @@ __device__ __forceinline__ void epi_only(const f32x16& x, Pieces (&out)[2], EpiS
 // MFMAs and the LDS stash writes therefore name the registers literally; the compiler never sees them (clobber list below; the
 // build is checked for compiler-made v_accvgpr_* = none).
 #define TC_ALL_AGPRS "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15", "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31", "a32", "a33", "a34", "a35", "a36", "a37", "a38", "a39", "a40", "a41", "a42", "a43", "a44", "a45", "a46", "a47", "a48", "a49", "a50", "a51", "a52", "a53", "a54", "a55", "a56", "a57", "a58", "a59", "a60", "a61", "a62", "a63", "a64", "a65", "a66", "a67", "a68", "a69", "a70", "a71", "a72", "a73", "a74", "a75", "a76", "a77", "a78", "a79", "a80", "a81", "a82", "a83", "a84", "a85", "a86", "a87", "a88", "a89", "a90", "a91", "a92", "a93", "a94", "a95", "a96", "a97", "a98", "a99", "a100", "a101", "a102", "a103", "a104", "a105", "a106", "a107", "a108", "a109", "a110", "a111", "a112", "a113", "a114", "a115", "a116", "a117", "a118", "a119", "a120", "a121", "a122", "a123", "a124", "a125", "a126", "a127", "a128", "a129", "a130", "a131", "a132", "a133", "a134", "a135", "a136", "a137", "a138", "a139", "a140", "a141", "a142", "a143", "a144", "a145", "a146", "a147", "a148", "a149", "a150", "a151", "a152", "a153", "a154", "a155", "a156", "a157", "a158", "a159", "a160", "a161", "a162", "a163", "a164", "a165", "a166", "a167", "a168", "a169", "a170", "a171", "a172", "a173", "a174", "a175", "a176", "a177", "a178", "a179", "a180", "a181", "a182", "a183", "a184", "a185", "a186", "a187", "a188", "a189", "a190", "a191", "a192", "a193", "a194", "a195", "a196", "a197", "a198", "a199", "a200", "a201", "a202", "a203", "a204", "a205", "a206", "a207", "a208", "a209", "a210", "a211", "a212", "a213", "a214", "a215", "a216", "a217", "a218", "a219", "a220", "a221", "a222", "a223", "a224", "a225", "a226", "a227", "a228", "a229", "a230", "a231", "a232", "a233", "a234", "a235", "a236", "a237", "a238", "a239", "a240", "a241", "a242", "a243", "a244", "a245", "a246", "a247", "a248", "a249", "a250", "a251", "a252", "a253", "a254", "a255"
+// -DTC_BUILTIN: the compiler allocates both accumulator sets (f32x16 arrays, __builtin_amdgcn_mfma) and reads finished values
+// with v_accvgpr_read pairs inside the epilogue steps -- the form that measured 237-240 TFLOP/s with the DMA in a clump
+struct Acc { f32x16 s0[NM], s1[NM]; };
 template <int BASE, bool ZERO>
 __device__ __forceinline__ void mfma_lit(const u32x4& a, const u32x4& b) {
     if constexpr (ZERO) asm volatile("v_mfma_f32_32x32x16_bf16 a[%c0:%c1], %2, %3, 0" ::"n"(BASE), "n"(BASE + 15), "v"(a), "v"(b));
@@ -84,10 +87,15 @@ __device__ __forceinline__ void mfma_lit(const u32x4& a, const u32x4& b) {
 // MFMA I (0..11) of group G (m-tiles 2G, 2G+1) into set NB: product-major, consecutive MFMAs hit different accumulators;
 // FIRST: the layer's first k-step starts the accumulators from 0 (inline constant C operand) instead of clearing them
 template <int NB, int G, int I, bool FIRST>
-__device__ __forceinline__ void mfma_step(const AFrag (&a)[2], const Pieces& b) {
+__device__ __forceinline__ void mfma_step(Acc& A, const AFrag (&a)[2], const Pieces& b) {
     constexpr int pw[6] = {2, 1, 0, 1, 0, 0}, px[6] = {0, 1, 2, 0, 1, 0};      // smallest terms first (tile16.h mfma6)
     constexpr int p = I / 2, t = I % 2, mt = 2 * G + t;
+#ifdef TC_BUILTIN
+    f32x16& acc = NB ? A.s1[mt] : A.s0[mt];
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[t].p[pw[p]]), __builtin_bit_cast(bf16x8, b.p[px[p]]), acc, 0, 0, 0);
+#else
     mfma_lit<NB + 16 * mt, FIRST && p == 0>(a[t].p[pw[p]], b.p[px[p]]);
+#endif
 }
 // the 12 MFMAs of a group, each followed by one epilogue micro-step EBASE + I of m-tile EM (EM < 0: bare MFMAs)
 typedef int i32x4 __attribute__((ext_vector_type(4)));
@@ -125,9 +133,9 @@ __device__ __forceinline__ void ring_advance_read(Ring& R) {
 }
 // DA / DB: the LDS-DMA piece issued after MFMA 3 / MFMA 9 of the group (-1: none)
 template <int NB, int G, int EM, int EBASE, bool FIRST, int DA, int DB, int I>
-__device__ __forceinline__ void group_steps(const AFrag (&a)[2], const Pieces& b, const f32x16& xE, Pieces (&bn)[2], EpiSt& st, Ring& R) {
+__device__ __forceinline__ void group_steps(Acc& A, const AFrag (&a)[2], const Pieces& b, const f32x16& xE, Pieces (&bn)[2], EpiSt& st, Ring& R) {
     if constexpr (I < 12) {
-        mfma_step<NB, G, I, FIRST>(a, b);
+        mfma_step<NB, G, I, FIRST>(A, a, b);
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (I == 3 && DA >= 0) { ring_issue_one<DA>(R); __builtin_amdgcn_sched_barrier(0); }
         if constexpr (I == 9 && DB >= 0) { ring_issue_one<DB>(R); __builtin_amdgcn_sched_barrier(0); }
@@ -135,7 +143,7 @@ __device__ __forceinline__ void group_steps(const AFrag (&a)[2], const Pieces& b
             epi_step<EM, EBASE + I>(xE, bn, st);
             __builtin_amdgcn_sched_barrier(0);
         }
-        group_steps<NB, G, EM, EBASE, FIRST, DA, DB, I + 1>(a, b, xE, bn, st, R);
+        group_steps<NB, G, EM, EBASE, FIRST, DA, DB, I + 1>(A, a, b, xE, bn, st, R);
     }
 }
 
@@ -178,16 +186,16 @@ __device__ __forceinline__ void read_group(AFrag (&a)[2], unsigned addr) {
 // EM / EH: the epilogue m-tile dealt under this k-step's MFMAs (its values in xE) and which half (48 micro-steps) of it.
 // PRE >= 0: in the last group the finished accumulators of m-tile PRE of the OTHER set go accumulator file -> stash -> xPre.
 template <int NB, int EM, int EH, int PRE, bool FIRST>
-__device__ __forceinline__ void kstep(const Pieces& b, const f32x16& xE, Pieces (&bn)[2], EpiSt& st, AFrag (&a0)[2], AFrag (&a1)[2], Ring& R,
+__device__ __forceinline__ void kstep(Acc& A, const Pieces& b, const f32x16& xE, Pieces (&bn)[2], EpiSt& st, AFrag (&a0)[2], AFrag (&a1)[2], Ring& R,
                                       f32x16& xPre) {
     read_group<1>(a1, R.rd_addr);
     __builtin_amdgcn_sched_barrier(0);
-    group_steps<NB, 0, EM, EH * 48 + 0, FIRST, 3, 4, 0>(a0, b, xE, bn, st, R);       // pieces 3, 4 of the stage begun last k-step
+    group_steps<NB, 0, EM, EH * 48 + 0, FIRST, 3, 4, 0>(A, a0, b, xE, bn, st, R);       // pieces 3, 4 of the stage begun last k-step
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
     read_group<2>(a0, R.rd_addr);
     __builtin_amdgcn_sched_barrier(0);
-    group_steps<NB, 1, EM, EH * 48 + 12, FIRST, 5, -1, 0>(a1, b, xE, bn, st, R);     // piece 5: the stage is fully issued
+    group_steps<NB, 1, EM, EH * 48 + 12, FIRST, 5, -1, 0>(A, a1, b, xE, bn, st, R);     // piece 5: the stage is fully issued
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
     // the NEXT k-step's pieces: this wave's DMAs for it have landed once at most DEPTH-1 younger groups are outstanding;
@@ -196,14 +204,16 @@ __device__ __forceinline__ void kstep(const Pieces& b, const f32x16& xE, Pieces 
     asm volatile("s_barrier" ::: "memory");
     read_group<3>(a1, R.rd_addr);
     __builtin_amdgcn_sched_barrier(0);
-    group_steps<NB, 2, EM, EH * 48 + 24, FIRST, 0, 1, 0>(a0, b, xE, bn, st, R);      // a new stage: its slot was freed by the barrier
+    group_steps<NB, 2, EM, EH * 48 + 24, FIRST, 0, 1, 0>(A, a0, b, xE, bn, st, R);      // a new stage: its slot was freed by the barrier
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
     ring_advance_read(R);
     read_group<0>(a0, R.rd_addr);
+#ifndef TC_BUILTIN
     if constexpr (PRE >= 0 && PRE < NM) { stash_write<(128 - NB) + 16 * PRE>(R.stash); stash_read(xPre, R.stash); }
+#endif
     __builtin_amdgcn_sched_barrier(0);
-    group_steps<NB, 3, EM, EH * 48 + 36, FIRST, 2, -1, 0>(a1, b, xE, bn, st, R);
+    group_steps<NB, 3, EM, EH * 48 + 36, FIRST, 2, -1, 0>(A, a1, b, xE, bn, st, R);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
 }
@@ -211,25 +221,36 @@ __device__ __forceinline__ void kstep(const Pieces& b, const f32x16& xE, Pieces 
 // k-steps 2M, 2M+1 of a layer (input pieces = the epilogue of m-tile M of the previous layer) with the epilogue of m-tile M+1
 // dealt under them (its values were brought into xA (M+1 even) / xB (odd) during the previous pair) and m-tile M+2 fetched
 template <int NB, int M, int EPI>
-__device__ __forceinline__ void mpair(f32x16& xA, f32x16& xB, Pieces (&bA)[2], Pieces (&bB)[2], EpiSt& st, AFrag (&a0)[2], AFrag (&a1)[2],
+__device__ __forceinline__ void mpair(Acc& A, f32x16& xA, f32x16& xB, Pieces (&bA)[2], Pieces (&bB)[2], EpiSt& st, AFrag (&a0)[2], AFrag (&a1)[2],
                                       Ring& R) {
     if constexpr (M < NM) {
         constexpr int EM = EPI ? M + 1 : -1, PRE = EPI ? M + 2 : -1;
+#ifdef TC_BUILTIN
+        // the epilogue reads the finished set directly (m-tile M + 1 of the set this layer does NOT write)
+        const f32x16& xO = (NB ? A.s0 : A.s1)[M + 1 < NM ? M + 1 : 0];
+        const f32x16& xE0 = xO; const f32x16& xE1 = xO;
+#else
+        const f32x16& xE0 = xB; const f32x16& xE1 = xA;
+#endif
         // even M: current pieces in bA, next into bB, epilogue values (m-tile M+1, odd) in xB, m-tile M+2 fetched into xA
         if constexpr (M % 2 == 0 || !EPI) {
-            kstep<NB, EM, 0, -1, M == 0>(bA[0], xB, bB, st, a0, a1, R, xA);
-            kstep<NB, EM, 1, PRE, false>(bA[1], xB, bB, st, a0, a1, R, xA);
+            kstep<NB, EM, 0, -1, M == 0>(A, bA[0], xE0, bB, st, a0, a1, R, xA);
+            kstep<NB, EM, 1, PRE, false>(A, bA[1], xE0, bB, st, a0, a1, R, xA);
         } else {
-            kstep<NB, EM, 0, -1, false>(bB[0], xA, bA, st, a0, a1, R, xB);
-            kstep<NB, EM, 1, PRE, false>(bB[1], xA, bA, st, a0, a1, R, xB);
+            kstep<NB, EM, 0, -1, false>(A, bB[0], xE1, bA, st, a0, a1, R, xB);
+            kstep<NB, EM, 1, PRE, false>(A, bB[1], xE1, bA, st, a0, a1, R, xB);
         }
-        mpair<NB, M + 1, EPI>(xA, xB, bA, bB, st, a0, a1, R);
+        mpair<NB, M + 1, EPI>(A, xA, xB, bA, bB, st, a0, a1, R);
     }
 }
 // one layer: accumulates into set NB from the finished set 128 - NB
 template <int NB, int EPI>
-__device__ __forceinline__ void layer(Pieces (&bA)[2], Pieces (&bB)[2], EpiSt& st, AFrag (&a0)[2], AFrag (&a1)[2], Ring& R) {
+__device__ __forceinline__ void layer(Acc& A, Pieces (&bA)[2], Pieces (&bB)[2], EpiSt& st, AFrag (&a0)[2], AFrag (&a1)[2], Ring& R) {
     f32x16 xA, xB;
+#ifdef TC_BUILTIN
+    DH_UNROLL for (int m = 0; m < NM; ++m) DH_UNROLL for (int r = 0; r < 16; ++r) (NB ? A.s1 : A.s0)[m][r] = 0.f;
+    epi_only<0, 0, 96>((NB ? A.s0 : A.s1)[0], bA, st);
+#else
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");        // the previous layer's last MFMAs must have written their results
     stash_write<(128 - NB) + 0>(R.stash); stash_read(xA, R.stash);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -238,8 +259,9 @@ __device__ __forceinline__ void layer(Pieces (&bA)[2], Pieces (&bB)[2], EpiSt& s
     epi_only<0, 0, 96>(xA, bA, st);           // the one exposed epilogue of a layer: m-tile 0
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
+#endif
     if constexpr (!EPI) { bB[0] = bA[0]; bB[1] = bA[1]; }
-    mpair<NB, 0, EPI>(xA, xB, bA, bB, st, a0, a1, R);
+    mpair<NB, 0, EPI>(A, xA, xB, bA, bB, st, a0, a1, R);
 }
 
 // EPI = 0: timing-only arm -- no epilogue at all (the pieces of m-tile 0 feed every k-step): the ceiling of MFMA + weight ring
@@ -255,14 +277,21 @@ __global__ __launch_bounds__(256, 1) void tchain(const bf16x8* __restrict__ wp, 
     R.is_goff = 0;
     R.is_slot = 0; R.rd_slot = 0; R.rd_addr = R.lds_base + lane * 16;
     R.stash = R.lds_base + NSTAGE * STAGE_BYTES + wave * 4096 + lane * 16;
+    Acc A;
+#ifndef TC_BUILTIN
     asm volatile("" ::: TC_ALL_AGPRS);            // the accumulator file is ours: the descriptor must allocate all of it
+#endif
     {                                             // set 0 = "the previous layer's" results: random start values
         float v0[128];
         DH_UNROLL for (int i = 0; i < 128; ++i) {
             unsigned h = (tid * 131u + i + blockIdx.x * 7919u) * 2654435761u; h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
             v0[i] = (float)(h & 0xffffff) * (100.f / 16777216.f);
         }
+#ifdef TC_BUILTIN
+        DH_UNROLL for (int i = 0; i < 128; ++i) { A.s0[i / 16][i % 16] = v0[i]; A.s1[i / 16][i % 16] = 0.f; }
+#else
         acc_write_all(v0);
+#endif
     }
     Pieces bA[2], bB[2];
     EpiSt st;
@@ -277,19 +306,23 @@ __global__ __launch_bounds__(256, 1) void tchain(const bf16x8* __restrict__ wp, 
     __builtin_amdgcn_sched_barrier(0);
     const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
     _Pragma("unroll 1") for (int lp = 0; lp < layer_pairs; ++lp) {
-        layer<128, EPI>(bA, bB, st, a0, a1, R);
-        layer<0, EPI>(bA, bB, st, a0, a1, R);
+        layer<128, EPI>(A, bA, bB, st, a0, a1, R);
+        layer<0, EPI>(A, bA, bB, st, a0, a1, R);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
     if (tid == 0) { clk[blockIdx.x * 2] = t1 - t0; clk[blockIdx.x * 2 + 1] = r1 - r0; }
-    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
     float sum = 0.f;
+#ifdef TC_BUILTIN
+    DH_UNROLL for (int m = 0; m < NM; ++m) DH_UNROLL for (int r = 0; r < 16; ++r) sum += A.s0[m][r];
+#else
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
     f32x16 x;
     stash_write<0>(R.stash); stash_read(x, R.stash);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
     DH_UNROLL for (int r = 0; r < 16; ++r) sum += x[r];
+#endif
     out[blockIdx.x * 256 + tid] = sum;
 }
 

@@ -50,6 +50,7 @@ class HipArm:
     def __init__(self, runner, arithmetic=None, scatter_mode=None):
         self.r, self.arith, self.scatter = runner, arithmetic, scatter_mode
         self.seconds = 0.0
+        self.eval_through_scratch = False
 
     def _modes(self):
         if self.arith is not None:
@@ -63,8 +64,16 @@ class HipArm:
         self.r.store.adam_step(lr)
         return stats[0], stats[5]
 
-    def eval_runner(self, _scratch):
+    def eval_runner(self, scratch):
         self._modes()
+        if self.eval_through_scratch and scratch is not None:
+            # evaluate THIS arm's weights with the scratch Runner's renderer (same sampler for both arms: separates what the
+            # training sampler did to the model from what the evaluation sampler does to the picture)
+            scratch.sdf_network.load_state_dict(self.r.sdf_network.state_dict())
+            scratch.color_network.load_state_dict(self.r.color_network.state_dict())
+            scratch.deviation_network.load_state_dict(self.r.deviation_network.state_dict())
+            scratch.store.bump()
+            return scratch
         return self.r
 
     def perturb(self, rel, seed):
@@ -186,6 +195,10 @@ def run_seed(args, seed, dev):
             A, B = HipArm(r_a, scatter_mode=0), HipArm(r_b, scatter_mode=2)
         elif mode == "hip_occgrid_vs_hierarchical":      # a QUALITY report of the two samplers (hash family), not a parity claim
             A, B = HipArm(r_a), HipArm(r_b)
+            if args.eval_sampler == "hierarchical":      # both arms' weights rendered by the hierarchical sampler
+                scratch = make_runner(args.family, wseed, args.batch, 2, 64, dev, tag + "_scratch")
+                scratch.dataset = ds
+                A.eval_through_scratch = True
         else:
             raise ValueError(mode)
     fp = schedules.FramePermutation(ds.n_images, 4321 + seed)
@@ -283,6 +296,8 @@ def run_parity(argv=None):
     ap.add_argument("--out", type=str, default=None)
     ap.add_argument("--march-samples", type=int, default=None, help="occgrid sampler: marching steps per cube diagonal (default 512)")
     ap.add_argument("--max-samples", type=int, default=None, help="occgrid sampler: capacity in samples per ray (default 128)")
+    ap.add_argument("--eval-sampler", choices=["own", "hierarchical"], default="own",
+                    help="hip_occgrid_vs_hierarchical: evaluate each arm with its own sampler, or both with the hierarchical one")
     args = ap.parse_args(argv)
     if args.march_samples:
         HASH_RENDERER_EXTRA["march_samples_per_ray"] = args.march_samples
@@ -305,7 +320,7 @@ def run_parity(argv=None):
             json.dump({"mode": args.mode, "family": args.family, "seeds": recs}, open(part, "w"))
     res = {"family": args.family, "mode": args.mode, "arms": recs[0]["arms"], "iters": args.iters, "batch": args.batch,
            "frames": args.frames, "res": args.res, "lr": args.lr, "eval_iters": args.eval_iters, "eval_level": args.eval_level,
-           "final_level": args.final_level, "lockstep": args.lockstep, "hash_renderer_extra": dict(HASH_RENDERER_EXTRA),
+           "final_level": args.final_level, "lockstep": args.lockstep, "hash_renderer_extra": dict(HASH_RENDERER_EXTRA), "eval_sampler": args.eval_sampler,
            "protocol": "paired seeds (ray stream + initial weights per seed, shared by both arms); PSNR = masked MSE aggregated over "
                        "ALL frames, rendered by the HIP forward-only path for both arms; window = mean over the eval checkpoints",
            "window_delta": summarize(recs, "window_delta_db"), "final_delta": summarize(recs, "final_delta_db"),

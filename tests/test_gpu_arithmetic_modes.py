@@ -48,3 +48,29 @@ def test_split_bf16_and_fp32_mfma_kernels_agree(tmp_path):
     assert rel < 1e-5
     assert float((dz > 1e-4).float().mean()) < 2e-3        # ill-conditioned inverse-CDF samples only
     assert (cols[0][0] - cols[1][0]).abs().max().item() < 2e-5 and (cols[0][1] - cols[1][1]).abs().max().item() < 2e-4
+
+
+def test_two_renderers_of_one_process_can_run_different_arithmetics(tmp_path):
+    """the arithmetic is a library-wide word, but the Python mirror sets it per renderer before each
+    stage group, so interleaved steps of a split-bf16 Runner and an fp32-MFMA Runner reproduce their own solo results."""
+    from dynhor_amd import _lib
+    from dynhor_amd.runner import Runner
+    base = {"seq_name": "t", "data_info": {"synthetic": {"n_frames": 4, "H": 96, "W": 96, "seed": 11}},
+            "train": {"batch_size": 512, "normal_weight": 0.05, "report_freq": 10 ** 9, "save_freq": 10 ** 9, "val_freq": 0}}
+    mk = lambda name, ar: Runner(conf={**base, "exp_name": name, "model": {"arithmetic": ar}}, device="cuda:0", exp_root=str(tmp_path))
+    try:
+        solo = {}
+        for ar in ("split_bf16", "fp32_mfma"):
+            r = mk("solo_" + ar, ar)
+            for _ in range(3):
+                r.train_iteration()
+            solo[ar] = r.store.flat.clone()
+        a, b = mk("a", "split_bf16"), mk("b", "fp32_mfma")
+        for _ in range(3):
+            a.train_iteration()
+            b.train_iteration()
+        torch.cuda.synchronize()
+        assert torch.equal(a.store.flat, solo["split_bf16"]) and torch.equal(b.store.flat, solo["fp32_mfma"])
+        assert not torch.equal(a.store.flat, b.store.flat), "the two arithmetics differ in the last bits"
+    finally:
+        _lib.set_arithmetic(_lib.ARITH_SPLIT_BF16)
