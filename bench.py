@@ -388,7 +388,7 @@ def main():
                                  "delta": round(w["mean_db"], 4), "se": None if w["n"] < 2 else round(w["se_db"], 4),
                                  "seeds": w["n"], "per_seed_delta": [round(x, 4) for x in w["per_seed"]],
                                  "iters": res["iters"], "protocol": res["protocol"],
-                                 "committed_runs": "profiles/psnr_parity_r02*.json (27 paired seeds neus, 6 hash, noise floors, lock-step)"}
+                                 "committed_runs": "profiles/psnr_parity_r02*.json + psnr_parity_r03*.json (43 paired seeds neus, oracle / HIP noise floors, lock-step; hash: 6 seeds + sampler reports)"}
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.barrier()

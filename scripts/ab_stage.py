@@ -58,6 +58,7 @@ def main():
         "sdf_tangent": lambda: L.dh_sdf_tangent(_p(packed), _p(s.pts), _p(dn), P, _p(s.ws), stream),
         "sdf_backward": lambda: L.dh_sdf_backward(_p(packed), _p(cap["d_sdf"]), P, _p(s.ws), stream),
         "weight_grads_gemm": lambda: L.dh_weight_grads_gemm(P, _p(s.ws), stream),
+        "weight_grads_fold": lambda: L.dh_weight_grads_fold(_p(packed), _p(st.flat), P, _p(s.ws), _p(cap["grad"]), stream),
     }
 
     def time_stage(fn, reps):
@@ -70,7 +71,7 @@ def main():
 
     res = {"lib": args.lib or "libdynhor_hip.so", "stages": {}}
     for name, fn in stages.items():
-        if name == "weight_grads_gemm":
+        if name in ("weight_grads_gemm", "weight_grads_fold"):
             continue
         for _ in range(2):
             _lib.check(fn())
@@ -78,6 +79,11 @@ def main():
         print(name, res["stages"][name], flush=True)
     res["stages"]["weight_grads_gemm"] = time_stage(stages["weight_grads_gemm"], args.reps)
     print("weight_grads_gemm", res["stages"]["weight_grads_gemm"], flush=True)
+    res["stages"]["weight_grads_fold"] = time_stage(stages["weight_grads_fold"], args.reps)
+    print("weight_grads_fold", res["stages"]["weight_grads_fold"], flush=True)
+    g = cap["grad"].double()
+    res["grad_checksum"] = {"l2": float(g.norm()), "sum": float(g.sum())}
+    print("grad checksum", res["grad_checksum"], flush=True)
     if args.stamps:
         import numpy as np
         n = 512 * 4 * 2 * 10 * 8
