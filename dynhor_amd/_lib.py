@@ -97,11 +97,11 @@ ARITH_SPLIT_BF16, ARITH_FP32_MFMA = 0, 1
 # scripts/make_traffic_json.py (rocprofv3 PMC -> HBM bytes per launch) both read THIS table, so a renamed or removed kernel
 # cannot leave a stale entry behind.
 STAGE_KERNELS = {
-    ARITH_SPLIT_BF16: {"weight_grads_gemm": "dw_bf16x3_kernel", "sdf_forward": "sdf_fwd_train_s_kernel",
+    ARITH_SPLIT_BF16: {"weight_grads_gemm": "dw_bf16x3_kernel", "sdf_forward": "sdf_fwd_train_t_kernel",
                        "sdf_gradient": "sdf_grad_s_kernel", "color_forward": "color_fwd_s_kernel",
                        "color_backward": "color_bwd_s_kernel", "sdf_tangent": "sdf_tangent_s_kernel",
-                       "sdf_backward": "sdf_bwd_s_kernel", "sdf_nograd_coarse": "sdf_nograd_s_kernel",
-                       "sdf_nograd_fine": "sdf_nograd_s_kernel"},
+                       "sdf_backward": "sdf_bwd_s_kernel", "sdf_nograd_coarse": "sdf_nograd_t_kernel",
+                       "sdf_nograd_fine": "sdf_nograd_t_kernel"},
     ARITH_FP32_MFMA: {"weight_grads_gemm": "dw_lds_kernel", "sdf_forward": "sdf_fwd_train_kernel",
                       "sdf_gradient": "sdf_grad_kernel", "color_forward": "color_fwd_kernel",
                       "color_backward": "color_bwd_kernel", "sdf_tangent": "sdf_tangent_kernel",

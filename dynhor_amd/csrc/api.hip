@@ -48,7 +48,7 @@ const char* dh_strerror(int status) {
 }
 
 int64_t dh_num_params(void) { return N_PARAMS; }
-int64_t dh_packed_floats(void) { return PACK16.total; }
+int64_t dh_packed_floats(void) { return PACKT.total; }
 
 int dh_param_layout(int net, int layer, int64_t* bias_off, int64_t* g_off, int64_t* v_off, int* out_dim, int* in_dim) {
     if (!bias_off || !g_off || !v_off || !out_dim || !in_dim) return DH_ERR_BAD_ARG;

@@ -1,0 +1,606 @@
+// Register-resident ("transposed") SDF chain, forward only: sdf_nograd_t_kernel   (round 3; scripts/micro/tchain_micro.hip is the
+// timing study this kernel is built from, profiles/r03_ab_register_resident_chain.json its record).
+//
+//   out^T[feature][point] = W[feature][k] * act^T[k][point]: the WEIGHTS are the MFMA A operand, the activations the B operand.  A
+//   wave owns 32 points (the MFMA's column axis = its lane & 31) and ALL 256 features of a layer: 8 accumulators (m-tiles) of
+//   32 x 32.  Accumulator register r of m-tile M on lane (p, h = lane >> 5) holds feature 32 M + 8 (r / 4) + 4 h + (r % 4) of
+//   point p -- which IS the B-operand layout of the next layer's k-steps 2 M (registers 0..7) and 2 M + 1 (registers 8..15) when
+//   the next layer's weights are packed with their k axis permuted to match (pack.hip, PackJob.rev == 2):
+//       hardware k slot (h, i) of k-step s  <->  input feature 16 s + 8 (i / 4) + 4 h + (i % 4).
+//   Activations therefore never leave registers: bias + softplus + ONE 3-way bf16 split per value; no LDS image, no hand-off
+//   barrier, no redundant split.  Two accumulator sets (256 registers, one wave per SIMD): layer l accumulates into set l & 1
+//   while the epilogue of m-tile M + 1 of layer l - 1 is dealt, one micro-step per MFMA, under k-steps 2 M, 2 M + 1 of layer l
+//   (which need only m-tile M).  Only m-tile 0's epilogue is exposed.
+//   Weights enter the CU once per 128 points: an LDS ring of 24 KB stages (one 16-deep k-step of all 256 output features, three
+//   bf16 pieces) filled by LDS-DMA (buffer_load ... lds) dealt singly between MFMAs, one raw s_barrier per k-step; the 116
+//   stages of the network (3 + 16 + 16 + 16 + (14 + 3) + 16 + 16 + 16) are one cyclic stream, so the ring never drains between
+//   layers or tiles.  The per-layer biases and lin8's row 0 sit in LDS (9 KB); the embedding's 24 values per lane are kept
+//   in a wave-private LDS stash for the skip layer.
+// Arithmetic: the same six bf16 products per fp32 product, smallest terms first, as tile16.h.
+#include "mlp_common.h"
+#include "kernels.h"
+
+namespace dh {
+
+constexpr int T_NM = 8;                          // 32-feature m-tiles of a 256-wide layer
+constexpr int T_STAGE_BYTES = T_NM * 3 * 1024;   // one k-step of weight pieces: 8 m-tiles x 3 pieces x 1 KiB fragments
+constexpr int T_DMA = T_NM * 3 / 4;              // 6 LDS-DMA instructions per wave and k-step
+constexpr int T_PTS = 128;                       // points per workgroup tile
+constexpr int T_BIAS_BYTES = 10 * 1024;          // layout.h PACKT.bias10
+constexpr int T_EMB_LD = 52;                     // floats per point of the embedding image (48 + pad: b128 reads of 16 rows conflict free)
+constexpr int T_EMB_BYTES = 32 * T_EMB_LD * 4;   // per wave: its 32 points x [39 embedding values, zero padded to 48]
+constexpr int T_PATCH_LD = 40;                   // floats per feature row of the transposition patch (4 * 40 % 64 == 32: the two half-waves' writes hit different banks)
+constexpr int T_PATCH_BYTES = 32 * T_PATCH_LD * 4;
+static_assert(T_STREAM_STAGES_TRAIN * T_STAGE_BYTES == PACKT_STREAM_FLOATS * 4, "layout.h PACKT");
+
+// NSTAGE ring slots / DEPTH k-steps in flight (NSTAGE >= DEPTH + 2: the barrier sits mid-step); STAGES: length of the cyclic
+// weight stream (the no-grad kernel stops before lin8's rows 1..256)
+struct TCfgNoGrad { static constexpr bool TRAIN = false; static constexpr int NSTAGE = 5, DEPTH = 3, STAGES = T_STREAM_STAGES_NOGRAD; };
+struct TCfgTrain { static constexpr bool TRAIN = true; static constexpr int NSTAGE = 4, DEPTH = 2, STAGES = T_STREAM_STAGES_TRAIN; };
+template <class C> constexpr int t_lds_bytes() { return C::NSTAGE * T_STAGE_BYTES + T_BIAS_BYTES + 4 * T_EMB_BYTES + (C::TRAIN ? 4 * T_PATCH_BYTES : 0); }
+
+struct TPieces { u32x4 p[3]; };                  // one k-step of the activation (B) operand: 3 bf16x8 pieces
+struct TFrag { u32x4 p[3]; };                    // one m-tile's weight (A) fragments of a k-step
+struct TAcc { f32x16 s[2][T_NM]; };
+// epilogue state.  b = the pair's biases (the next pair's are read into the same registers right after their last use).  Training
+// kernel only: w = lin8 row-0 weights of the pair, dot = this lane's partial sdf, patch_wr = the lane's write address in the patch,
+// hd = pair 0's activations on their way to the patch
+struct TEpi { f32x2 x, t, e, u, b, w, hd; float dot0, dot1; unsigned bias_addr, patch_wr; };
+// saving an m-tile as a native tile (tile.h): patch_rd = the lane's read address in the patch, v = two float4 in flight, rsrc =
+// buffer descriptor of the native tile (wave-uniform; zero records when the tile does not exist -- ragged last tile -- so the
+// hardware drops the stores), loff = the lane's byte offset in it (its half of the tile and its lane slot)
+struct TSave { f32x4 v[2]; unsigned patch_rd, loff; __amdgpu_buffer_rsrc_t rsrc; };
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t t_tile_rsrc(const void* tile, bool ok, int bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(tile), 0, ok ? bytes : 0, 0x00020000);
+}
+
+// Every LDS access of this kernel is inline asm: an LDS access the compiler can see makes it wait for ALL outstanding LDS-DMA
+// (vmcnt(0): it cannot prove the access does not alias a DMA's destination), which would drain the ring.  The "_w" forms
+// complete before they return (exposed code: the compiler may move other instructions across a separate s_waitcnt statement);
+// the others are waited for by the lgkmcnt(0) that ends every 12-MFMA group.  An asm output nobody reads is given a register
+// that holds something else by the time the data lands: never issue a read whose result is not used
+// (scripts/isa_inflight_check.py scans the listing for both mistakes; tests/test_cpu_isa_inflight.py).
+template <int OFF>
+__device__ __forceinline__ u32x4 t_lds_b128(unsigned addr) {
+    u32x4 v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+    return v;
+}
+template <int OFF>
+__device__ __forceinline__ void t_lds_read(f32x4& v, unsigned addr) { asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF)); }
+template <int OFF>
+__device__ __forceinline__ f32x4 t_lds_read_w(unsigned addr) {
+    f32x4 v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+    return v;
+}
+// four float4 at byte offsets O0..O3 from addr, complete when the statement ends (one LDS latency for the four)
+template <int O0, int O1, int O2, int O3>
+__device__ __forceinline__ void t_lds_read4_w(f32x4& a, f32x4& b, f32x4& c, f32x4& d, unsigned addr) {
+    asm volatile("ds_read_b128 %0, %4 offset:%5\n\tds_read_b128 %1, %4 offset:%6\n\tds_read_b128 %2, %4 offset:%7\n\tds_read_b128 %3, %4 offset:%8\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(d) : "v"(addr), "n"(O0), "n"(O1), "n"(O2), "n"(O3) : "memory");
+}
+// four floats likewise
+template <int O0, int O1, int O2, int O3>
+__device__ __forceinline__ f32x4 t_lds_read32x4_w(unsigned addr) {
+    float a, b, c, d;
+    asm volatile("ds_read_b32 %0, %4 offset:%5\n\tds_read_b32 %1, %4 offset:%6\n\tds_read_b32 %2, %4 offset:%7\n\tds_read_b32 %3, %4 offset:%8\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(d) : "v"(addr), "n"(O0), "n"(O1), "n"(O2), "n"(O3) : "memory");
+    return f32x4{a, b, c, d};
+}
+template <int OFF>
+__device__ __forceinline__ float t_lds_read32_w(unsigned addr) {
+    float v;
+    asm volatile("ds_read_b32 %0, %1 offset:%2\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+    return v;
+}
+template <int OFF>
+__device__ __forceinline__ void t_lds_write_b32(unsigned addr, float v) { asm volatile("ds_write_b32 %0, %1 offset:%2" ::"v"(addr), "v"(v), "n"(OFF) : "memory"); }
+// bias pair of (m-tile M, pair J): features 32 M + 8 (J / 2) + 2 (J % 2) + 4 h, +1   (addr carries the row and 16 h)
+template <int M, int J, int ROWOFF = 0>
+__device__ __forceinline__ void t_bias_read(f32x2& dst, unsigned addr) {
+    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(ROWOFF + (32 * M + 8 * (J / 2) + 2 * (J % 2)) * 4));
+}
+template <int M, int J, int ROWOFF = 0>
+__device__ __forceinline__ void t_bias_read_w(f32x2& dst, unsigned addr) {
+    asm volatile("ds_read_b64 %0, %1 offset:%2\n\ts_waitcnt lgkmcnt(0)" : "=v"(dst) : "v"(addr), "n"(ROWOFF + (32 * M + 8 * (J / 2) + 2 * (J % 2)) * 4) : "memory");
+}
+
+// one micro-step of the epilogue of m-tile M whose 16 finished values are x: pair j = STEP / 12 = values 2j, 2j+1 -> u32 j % 4 of
+// the pieces of k-step half j / 4.  12 steps of 2-4 vector ops: + bias, -|x| c, exp2, 1 + e, log2, max, fma, then the 3-way split.
+// Step 1 also issues the bias read of the next pair; after the last pair that of the next m-tile's first pair -- only if NEXT
+// says that m-tile's epilogue will run.  EXPOSED: outside the MFMA stream, blocking reads.  SAVE (training kernel): the pair's
+// activations also go to the transposition patch; DOT (training kernel, lin7's output): and into lin8's row 0 (its weights sit
+// one bias row further, read beside the bias pair).
+template <int M, int STEP, bool NEXT, bool EXPOSED, bool SAVE, bool DOT>
+__device__ __forceinline__ void t_epi_step(const f32x16& x, TPieces (&out)[2], TEpi& st) {
+    constexpr int j = STEP / 12, s = STEP % 12, half = j / 4, q = j % 4, r0 = 2 * j;
+    constexpr int PW = (8 * (r0 / 4) + r0 % 4) * T_PATCH_LD * 4;           // patch row of value r0 (this lane's 4 h rows are in patch_wr)
+    if constexpr (s == 0) { st.x[0] = x[r0] + st.b[0]; }
+    else if constexpr (s == 1) {
+        st.x[1] = x[r0 + 1] + st.b[1];
+        if constexpr (EXPOSED) {
+            if constexpr (j < 7) t_bias_read_w<M, j + 1>(st.b, st.bias_addr);
+            else if constexpr (NEXT) t_bias_read_w<M + 1, 0>(st.b, st.bias_addr);
+        } else {
+            if constexpr (j < 7) t_bias_read<M, j + 1>(st.b, st.bias_addr);
+            else if constexpr (NEXT) t_bias_read<M + 1, 0>(st.b, st.bias_addr);
+        }
+    }
+    else if constexpr (s == 2) { st.t[0] = -fabsf(st.x[0]) * (SOFTPLUS_BETA * 1.44269504088896f); st.t[1] = -fabsf(st.x[1]) * (SOFTPLUS_BETA * 1.44269504088896f); }
+    else if constexpr (s == 3) { st.e[0] = __builtin_amdgcn_exp2f(st.t[0]); st.e[1] = __builtin_amdgcn_exp2f(st.t[1]); }
+    else if constexpr (s == 4) {
+        st.e[0] = 1.f + st.e[0]; st.e[1] = 1.f + st.e[1];
+        if constexpr (SAVE && !EXPOSED && j == 1) t_lds_write_b32<0>(st.patch_wr, st.hd[0]);                    // pair 0's, deferred (below)
+    }
+    else if constexpr (s == 5) {
+        st.e[0] = __builtin_amdgcn_logf(st.e[0]); st.e[1] = __builtin_amdgcn_logf(st.e[1]);
+        if constexpr (SAVE && !EXPOSED && j == 1) t_lds_write_b32<T_PATCH_LD * 4>(st.patch_wr, st.hd[1]);
+    }
+    else if constexpr (s == 6) { st.t[0] = fmaxf(st.x[0], 0.f); st.t[1] = fmaxf(st.x[1], 0.f); }
+    else if constexpr (s == 7) {
+        st.x[0] = fmaf(st.e[0], 0.69314718055995f / SOFTPLUS_BETA, st.t[0]); st.x[1] = fmaf(st.e[1], 0.69314718055995f / SOFTPLUS_BETA, st.t[1]);
+        // dealt under a k-step, pair 0 is finished in group 0 while the PREVIOUS m-tile's patch is still being read (its last two
+        // float4 leave in group 1, slots 2-3): pair 0's two values wait in hd until pair 1's steps 4 and 5 (group 1, slots 4-5)
+        if constexpr (SAVE && !EXPOSED && j == 0) st.hd = st.x;
+        else if constexpr (SAVE) t_lds_write_b32<PW>(st.patch_wr, st.x[0]);
+        if constexpr (DOT) { st.dot0 = fmaf(st.x[0], st.w[0], st.dot0); st.dot1 = fmaf(st.x[1], st.w[1], st.dot1); }
+    }
+    else if constexpr (s == 8) {
+        if constexpr (SAVE && (EXPOSED || j > 0)) t_lds_write_b32<PW + T_PATCH_LD * 4>(st.patch_wr, st.x[1]);
+        const unsigned h = pack_bf16x2(st.x); out[half].p[0][q] = h; st.u = unpack_bf16x2(h);
+        if constexpr (DOT) {            // the next pair's row-0 weights (this pair's were last used in step 7)
+            if constexpr (EXPOSED) {
+                if constexpr (j < 7) t_bias_read_w<M, j + 1, 1024>(st.w, st.bias_addr);
+                else if constexpr (NEXT) t_bias_read_w<M + 1, 0, 1024>(st.w, st.bias_addr);
+            } else {
+                if constexpr (j < 7) t_bias_read<M, j + 1, 1024>(st.w, st.bias_addr);
+                else if constexpr (NEXT) t_bias_read<M + 1, 0, 1024>(st.w, st.bias_addr);
+            }
+        }
+    }
+    else if constexpr (s == 9) { st.x[0] -= st.u[0]; st.x[1] -= st.u[1]; }
+    else if constexpr (s == 10) { const unsigned h = pack_bf16x2(st.x); out[half].p[1][q] = h; st.u = unpack_bf16x2(h); }
+    else { st.x[0] -= st.u[0]; st.x[1] -= st.u[1]; out[half].p[2][q] = pack_bf16x2(st.x); }
+}
+
+struct TRing {
+    unsigned rd_addr;          // LDS byte address of the slot being read + lane * 16
+    unsigned rd_slot;
+    unsigned is_slot;          // slot the stage being issued goes to
+    unsigned is_goff;          // byte offset of that stage in the packed stream (wraps over the kernel's stages)
+    __amdgpu_buffer_rsrc_t rsrc;
+    unsigned lds_base;
+    char* lds;
+    int wave, lane;
+};
+// One LDS-DMA of the stage being issued: fragment wave + 4 i (1 KiB: 64 lanes x 16 B)
+template <class C, int I>
+__device__ __forceinline__ void t_ring_issue_one(TRing& R) {
+    const unsigned frag = R.wave + 4 * I;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(R.rsrc, (__attribute__((address_space(3))) void*)(R.lds + R.is_slot * T_STAGE_BYTES + frag * 1024),
+                                             16, R.lane * 16, R.is_goff + frag * 1024, 0, 0);
+    if constexpr (I == T_DMA - 1) {
+        R.is_slot = (R.is_slot + 1 == C::NSTAGE) ? 0 : R.is_slot + 1;
+        R.is_goff = (R.is_goff + T_STAGE_BYTES == (unsigned)(C::STAGES * T_STAGE_BYTES)) ? 0 : R.is_goff + T_STAGE_BYTES;
+    }
+}
+template <class C>
+__device__ __forceinline__ void t_ring_advance_read(TRing& R) {
+    R.rd_slot = (R.rd_slot + 1 == C::NSTAGE) ? 0 : R.rd_slot + 1;
+    R.rd_addr = R.lds_base + R.rd_slot * T_STAGE_BYTES + R.lane * 16;
+}
+template <int G>
+__device__ __forceinline__ void t_read_group(TFrag (&a)[2], unsigned addr) {
+    DH_UNROLL for (int t = 0; t < 2; ++t) {
+        a[t].p[0] = t_lds_b128<((2 * G + 0) * 3 + 0) * 1024>(addr + t * 3072);
+        a[t].p[1] = t_lds_b128<((2 * G + 0) * 3 + 1) * 1024>(addr + t * 3072);
+        a[t].p[2] = t_lds_b128<((2 * G + 0) * 3 + 2) * 1024>(addr + t * 3072);
+    }
+}
+
+// float offset of float4 r4 of m-tile M inside a wave's half of a native [64 x 256] tile (tile.h: float4 index
+// (((w*MT + m)*2 + t)*4 + r4)*64 + lane with w = M / 2, t = M % 2; the m and lane terms are in TSave::base)
+constexpr int t_native_off(int M, int r4) { return (M / 2) * 4096 + (M % 2) * 1024 + r4 * 256; }
+template <int M, int R4>
+__device__ __forceinline__ void t_save_store(const TSave& sv) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, sv.v[R4 & 1]), sv.rsrc, sv.loff + 4 * t_native_off(M, R4), 0, 2);     // nt, as DH_TILE_ST
+}
+
+// MFMA I (0..11) of group G (m-tiles 2G, 2G+1) into set NB: product-major, consecutive MFMAs hit different accumulators
+template <int NB, int G, int I>
+__device__ __forceinline__ void t_mfma_step(TAcc& A, const TFrag (&a)[2], const TPieces& b) {
+    constexpr int pw[6] = {2, 1, 0, 1, 0, 0}, px[6] = {0, 1, 2, 0, 1, 0};      // smallest terms first (tile16.h mfma6)
+    constexpr int p = I / 2, t = I % 2, mt = 2 * G + t;
+    A.s[NB][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[t].p[pw[p]]), __builtin_bit_cast(bf16x8, b.p[px[p]]),
+                                                          A.s[NB][mt], 0, 0, 0);
+}
+// What is dealt under one k-step's MFMAs (compile-time): the accumulator set NB it writes; the epilogue m-tile EM of the OTHER
+// set (-1: none) and which half EH of its 96 micro-steps; ENEXT: m-tile EM + 1 follows; SM (training kernel): the m-tile whose
+// patch is complete -- two of its float4 are read in group 0 and stored in group 1, the other two read in group 1 and stored in
+// group 2 (-1: none); DOT: see t_epi_step
+template <class C_, int NB_, int EM_, int EH_, bool ENEXT_, int SM_, bool DOT_>
+struct TK {
+    using C = C_;
+    static constexpr int NB = NB_, EM = EM_, EH = EH_, SM = SM_;
+    static constexpr bool ENEXT = ENEXT_, DOT = DOT_;
+};
+// the 12 MFMAs of group G, each followed by its share of the dealt work; DA / DB: the LDS-DMA piece issued after MFMA 3 / 9 (-1: none)
+template <class K, int G, int DA, int DB, int I>
+__device__ __forceinline__ void t_group_steps(TAcc& A, const TFrag (&a)[2], const TPieces& b, TPieces (&bn)[2], TEpi& st, TRing& R, TSave& sv) {
+    if constexpr (I < 12) {
+        t_mfma_step<K::NB, G, I>(A, a, b);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (I == 3 && DA >= 0) { t_ring_issue_one<typename K::C, DA>(R); __builtin_amdgcn_sched_barrier(0); }
+        if constexpr (I == 9 && DB >= 0) { t_ring_issue_one<typename K::C, DB>(R); __builtin_amdgcn_sched_barrier(0); }
+        if constexpr (K::C::TRAIN && K::SM >= 0 && I < 4) {
+            if constexpr (G == 0 && I < 2) { t_lds_read<32 * I>(sv.v[I], sv.patch_rd); __builtin_amdgcn_sched_barrier(0); }
+            if constexpr (G == 1 && I < 2) { t_save_store<K::SM, I>(sv); __builtin_amdgcn_sched_barrier(0); }
+            if constexpr (G == 1 && I >= 2) { t_lds_read<32 * I>(sv.v[I - 2], sv.patch_rd); __builtin_amdgcn_sched_barrier(0); }
+            if constexpr (G == 2 && I < 2) { t_save_store<K::SM, I + 2>(sv); __builtin_amdgcn_sched_barrier(0); }
+        }
+        if constexpr (K::EM >= 0 && K::EM < T_NM) {
+            t_epi_step<K::EM, K::EH * 48 + 12 * G + I, K::ENEXT, false, K::C::TRAIN, K::DOT>(A.s[1 - K::NB][K::EM], bn, st);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        t_group_steps<K, G, DA, DB, I + 1>(A, a, b, bn, st, R, sv);
+    }
+}
+
+// one k-step: entering, a0 holds group 0's fragments; leaving, a0 holds group 0 of the NEXT stage of the stream
+template <class K>
+__device__ __forceinline__ void t_kstep(TAcc& A, const TPieces& b, TPieces (&bn)[2], TEpi& st, TFrag (&a0)[2], TFrag (&a1)[2], TRing& R, TSave& sv) {
+    using C = typename K::C;
+    t_read_group<1>(a1, R.rd_addr);
+    __builtin_amdgcn_sched_barrier(0);
+    t_group_steps<K, 0, 3, 4, 0>(A, a0, b, bn, st, R, sv);        // pieces 3, 4 of the stage begun last k-step
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    t_read_group<2>(a0, R.rd_addr);
+    __builtin_amdgcn_sched_barrier(0);
+    t_group_steps<K, 1, 5, -1, 0>(A, a1, b, bn, st, R, sv);       // piece 5: the stage is fully issued
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    // the NEXT k-step's pieces: this wave's DMAs for it have landed once at most DEPTH-1 younger groups are outstanding (tile
+    // stores in flight count too and only make the wait stricter); after the barrier everyone's have, and everyone has left the
+    // previous k-step (its slot may be refilled)
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(T_DMA * (C::DEPTH - 1)) : "memory");
+    asm volatile("s_barrier" ::: "memory");
+    t_read_group<3>(a1, R.rd_addr);
+    __builtin_amdgcn_sched_barrier(0);
+    t_group_steps<K, 2, 0, 1, 0>(A, a0, b, bn, st, R, sv);        // a new stage: its slot was freed by the barrier
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    t_ring_advance_read<C>(R);
+    t_read_group<0>(a0, R.rd_addr);
+    __builtin_amdgcn_sched_barrier(0);
+    t_group_steps<K, 3, 2, -1, 0>(A, a1, b, bn, st, R, sv);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+template <class C, int NB>
+using TBare = TK<C, NB, -1, 0, false, -1, false>;
+
+template <int NB>
+__device__ __forceinline__ void t_zero(TAcc& A) {
+    DH_UNROLL for (int m = 0; m < T_NM; ++m) DH_UNROLL for (int r = 0; r < 16; ++r) A.s[NB][m][r] = 0.f;
+}
+template <int M, int I, int N, bool SAVE, bool DOT>
+__device__ __forceinline__ void t_epi_only(const f32x16& x, TPieces (&out)[2], TEpi& st) {
+    if constexpr (I < N) {
+        t_epi_step<M, I, true, true, SAVE, DOT>(x, out, st);
+        t_epi_only<M, I + 1, N, SAVE, DOT>(x, out, st);
+    }
+}
+// k-steps 2M, 2M+1 (input pieces = the epilogue of m-tile M of the source set) with the epilogue of m-tile M+1 dealt under them
+// and (training kernel) m-tile M saved; MEND: m-tiles of the source the layer consumes (8; the skip layer takes 7 of lin3's)
+template <class C, int NB, int M, int MEND, bool DOT>
+__device__ __forceinline__ void t_mpair(TAcc& A, TPieces (&bA)[2], TPieces (&bB)[2], TEpi& st, TFrag (&a0)[2], TFrag (&a1)[2], TRing& R, TSave& sv) {
+    if constexpr (M < MEND) {
+        constexpr int EM = M + 1 < MEND ? M + 1 : -1;
+        constexpr bool EN = M + 2 < MEND;                 // m-tile EM + 1 will have its epilogue dealt too
+        using K0 = TK<C, NB, EM, 0, EN, M, DOT>;
+        using K1 = TK<C, NB, EM, 1, EN, -1, DOT>;
+        if constexpr (M % 2 == 0) {
+            t_kstep<K0>(A, bA[0], bB, st, a0, a1, R, sv);
+            t_kstep<K1>(A, bA[1], bB, st, a0, a1, R, sv);
+        } else {
+            t_kstep<K0>(A, bB[0], bA, st, a0, a1, R, sv);
+            t_kstep<K1>(A, bB[1], bA, st, a0, a1, R, sv);
+        }
+        t_mpair<C, NB, M + 1, MEND, DOT>(A, bA, bB, st, a0, a1, R, sv);
+    }
+}
+// the main part of a layer: accumulates MEND * 32 input features into set NB from the finished set 1 - NB, whose bias row is
+// at bias_row (LDS byte address, + 16 h); training kernel: the source layer's activations go to the native tile sv.base points at
+template <class C, int NB, int MEND, bool DOT = false>
+__device__ __forceinline__ void t_layer(TAcc& A, TPieces (&bA)[2], TPieces (&bB)[2], TEpi& st, TFrag (&a0)[2], TFrag (&a1)[2], TRing& R, TSave& sv,
+                                        unsigned bias_row) {
+    t_zero<NB>(A);
+    st.bias_addr = bias_row;
+    t_bias_read_w<0, 0>(st.b, st.bias_addr);
+    if constexpr (DOT) t_bias_read_w<0, 0, 1024>(st.w, st.bias_addr);
+    t_epi_only<0, 0, 96, C::TRAIN, DOT>(A.s[1 - NB][0], bA, st);      // the one exposed epilogue of a layer: m-tile 0 (leaves m-tile 1's first pair in b[0])
+    __builtin_amdgcn_sched_barrier(0);
+    t_mpair<C, NB, 0, MEND, DOT>(A, bA, bB, st, a0, a1, R, sv);
+}
+
+// Embedding image of the wave's 32 points in its private LDS rows: [x, sin(2^k x), cos(2^k x)]_{k<6}, zero padded to 48
+// (mlp_common.h embed_tile's order).  The two lanes of a point share the work: h = 0 takes frequencies 0..2, h = 1 3..5.
+__device__ __forceinline__ void t_embed_rows(const float (&x)[3], unsigned row, int h) {
+    if (h == 0) { t_lds_write_b32<0>(row, x[0]); t_lds_write_b32<4>(row, x[1]); t_lds_write_b32<8>(row, x[2]); }
+    else {
+        t_lds_write_b32<4 * 39>(row, 0.f); t_lds_write_b32<4 * 40>(row, 0.f); t_lds_write_b32<4 * 41>(row, 0.f);
+        t_lds_write_b32<4 * 42>(row, 0.f); t_lds_write_b32<4 * 43>(row, 0.f); t_lds_write_b32<4 * 44>(row, 0.f);
+        t_lds_write_b32<4 * 45>(row, 0.f); t_lds_write_b32<4 * 46>(row, 0.f); t_lds_write_b32<4 * 47>(row, 0.f);
+    }
+    _Pragma("unroll 1") for (int kk = 0; kk < 3; ++kk) {
+        const int k = 3 * h + kk;
+        const float f = (float)(1 << k);
+        const unsigned rk = row + 24 * k;
+        float sn, co;
+        sincosf(x[0] * f, &sn, &co); t_lds_write_b32<12>(rk, sn); t_lds_write_b32<24>(rk, co);
+        sincosf(x[1] * f, &sn, &co); t_lds_write_b32<16>(rk, sn); t_lds_write_b32<28>(rk, co);
+        sincosf(x[2] * f, &sn, &co); t_lds_write_b32<20>(rk, sn); t_lds_write_b32<32>(rk, co);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+// 8 fp32 of one k-step (this lane's slots i = 0..7) -> pieces
+__device__ __forceinline__ TPieces t_split8(const f32x4& lo, const f32x4& hi) {
+    const Bf3 b = split3(lo, hi);
+    TPieces r;
+    DH_UNROLL for (int p = 0; p < 3; ++p) r.p[p] = __builtin_bit_cast(u32x4, b.p[p]);
+    return r;
+}
+// the three k-steps of the embedding as B pieces: lane (p, h) holds features 16 s + 8 g + 4 h + (0..3), g = 0, 1 of k-step s
+__device__ __forceinline__ void t_embed_pieces(unsigned row_h, TPieces& e0, TPieces& e1, TPieces& e2) {
+    e0 = t_split8(t_lds_read_w<0>(row_h), t_lds_read_w<32>(row_h));
+    e1 = t_split8(t_lds_read_w<64>(row_h), t_lds_read_w<96>(row_h));
+    e2 = t_split8(t_lds_read_w<128>(row_h), t_lds_read_w<160>(row_h));
+}
+// training kernel: the wave's half of the aux native tile ([64 x 64], tile.h aux_store_native) from the embedding image: lane L's
+// float4 (t, r4) = column 32 t + (L & 31) of points 8 r4 + 4 (L >> 5) + (0..3).  col_addr = image + (4 (L>>5) rows, column L&31)
+template <int I>
+__device__ __forceinline__ void t_store_eaux(unsigned col_addr, int fl, __amdgpu_buffer_rsrc_t rsrc, unsigned loff) {
+    if constexpr (I < 8) {
+        constexpr int t = I / 4, r4 = I % 4;
+        f32x4 v = t_lds_read32x4_w<((8 * r4 + 0) * T_EMB_LD + 32 * t) * 4, ((8 * r4 + 1) * T_EMB_LD + 32 * t) * 4,
+                                   ((8 * r4 + 2) * T_EMB_LD + 32 * t) * 4, ((8 * r4 + 3) * T_EMB_LD + 32 * t) * 4>(col_addr);
+        if (32 * t + fl >= EMB) v = f32x4{0.f, 0.f, 0.f, 0.f};                   // the image is zero only up to column 47
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsrc, loff + 4 * (t * 4 + r4) * 256, 0, 0);
+        t_store_eaux<I + 1>(col_addr, fl, rsrc, loff);
+    }
+}
+
+// lin8 row 0 on softplus(lin7 + bias): this lane's 128 features of its point (accumulator set 1)   [no-grad kernel]
+template <int M>
+__device__ __forceinline__ void t_final_dot(const TAcc& A, unsigned bias_base, float& s0, float& s1) {
+    if constexpr (M < T_NM) {
+        f32x4 bb[4], ww[4];
+        t_lds_read4_w<7 * 1024 + 4 * (32 * M), 7 * 1024 + 4 * (32 * M + 8), 7 * 1024 + 4 * (32 * M + 16), 7 * 1024 + 4 * (32 * M + 24)>(bb[0], bb[1], bb[2], bb[3], bias_base);
+        t_lds_read4_w<8 * 1024 + 4 * (32 * M), 8 * 1024 + 4 * (32 * M + 8), 8 * 1024 + 4 * (32 * M + 16), 8 * 1024 + 4 * (32 * M + 24)>(ww[0], ww[1], ww[2], ww[3], bias_base);
+        DH_UNROLL for (int r4 = 0; r4 < 4; ++r4) {
+            s0 = fmaf(softplus100(A.s[1][M][4 * r4 + 0] + bb[r4][0]), ww[r4][0], s0);
+            s1 = fmaf(softplus100(A.s[1][M][4 * r4 + 1] + bb[r4][1]), ww[r4][1], s1);
+            s0 = fmaf(softplus100(A.s[1][M][4 * r4 + 2] + bb[r4][2]), ww[r4][2], s0);
+            s1 = fmaf(softplus100(A.s[1][M][4 * r4 + 3] + bb[r4][3]), ww[r4][3], s1);
+        }
+        t_final_dot<M + 1>(A, bias_base, s0, s1);
+    }
+}
+// training kernel: lin8 rows 1..256 (accumulator set 0) + their bias (row 9) -> the feature tile, m-tile by m-tile through the patch
+template <int M>
+__device__ __forceinline__ void t_store_feat(const TAcc& A, unsigned bias_base, const TEpi& st, TSave& sv) {
+    if constexpr (M < T_NM) {
+        f32x4 bb[4];
+        t_lds_read4_w<9 * 1024 + 4 * (32 * M), 9 * 1024 + 4 * (32 * M + 8), 9 * 1024 + 4 * (32 * M + 16), 9 * 1024 + 4 * (32 * M + 24)>(bb[0], bb[1], bb[2], bb[3], bias_base);
+        DH_UNROLL for (int g = 0; g < 4; ++g)
+            DH_UNROLL for (int i = 0; i < 4; ++i) {
+                const float v = A.s[0][M][4 * g + i] + bb[g][i];
+                const unsigned a = st.patch_wr + (8 * g + i) * T_PATCH_LD * 4;
+                asm volatile("ds_write_b32 %0, %1" ::"v"(a), "v"(v) : "memory");
+            }
+        f32x4 o[4];
+        t_lds_read4_w<0, 32, 64, 96>(o[0], o[1], o[2], o[3], sv.patch_rd);
+        sv.v[0] = o[0]; sv.v[1] = o[1];
+        t_save_store<M, 0>(sv); t_save_store<M, 1>(sv);
+        sv.v[0] = o[2]; sv.v[1] = o[3];
+        t_save_store<M, 2>(sv); t_save_store<M, 3>(sv);
+        t_store_feat<M + 1>(A, bias_base, st, sv);
+    }
+}
+
+#ifdef DH_T_DEBUG
+// development build: the raw accumulators (pre-bias) of layer dbg_layer as [npts][256]
+template <int NB>
+__device__ __forceinline__ void t_dump(const TAcc& A, float* dbg, int64_t gp, int64_t npts, int h) {
+    if (gp >= npts) return;
+    DH_UNROLL for (int m = 0; m < T_NM; ++m)
+        DH_UNROLL for (int r = 0; r < 16; ++r) dbg[gp * 256 + 32 * m + 8 * (r / 4) + 4 * h + (r % 4)] = A.s[NB][m][r];
+}
+#define T_DUMP(NB, L) if (dbg_layer == (L)) t_dump<NB>(A, dbg, gp, npts, h)
+#define T_DBG_PARAMS , float* dbg, int dbg_layer
+#else
+#define T_DUMP(NB, L)
+#define T_DBG_PARAMS
+#endif
+
+// C = TCfgNoGrad: sdf only.  C = TCfgTrain: also the saved tiles of the training forward (act[l] = softplus(lin_l), l = 0..7, feat =
+// lin8 rows 1..256, eaux = the embedding) in the layouts of sdf_fwd_train_kernel (tile.h native tiles of 64 points: a workgroup
+// tile is two of them, waves 0-1 and 2-3).
+template <class C>
+__device__ __forceinline__ void sdf_chain_t_body(const void* __restrict__ stream, const float* __restrict__ bias10,
+                                                 const float* __restrict__ b8_0, const float* __restrict__ pts, int64_t npts,
+                                                 float* __restrict__ sdf_out, float* __restrict__ feat, float* __restrict__ act,
+                                                 float* __restrict__ eaux T_DBG_PARAMS) {
+    __shared__ __attribute__((aligned(16))) char lds[t_lds_bytes<C>()];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5, p = lane & 31;
+    float* lbias = reinterpret_cast<float*>(lds + C::NSTAGE * T_STAGE_BYTES);
+    for (int i = tid; i < T_BIAS_BYTES / 4; i += 256) lbias[i] = bias10[i];
+    TRing R;
+    R.lds = lds; R.lds_base = (unsigned)(uintptr_t)lds; R.wave = wave; R.lane = lane;
+    R.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(stream), 0, C::STAGES * T_STAGE_BYTES, 0x00020000);
+    R.is_goff = 0; R.is_slot = 0; R.rd_slot = 0; R.rd_addr = R.lds_base + lane * 16;
+    const unsigned bias_base = R.lds_base + C::NSTAGE * T_STAGE_BYTES + 16 * h;
+    const unsigned emb_wave = R.lds_base + C::NSTAGE * T_STAGE_BYTES + T_BIAS_BYTES + wave * T_EMB_BYTES;
+    const unsigned emb_row = emb_wave + p * (T_EMB_LD * 4);
+    TAcc A;
+    TPieces bA[2], bB[2];
+    TEpi st;
+    TSave sv;
+    TFrag a0[2], a1[2];
+    if constexpr (C::TRAIN) {
+        const unsigned patch = R.lds_base + C::NSTAGE * T_STAGE_BYTES + T_BIAS_BYTES + 4 * T_EMB_BYTES + wave * T_PATCH_BYTES;
+        st.patch_wr = patch + (4 * h * T_PATCH_LD + p) * 4;
+        sv.patch_rd = patch + (p * T_PATCH_LD + 4 * h) * 4;
+    }
+    // ring prologue: DEPTH full stages + the first 3 pieces of the next (the steady state enters a k-step with 3 of 6 issued)
+    for (int d = 0; d < C::DEPTH; ++d) {
+        t_ring_issue_one<C, 0>(R); t_ring_issue_one<C, 1>(R); t_ring_issue_one<C, 2>(R); t_ring_issue_one<C, 3>(R); t_ring_issue_one<C, 4>(R); t_ring_issue_one<C, 5>(R);
+    }
+    t_ring_issue_one<C, 0>(R); t_ring_issue_one<C, 1>(R); t_ring_issue_one<C, 2>(R);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(T_DMA * (C::DEPTH - 1) + 3) : "memory");
+    __syncthreads();                                  // stage 0 has landed for every wave; the bias table is written
+    t_read_group<0>(a0, R.rd_addr);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+
+    const int64_t ntiles = (npts + T_PTS - 1) / T_PTS, ntiles64 = (npts + TM - 1) / TM;
+    // a tile's points are fetched while the previous tile's last exposed section runs (a load issued at the tile's start would
+    // be waited for at once, behind every LDS-DMA in flight)
+    float xn[3] = {0.f, 0.f, 0.f};
+    {
+        const int64_t g0 = (int64_t)blockIdx.x * T_PTS + wave * 32 + p;
+        if (g0 < npts) { xn[0] = pts[g0 * 3 + 0]; xn[1] = pts[g0 * 3 + 1]; xn[2] = pts[g0 * 3 + 2]; }
+    }
+    _Pragma("unroll 1") for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t gp = tile * T_PTS + wave * 32 + p;
+        // training kernel: this wave's half (m = wave & 1) of native tile tile64; lane part of every native address
+        const int64_t tile64 = 2 * tile + (wave >> 1);
+        const char* act_tile = nullptr;                 // act[0]'s native tile; act[l] is l * lstride further
+        const int64_t lstride = ntiles64 * TILE_F * 4;
+        const bool tile_ok = tile64 < ntiles64;
+        if constexpr (C::TRAIN) {
+            sv.loff = ((wave & 1) * 2048 + lane * 4) * 4;
+            act_tile = reinterpret_cast<const char*>(act + tile64 * TILE_F);
+        }
+        {   // embedding
+            const float x[3] = {xn[0], xn[1], xn[2]};
+            t_embed_rows(x, emb_row, h);
+            t_embed_pieces(emb_row + 16 * h, bA[0], bA[1], bB[0]);
+            if constexpr (C::TRAIN)
+                t_store_eaux<0>(emb_wave + (4 * h * T_EMB_LD + p) * 4, p, t_tile_rsrc(eaux + tile64 * AUXT_F, tile_ok, AUXT_F * 4), sv.loff);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // lin0: 3 k-steps of the embedding into set 0
+        t_zero<0>(A);
+        t_kstep<TBare<C, 0>>(A, bA[0], bB, st, a0, a1, R, sv);
+        t_kstep<TBare<C, 0>>(A, bA[1], bB, st, a0, a1, R, sv);
+        t_kstep<TBare<C, 0>>(A, bB[0], bA, st, a0, a1, R, sv);
+        T_DUMP(0, 0);
+        _Pragma("unroll 1") for (int q = 0; q < 2; ++q) {
+            // (the training kernel saves the SOURCE layer of each call: act[4q], act[4q+1], act[4q+2], act[3])
+            if constexpr (C::TRAIN) sv.rsrc = t_tile_rsrc(act_tile + (4 * q + 0) * lstride, tile_ok, TILE_F * 4);
+            t_layer<C, 1, 8>(A, bA, bB, st, a0, a1, R, sv, bias_base + (4 * q + 0) * 1024);        // lin1 / lin5
+            T_DUMP(1, 4 * q + 1);
+            if constexpr (C::TRAIN) sv.rsrc = t_tile_rsrc(act_tile + (4 * q + 1) * lstride, tile_ok, TILE_F * 4);
+            t_layer<C, 0, 8>(A, bA, bB, st, a0, a1, R, sv, bias_base + (4 * q + 1) * 1024);        // lin2 / lin6
+            T_DUMP(0, 4 * q + 2);
+            if constexpr (C::TRAIN) sv.rsrc = t_tile_rsrc(act_tile + (4 * q + 2) * lstride, tile_ok, TILE_F * 4);
+            t_layer<C, 1, 8>(A, bA, bB, st, a0, a1, R, sv, bias_base + (4 * q + 2) * 1024);        // lin3 / lin7
+            T_DUMP(1, 4 * q + 3);
+            if (q == 0) {
+                // lin4: 14 k-steps of lin3's output (217 valid features: the packer zeroes the rest), then the embedding again
+                if constexpr (C::TRAIN) sv.rsrc = t_tile_rsrc(act_tile + 3 * lstride, tile_ok, TILE_F * 4);
+                t_layer<C, 0, 7>(A, bA, bB, st, a0, a1, R, sv, bias_base + 3 * 1024);
+                if constexpr (C::TRAIN) {
+                    // columns 224..255 of lin3's tile: its rows 217.. have zero weights and bias, the activation is softplus(0)
+                    const float c0 = 0.69314718055995f / SOFTPLUS_BETA;
+                    sv.v[0] = sv.v[1] = f32x4{c0, c0, c0, c0};
+                    t_save_store<7, 0>(sv); t_save_store<7, 1>(sv); t_save_store<7, 2>(sv); t_save_store<7, 3>(sv);
+                }
+                t_embed_pieces(emb_row + 16 * h, bA[0], bA[1], bB[0]);
+                __builtin_amdgcn_sched_barrier(0);
+                t_kstep<TBare<C, 0>>(A, bA[0], bB, st, a0, a1, R, sv);
+                t_kstep<TBare<C, 0>>(A, bA[1], bB, st, a0, a1, R, sv);
+                t_kstep<TBare<C, 0>>(A, bB[0], bA, st, a0, a1, R, sv);
+                T_DUMP(0, 4);
+            }
+        }
+        {
+            const int64_t gq = gp + (int64_t)gridDim.x * T_PTS;
+            xn[0] = xn[1] = xn[2] = 0.f;
+            if (gq < npts) { xn[0] = pts[gq * 3 + 0]; xn[1] = pts[gq * 3 + 1]; xn[2] = pts[gq * 3 + 2]; }
+        }
+        if constexpr (C::TRAIN) {
+            // lin8 rows 1..256 from softplus(lin7 + bias) into set 0; its epilogue saves act[7] and forms row 0 (the sdf) on the way
+            st.dot0 = st.dot1 = 0.f;
+            sv.rsrc = t_tile_rsrc(act_tile + 7 * lstride, tile_ok, TILE_F * 4);
+            t_layer<C, 0, 8, true>(A, bA, bB, st, a0, a1, R, sv, bias_base + 7 * 1024);
+            float s = st.dot0 + st.dot1;
+            s += __shfl_xor(s, 32);
+            if (h == 0 && gp < npts) sdf_out[gp] = s + b8_0[0];
+            sv.rsrc = t_tile_rsrc(feat + tile64 * TILE_F, tile_ok, TILE_F * 4);
+            t_store_feat<0>(A, bias_base, st, sv);
+        } else {
+            // lin8 row 0 on softplus(lin7 + bias): per lane 128 features of its point, the two half-waves add up
+            float s0 = 0.f, s1 = 0.f;
+            t_final_dot<0>(A, bias_base, s0, s1);
+            float s = s0 + s1;
+            s += __shfl_xor(s, 32);
+            if (h == 0 && gp < npts) sdf_out[gp] = s + b8_0[0];
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the ring runs ahead of the last tile: let its DMAs land before the LDS goes away
+}
+
+// (the weight stream is passed as const void*: a bf16 vector type in a kernel's signature leaves rocprofv3 unable to demangle its name)
+__global__ __launch_bounds__(256, 1) void sdf_nograd_t_kernel(const void* __restrict__ stream, const float* __restrict__ bias10,
+                                                              const float* __restrict__ b8_0, const float* __restrict__ pts, int64_t npts,
+                                                              float* __restrict__ sdf_out T_DBG_PARAMS) {
+#ifdef DH_T_DEBUG
+    sdf_chain_t_body<TCfgNoGrad>(stream, bias10, b8_0, pts, npts, sdf_out, nullptr, nullptr, nullptr, dbg, dbg_layer);
+#else
+    sdf_chain_t_body<TCfgNoGrad>(stream, bias10, b8_0, pts, npts, sdf_out, nullptr, nullptr, nullptr);
+#endif
+}
+__global__ __launch_bounds__(256, 1) void sdf_fwd_train_t_kernel(const void* __restrict__ stream, const float* __restrict__ bias10,
+                                                                 const float* __restrict__ b8_0, const float* __restrict__ pts, int64_t npts,
+                                                                 float* __restrict__ sdf_out, float* __restrict__ feat, float* __restrict__ act,
+                                                                 float* __restrict__ eaux T_DBG_PARAMS) {
+#ifdef DH_T_DEBUG
+    sdf_chain_t_body<TCfgTrain>(stream, bias10, b8_0, pts, npts, sdf_out, feat, act, eaux, dbg, dbg_layer);
+#else
+    sdf_chain_t_body<TCfgTrain>(stream, bias10, b8_0, pts, npts, sdf_out, feat, act, eaux);
+#endif
+}
+
+#ifdef DH_T_DEBUG
+static float* g_dbg = nullptr;
+static int g_dbg_layer = -1;
+extern "C" void dh_dev_nograd_t_debug(float* dbg, int layer) { g_dbg = dbg; g_dbg_layer = layer; }
+#endif
+#ifdef DH_T_DEBUG
+#define T_DBG_ARGS , g_dbg, g_dbg_layer
+#else
+#define T_DBG_ARGS
+#endif
+int launch_sdf_nograd_t(const float* packed, const float* pts, int64_t npts, float* sdf, hipStream_t stream) {
+    const int64_t ntiles = (npts + T_PTS - 1) / T_PTS;
+    const int g = (int)(ntiles < 256 ? ntiles : 256);
+    hipLaunchKernelGGL(sdf_nograd_t_kernel, dim3(g), dim3(256), 0, stream, static_cast<const void*>(packed + PACKT.stream),
+                       packed + PACKT.bias10, packed + PACK.sdf_b8_0, pts, npts, sdf T_DBG_ARGS);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+int launch_sdf_fwd_train_t(const float* packed, const float* pts, int64_t npts, float* sdf, float* feat, float* act, float* eaux,
+                           hipStream_t stream) {
+    const int64_t ntiles = (npts + T_PTS - 1) / T_PTS;
+    const int g = (int)(ntiles < 256 ? ntiles : 256);
+    hipLaunchKernelGGL(sdf_fwd_train_t_kernel, dim3(g), dim3(256), 0, stream, static_cast<const void*>(packed + PACKT.stream),
+                       packed + PACKT.bias10, packed + PACK.sdf_b8_0, pts, npts, sdf, feat, act, eaux T_DBG_ARGS);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+}  // namespace dh

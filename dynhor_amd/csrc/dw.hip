@@ -19,6 +19,23 @@ struct DwJob {
     int nb;                                // 8: B is a main native tile; 2: B is an aux native tile
 };
 struct DwJobs { DwJob j[16]; int n; };
+// Job groups (round 3): the persistent workgroups are dealt to DW_GROUPS groups of consecutive jobs, group k getting a share of
+// the workgroups proportional to its MFMA cost; a workgroup of group k runs ONLY that group's jobs, over ntiles / (its group's
+// size) tiles.  Work per workgroup is unchanged (fewer jobs x more tiles) and still equal across workgroups, but a job now has
+// as many split-K slabs as its group has workgroups (~G / DW_GROUPS) instead of G: the slab traffic (0.84 GB written by this
+// kernel + read back by slab_reduce_kernel with one group) falls by that factor.  DW_GROUPS = 1 is the round-2 kernel.
+#ifndef DW_GROUPS
+#define DW_GROUPS 8
+#endif
+#ifndef DW_AUX_COST
+#define DW_AUX_COST 10.0
+#endif
+struct DwGroups { int n; int job0[DW_GROUPS + 1]; int wg0[DW_GROUPS + 1]; int64_t off0[DW_GROUPS + 1]; };
+__device__ __forceinline__ int dw_group_of(const DwGroups& Gp, int g) {
+    int k = 0;
+    while (k + 1 < Gp.n && g >= Gp.wg0[k + 1]) ++k;
+    return k;
+}
 
 // NB == 8: wave (wo = wave>>1, wn = wave&1) owns output rows [64wo, 64wo+64) x cols [128wn, 128wn+128): 2 x 4 tiles,
 //          6 operand float4 per 32 MFMAs.   NB == 2: wave owns rows [32wave, 32wave+32) x 64 cols: 1 x 2 tiles.
@@ -337,40 +354,49 @@ __device__ __forceinline__ void dw_body_pieces(const DwJob& J, int64_t t0, int64
         }
 }
 
-__global__ __launch_bounds__(512, 1) void dw_bf16x3_kernel(DwJobs jobs, int64_t ntiles, float* __restrict__ slabs, int64_t gstride) {
+__global__ __launch_bounds__(512, 1) void dw_bf16x3_kernel(DwJobs jobs, DwGroups groups, int64_t ntiles, float* __restrict__ slabs,
+                                                           int64_t gstride) {
     __shared__ __attribute__((aligned(16))) char pieces[2 * DWP_BUF];
-    const int G = gridDim.x, g = blockIdx.x;
+    const int g = blockIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int64_t t0 = ntiles * g / G, t1 = ntiles * (g + 1) / G;
+    const int k = dw_group_of(groups, g), gl = g - groups.wg0[k], gc = groups.wg0[k + 1] - groups.wg0[k];
+    const int64_t t0 = ntiles * gl / gc, t1 = ntiles * (gl + 1) / gc;
     float* base = slabs + (int64_t)g * gstride;
-    for (int job = 0; job < jobs.n; ++job) {
+    for (int job = groups.job0[k]; job < groups.job0[k + 1]; ++job) {
         const DwJob J = jobs.j[job];
         if (J.nb == 8) dw_body_pieces<8>(J, t0, t1, base + J.off, wave, lane, pieces);
         else dw_body_pieces<2>(J, t0, t1, base + J.off, wave, lane, pieces);
     }
 }
 
-__global__ __launch_bounds__(512, 2) void dw_lds_kernel(DwJobs jobs, int64_t ntiles, float* __restrict__ slabs, int64_t gstride) {
+__global__ __launch_bounds__(512, 2) void dw_lds_kernel(DwJobs jobs, DwGroups groups, int64_t ntiles, float* __restrict__ slabs,
+                                                        int64_t gstride) {
     __shared__ __attribute__((aligned(16))) char ring[DW_STAGES * DW_STAGE_BYTES];
-    const int G = gridDim.x, g = blockIdx.x;
+    const int g = blockIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int64_t t0 = ntiles * g / G, t1 = ntiles * (g + 1) / G;
+    const int k = dw_group_of(groups, g), gl = g - groups.wg0[k], gc = groups.wg0[k + 1] - groups.wg0[k];
+    const int64_t t0 = ntiles * gl / gc, t1 = ntiles * (gl + 1) / gc;
     float* base = slabs + (int64_t)g * gstride;
-    for (int job = 0; job < jobs.n; ++job) {
+    for (int job = groups.job0[k]; job < groups.job0[k + 1]; ++job) {
         const DwJob J = jobs.j[job];
         if (J.nb == 8) dw_body_lds<8>(J, t0, t1, base + J.off, wave, lane, ring);
         else dw_body_lds<2>(J, t0, t1, base + J.off, wave, lane, ring);
     }
 }
 
-// red[e] = sum_g slabs[g*gstride + e].  Eight independent partial sums (slab g goes to partial g % 8, combined pairwise in a fixed
-// order: deterministic) keep eight 16-B loads in flight per lane; the slabs are read once: non-temporal.
-__global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slabs, int64_t gstride, int G, float* __restrict__ red) {
+// red[e] = sum over the workgroups of e's job group of slabs[g*gstride + e].  Eight independent partial sums (slab g goes to
+// partial (g - first) % 8, combined pairwise in a fixed order: deterministic) keep eight 16-B loads in flight per lane; the slabs
+// are read once: non-temporal.
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slabs, int64_t gstride, DwGroups groups,
+                                                          float* __restrict__ red) {
     const int64_t e = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
     if (e >= gstride) return;
+    int kg = 0;
+    while (kg + 1 < groups.n && e >= groups.off0[kg + 1]) ++kg;
+    const int G = groups.wg0[kg + 1] - groups.wg0[kg];
     f32x4 s[8];
     DH_UNROLL for (int k = 0; k < 8; ++k) s[k] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const float* p = slabs + e;
+    const float* p = slabs + e + (int64_t)groups.wg0[kg] * gstride;
     int g = 0;
     for (; g + 8 <= G; g += 8) {
         f32x4 v[8];
@@ -524,14 +550,48 @@ static void build_dw_jobs(const Workspace& w, float* red, DwJobs& J, SlabPtrs& S
     }
 }
 
+// job groups: consecutive jobs, workgroup shares proportional to the jobs' cost, every group >= 1 workgroup
+static DwGroups build_dw_groups(const DwJobs& J, int G) {
+    DwGroups Gp{};
+    const int ng = DW_GROUPS < G ? DW_GROUPS : (G < 1 ? 1 : G);
+    double cost[16], total = 0.0;
+    // cost of a job per tile: a main job (64 KB + 64 KB of operands, 48 MFMAs per wave and 16 points) = 16; an aux job (64 KB +
+    // 16 KB, a quarter of the MFMAs) is bound by its bytes = 10; two operand pairs = twice
+    for (int j = 0; j < J.n; ++j) { cost[j] = (J.j[j].nb == 8 ? 16.0 : (double)DW_AUX_COST) * (J.j[j].A2 ? 2 : 1); total += cost[j]; }
+    // greedy contiguous partition: close a group when its cost reaches the running target
+    Gp.n = ng; Gp.job0[0] = 0;
+    double acc = 0.0; int k = 1;
+    for (int j = 0; j < J.n && k < ng; ++j) {
+        acc += cost[j];
+        const int jobs_left = J.n - (j + 1), groups_left = ng - k;
+        if (acc >= total * k / ng - 1e-9 || jobs_left <= groups_left) { if (jobs_left >= groups_left) { Gp.job0[k++] = j + 1; } }
+    }
+    while (k < ng) { Gp.job0[k] = Gp.job0[k - 1] + 1; ++k; }
+    Gp.job0[ng] = J.n;
+    // workgroup shares (largest-remainder rounding, at least one each)
+    double gc[DW_GROUPS + 1]; int cnt[DW_GROUPS + 1]; int used = 0;
+    for (int g2 = 0; g2 < ng; ++g2) {
+        gc[g2] = 0.0;
+        for (int j = Gp.job0[g2]; j < Gp.job0[g2 + 1]; ++j) gc[g2] += cost[j];
+        cnt[g2] = (int)(G * gc[g2] / total); if (cnt[g2] < 1) cnt[g2] = 1; used += cnt[g2];
+    }
+    while (used < G) { int best = 0; double bv = -1.0; for (int g2 = 0; g2 < ng; ++g2) { const double v = gc[g2] / cnt[g2]; if (v > bv) { bv = v; best = g2; } } ++cnt[best]; ++used; }
+    while (used > G) { int best = -1; double bv = 1e300; for (int g2 = 0; g2 < ng; ++g2) { if (cnt[g2] > 1) { const double v = gc[g2] / cnt[g2]; if (v < bv) { bv = v; best = g2; } } } --cnt[best]; --used; }
+    Gp.wg0[0] = 0;
+    for (int g2 = 0; g2 < ng; ++g2) { Gp.wg0[g2 + 1] = Gp.wg0[g2] + cnt[g2]; Gp.off0[g2] = J.j[Gp.job0[g2]].off; }
+    Gp.off0[ng] = dw_gstride();
+    return Gp;
+}
+
 // stage 1: the split-K weight-gradient GEMMs (one kernel)
 int launch_weight_grads_gemm(const Workspace& w, float* slabs, int G, hipStream_t st) {
     const int64_t gstride = dw_gstride();
     DwJobs J{};
     SlabPtrs S{};
     build_dw_jobs(w, slabs + (int64_t)G * gstride, J, S);
-    if (arith_fp32()) hipLaunchKernelGGL(dw_lds_kernel, dim3(G), dim3(512), 0, st, J, w.ntiles, slabs, gstride);
-    else hipLaunchKernelGGL(dw_bf16x3_kernel, dim3(G), dim3(512), 0, st, J, w.ntiles, slabs, gstride);
+    const DwGroups Gp = build_dw_groups(J, G);
+    if (arith_fp32()) hipLaunchKernelGGL(dw_lds_kernel, dim3(G), dim3(512), 0, st, J, Gp, w.ntiles, slabs, gstride);
+    else hipLaunchKernelGGL(dw_bf16x3_kernel, dim3(G), dim3(512), 0, st, J, Gp, w.ntiles, slabs, gstride);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 
@@ -543,7 +603,8 @@ int launch_weight_grads_fold(const Workspace& w, float* slabs, float* tred, int 
     DwJobs J{};
     SlabPtrs S{};
     build_dw_jobs(w, red, J, S);
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((gstride / 4 + 255) / 256)), dim3(256), 0, st, slabs, gstride, G, red);
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((gstride / 4 + 255) / 256)), dim3(256), 0, st, slabs, gstride,
+                       build_dw_groups(J, G), red);
     hipLaunchKernelGGL(tpart_reduce_kernel, dim3(N_TILE_PART, nS), dim3(256), 0, st, w.tpart, w.ntiles, tred);
     static const FoldTable T = build_fold_table();
     hipLaunchKernelGGL(fold_kernel, dim3(T.total_rows), dim3(256), 0, st, T, S, tred, nS, params, packed, grad);

@@ -15,6 +15,9 @@ int launch_pack_weights(const float* params, float* packed, hipStream_t stream);
 
 // MLP chains (kernels_mlp.hip).  npts is padded by the caller to a multiple of 128 for saved buffers.
 int launch_sdf_nograd(const float* packed, const float* pts, int64_t npts, float* sdf, int grid, hipStream_t stream);
+int launch_sdf_nograd_t(const float* packed, const float* pts, int64_t npts, float* sdf, hipStream_t stream);   // chain_t.hip
+int launch_sdf_fwd_train_t(const float* packed, const float* pts, int64_t npts, float* sdf, float* feat, float* act, float* eaux,
+                           hipStream_t stream);
 
 int launch_sdf_fwd_train(const float* packed, const float* pts, int64_t npts, float* sdf, float* feat, float* act,
                          float* eaux, int grid, hipStream_t stream);

@@ -1,14 +1,13 @@
 // Tile-resident MLP chain kernels (SDF no-grad / train forward / input-gradient / colour forward).  Each chain exists in two
-// forms: the shipping split-bf16 kernel -- `<name>_s_kernel` (A split on fetch from the fp32 LDS image, tile16.h) or, where that
-// measured faster, `<name>16_kernel` (bf16 piece planes in LDS) -- and `<name>_kernel`, its native-fp32-MFMA twin (tile.h), the
-// second arithmetic the parity tests check the first against.  dh_set_arithmetic() (include/dynhor_hip.h) selects the set.
+// forms: the shipping split-bf16 kernel and `<name>_kernel`, its native-fp32-MFMA twin (tile.h), the second arithmetic the parity
+// tests check the first against; dh_set_arithmetic() (include/dynhor_hip.h) selects the set.  The split-bf16 form of the two SDF
+// forward chains is the register-resident kernel of chain_t.hip (round 3); the input-gradient and colour chains are
+// `<name>_s_kernel` here (A split on fetch from the fp32 LDS image, tile16.h).
 #include "tile.h"
 #include "kernels.h"
 #include "mlp_common.h"
 #include "tile16.h"
-#include "stamps.h"
 
-DH_STAMP_READER(dh_dev_read_stamps_fwd)
 
 namespace dh {
 
@@ -310,77 +309,9 @@ __global__ __launch_bounds__(256, 2) void color_fwd_kernel(ColPtrs C, const floa
     }
 }
 
-// K1, split-on-fetch (tile16.h): the fp32 LDS image of sdf_nograd_kernel, GEMMs as six bf16 products
-__global__ __launch_bounds__(256, 2) void sdf_nograd_s_kernel(Sdf16Ptrs P, const float* __restrict__ pts, int64_t npts,
-                                                             float* __restrict__ sdf_out) {
-    __shared__ __attribute__((aligned(16))) float smain[TM * LDX];
-    __shared__ __attribute__((aligned(16))) float saux[TM * LDA];
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int64_t ntiles = (npts + TM - 1) / TM;
-    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        embed_tile(pts, tile * TM, npts, saux, tid);
-        __syncthreads();
-        f32x16 acc[MT][2];
-        for (int l = 0; l < 8; ++l) {
-            acc_zero(acc);
-            if (l > 0) gemm_rows_s(acc, smain, LDX, l == 4 ? 14 : 16, P.main16[l], wave, lane);
-            if (l == 0 || l == 4) gemm_rows_s(acc, saux, LDA, AUX_KC, P.aux16[l], wave, lane);
-            const float b0 = P.bias[l][acc_col(wave, 0, lane)], b1 = P.bias[l][acc_col(wave, 1, lane)];
-            acc_map(acc, [&](int, int t, int, float v) { return softplus100(v + (t ? b1 : b0)); });
-            __syncthreads();                 // every wave finished reading smain as the A operand
-            acc_to_lds(acc, smain, wave, lane);
-            __syncthreads();
-        }
-        const float s = row_dot256(smain, P.w8row0, tid) + P.b8_0[0];
-        const int64_t gp = tile * TM + tid / TPP;
-        if (tid % TPP == 0 && gp < npts) sdf_out[gp] = s;
-        __syncthreads();                     // smain/saux are rewritten by the next tile
-    }
-}
+// K1 in the split-bf16 arithmetic is chain_t.hip's register-resident kernel (sdf_nograd_t_kernel)
 
-// K2a, split-on-fetch
-__global__ __launch_bounds__(256, 2) void sdf_fwd_train_s_kernel(Sdf16Ptrs P, const float* __restrict__ pts, int64_t npts,
-                                                                float* __restrict__ sdf_out, float* __restrict__ feat,
-                                                                float* __restrict__ act, float* __restrict__ eaux) {
-    __shared__ __attribute__((aligned(16))) float smain[TM * LDX];
-    __shared__ __attribute__((aligned(16))) float saux[TM * LDA];
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int64_t ntiles = (npts + TM - 1) / TM;
-    int it = 0;
-    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x, ++it) {
-        embed_tile(pts, tile * TM, npts, saux, tid);
-        __syncthreads();
-        aux_lds_to_native(saux, eaux + tile * AUXT_F, wave, lane);
-        f32x16 acc[MT][2];
-        for (int l = 0; l < 8; ++l) {
-            DH_STAMP(it, l, 0);
-            acc_zero(acc);
-            if (l > 0) gemm_rows_s(acc, smain, LDX, l == 4 ? 14 : 16, P.main16[l], wave, lane);
-            if (l == 0 || l == 4) gemm_rows_s(acc, saux, LDA, AUX_KC, P.aux16[l], wave, lane);
-            DH_STAMP(it, l, 1);
-            const float b0 = P.bias[l][acc_col(wave, 0, lane)], b1 = P.bias[l][acc_col(wave, 1, lane)];
-            acc_map(acc, [&](int, int t, int, float v) { return softplus100(v + (t ? b1 : b0)); });
-            DH_STAMP(it, l, 2);
-            acc_store_native(acc, act + ((int64_t)l * ntiles + tile) * TILE_F, wave, lane);
-            DH_STAMP(it, l, 3);
-            __syncthreads();
-            DH_STAMP(it, l, 4);
-            acc_to_lds(acc, smain, wave, lane);
-            DH_STAMP(it, l, 5);
-            __syncthreads();
-            DH_STAMP(it, l, 6);
-        }
-        const float s = row_dot256(smain, P.w8row0, tid) + P.b8_0[0];
-        const int64_t gp = tile * TM + tid / TPP;
-        if (tid % TPP == 0 && gp < npts) sdf_out[gp] = s;
-        acc_zero(acc);
-        gemm_rows_s(acc, smain, LDX, 16, P.main16[8], wave, lane);
-        const float b0 = P.bias[8][acc_col(wave, 0, lane)], b1 = P.bias[8][acc_col(wave, 1, lane)];
-        acc_map(acc, [&](int, int t, int, float v) { return v + (t ? b1 : b0); });
-        acc_store_native(acc, feat + tile * TILE_F, wave, lane);
-        __syncthreads();
-    }
-}
+// K2a in the split-bf16 arithmetic is chain_t.hip's register-resident kernel (sdf_fwd_train_t_kernel)
 
 // K2c, split-on-fetch
 __global__ __launch_bounds__(256, 2) void color_fwd_s_kernel(Col16Ptrs C, const float* __restrict__ pts, const float* __restrict__ dirs,
@@ -447,9 +378,8 @@ static inline int grid_for(int64_t npts, int grid) {
 
 int launch_sdf_fwd_train(const float* packed, const float* pts, int64_t npts, float* sdf, float* feat, float* act,
                          float* eaux, int grid, hipStream_t stream) {
-    const int g = grid_for(npts, grid);
-    if (arith_fp32()) hipLaunchKernelGGL(sdf_fwd_train_kernel, dim3(g), dim3(256), 0, stream, make_sdf_ptrs(packed), pts, npts, sdf, feat, act, eaux);
-    else hipLaunchKernelGGL(sdf_fwd_train_s_kernel, dim3(g), dim3(256), 0, stream, make_sdf16_ptrs(packed), pts, npts, sdf, feat, act, eaux);
+    if (!arith_fp32()) return launch_sdf_fwd_train_t(packed, pts, npts, sdf, feat, act, eaux, stream);
+    hipLaunchKernelGGL(sdf_fwd_train_kernel, dim3(grid_for(npts, grid)), dim3(256), 0, stream, make_sdf_ptrs(packed), pts, npts, sdf, feat, act, eaux);
     return ok();
 }
 int launch_sdf_grad(const float* packed, const float* pts, int64_t npts, const float* act, float* asave, float* normals,
@@ -472,9 +402,8 @@ int launch_color_fwd(const float* packed, const float* pts, const float* dirs, i
 
 int launch_sdf_nograd(const float* packed, const float* pts, int64_t npts, float* sdf, int grid, hipStream_t stream) {
     if (npts <= 0) return 0;
-    const int g = grid_for(npts, grid);
-    if (arith_fp32()) hipLaunchKernelGGL(sdf_nograd_kernel, dim3(g), dim3(256), 0, stream, make_sdf_ptrs(packed), pts, npts, sdf);
-    else hipLaunchKernelGGL(sdf_nograd_s_kernel, dim3(g), dim3(256), 0, stream, make_sdf16_ptrs(packed), pts, npts, sdf);
+    if (!arith_fp32()) return launch_sdf_nograd_t(packed, pts, npts, sdf, stream);
+    hipLaunchKernelGGL(sdf_nograd_kernel, dim3(grid_for(npts, grid)), dim3(256), 0, stream, make_sdf_ptrs(packed), pts, npts, sdf);
     return ok();
 }
 

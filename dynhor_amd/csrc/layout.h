@@ -153,4 +153,21 @@ constexpr Pack16Off make_pack16_off() {
 }
 constexpr Pack16Off PACK16 = make_pack16_off();
 
+// ---------------------------------------------------------------- register-resident chain (chain_t.hip), appended after PACK16
+// `stream`: the SDF network's forward weights as ONE sequence of 132 stages (3 + 16 + 16 + 16 + (14 + 3) + 16 + 16 + 16 k-steps
+// of lin0 .. lin7 = the 116 the no-grad kernel cycles through, then 16 of lin8's rows 1..256 for the training forward); a stage = 8 m-tiles x 3 pieces x 64 lanes of bf16x8 = 24 KB, bf16x8 index ((stage*8 + M)*3 + piece)*64
+// + lane holding W[32 M + (lane&31)][k], k slot i <-> input feature 16 s + 8 (i/4) + 4 (lane>>5) + (i%4) of the layer's k-step s.
+// `bias10`: bias rows of lin0..lin7 (256 each, zero past a layer's width), the effective weight row 0 of lin8, lin8's bias rows 1..256.
+constexpr int T_STREAM_STAGES_NOGRAD = 116, T_STREAM_STAGES_TRAIN = 132;
+constexpr int64_t PACKT_STREAM_FLOATS = (int64_t)T_STREAM_STAGES_TRAIN * 8 * 3 * 64 * 4;
+struct PackTOff { int64_t stream, bias10, total; };
+constexpr PackTOff make_packt_off() {
+    PackTOff p{};
+    p.stream = PACK16.total;
+    p.bias10 = p.stream + PACKT_STREAM_FLOATS;
+    p.total = p.bias10 + 10 * 256;
+    return p;
+}
+constexpr PackTOff PACKT = make_packt_off();
+
 }  // namespace dh

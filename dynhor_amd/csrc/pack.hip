@@ -36,7 +36,8 @@ struct PackJob {
     int ldv;            // in-dim of the linear
     int nkg;            // k-groups
     int nt;             // n-tiles (8 or 2)
-    int rev;            // 0: M[k=in][n=out]   1: M[k=out][n=in]
+    int rev;            // 0: M[k=in][n=out]   1: M[k=out][n=in]   2 (pack16_kernel only): as 0 with the k slots of a chunk permuted for
+                        //    chain_t.hip: slot s of lane half h <-> k = 16 kc + 8 (s/4) + 4 h + (s%4)
     int row_off;        // output-row offset (lin8: 1)
     int col_off;        // input-col offset
     int out_valid;      // valid output rows (after row_off)
@@ -44,7 +45,7 @@ struct PackJob {
     float scale;
 };
 
-struct PackJobs { PackJob j[32]; int n; };
+struct PackJobs { PackJob j[44]; int n; };
 
 __global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ params, float* __restrict__ packed, PackJobs jobs) {
     const PackJob J = jobs.j[blockIdx.y];
@@ -105,8 +106,8 @@ __global__ __launch_bounds__(256) void pack16_kernel(const float* __restrict__ p
         const int n = nt * 32 + (lane & 31);
         Bf3 w;
         DH_UNROLL for (int s = 0; s < 8; ++s) {
-            const int k = kc * 16 + 8 * (lane >> 5) + s;
-            const int o = J.rev ? k : n, c = J.rev ? n : k;
+            const int k = kc * 16 + (J.rev == 2 ? 8 * (s >> 2) + 4 * (lane >> 5) + (s & 3) : 8 * (lane >> 5) + s);
+            const int o = J.rev == 1 ? k : n, c = J.rev == 1 ? n : k;
             float x = 0.f;
             if (o < J.out_valid && c < J.in_valid) {
                 const int row = o + J.row_off;
@@ -118,6 +119,16 @@ __global__ __launch_bounds__(256) void pack16_kernel(const float* __restrict__ p
         }
         DH_UNROLL for (int p = 0; p < 3; ++p) dst[(((int64_t)kc * J.nt + nt) * 3 + p) * 64 + lane] = w.p[p];
     }
+}
+
+// chain_t.hip's bias rows, lin8 row 0 and lin8's bias rows 1..256 (layout.h PACKT.bias10)
+__global__ __launch_bounds__(256) void packt_small_kernel(const float* __restrict__ params, float* __restrict__ packed) {
+    const int c = threadIdx.x, l = blockIdx.x;
+    float v;
+    if (l < 8) v = c < SDF_DIMS[l].out ? params[sdf_off(l).bias + c] : 0.f;
+    else if (l == 8) v = packed[PACK.rowscale + 8 * 260] * params[sdf_off(8).v + c];
+    else v = params[sdf_off(8).bias + 1 + c];
+    packed[PACKT.bias10 + l * 256 + c] = v;
 }
 
 static PackJobs build_jobs16() {
@@ -147,6 +158,18 @@ static PackJobs build_jobs16() {
             add(PACK16.sdf_rev_main[l], v, rs, in, 16, 8, 1, 0, 0, out, in, 1.f);
         }
     }
+    // the register-resident chain's stream: lin0 .. lin7 in stage order
+    int64_t ts = PACKT.stream;
+    auto addt = [&](int l, int nstage, int col_off, int in_valid, float scale, int row_off = 0) {
+        add(ts, sdf_off(l).v, PACK.rowscale + (int64_t)l * 260, SDF_DIMS[l].in, nstage, 8, 2, row_off, col_off, SDF_DIMS[l].out - row_off, in_valid, scale);
+        ts += pack16_floats(nstage, 8);
+    };
+    addt(0, 3, 0, EMB, 1.f);
+    for (int l = 1; l <= 3; ++l) addt(l, 16, 0, 256, 1.f);
+    addt(4, 14, 0, SKIP_OUT, INV_SQRT2);
+    addt(4, 3, SKIP_OUT, EMB, INV_SQRT2);
+    for (int l = 5; l <= 7; ++l) addt(l, 16, 0, 256, 1.f);
+    addt(8, 16, 0, 256, 1.f, 1);
     for (int l = 0; l < 4; ++l) {
         const int64_t rs = PACK.rowscale + (int64_t)N_SDF * 260 + (int64_t)l * 256;
         const int64_t v = col_off(l).v;
@@ -217,6 +240,7 @@ int launch_pack_weights(const float* params, float* packed, hipStream_t stream) 
     hipLaunchKernelGGL(pack_small_kernel, dim3(N_SDF + 1 + 4 + 1), dim3(256), 0, stream, params, packed);
     static const PackJobs jobs16 = build_jobs16();
     hipLaunchKernelGGL(pack16_kernel, dim3(8, jobs16.n), dim3(256), 0, stream, params, packed, jobs16);
+    hipLaunchKernelGGL(packt_small_kernel, dim3(10), dim3(256), 0, stream, params, packed);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 

@@ -1,0 +1,36 @@
+"""The register-resident chain's inline-asm LDS reads: no instruction may touch a destination register before the wait that
+covers it (scripts/isa_inflight_check.py explains the hazard; it produced wrong values during bring-up).  Compiles the kernel
+for gfx950 (hipcc cross-compiles without a GPU) and scans the listing."""
+import os
+import shutil
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "scripts"))
+
+
+def test_scanner_sees_both_hazard_kinds():
+    from isa_inflight_check import scan
+    use_before_wait = ["ds_read_b64 v[6:7], v52 offset:96", "v_add_f32_e32 v32, v25, v6", "s_waitcnt lgkmcnt(0)"]
+    clobber = ["ds_read_b64 v[12:13], v185", "v_mul_f32_e64 v12, |v7|, s51", "s_waitcnt lgkmcnt(0)"]
+    clean = ["ds_read_b128 v[96:99], v193 offset:0x4800", "v_mfma_f32_32x32x16_bf16 a[0:15], v[1:4], v[5:8], a[0:15]",
+             "s_waitcnt lgkmcnt(0)", "v_add_f32_e32 v1, v96, v97"]
+    assert [f[3] for f in scan(use_before_wait)[1]] == ["read"]
+    assert [f[3] for f in scan(clobber)[1]] == ["write"]
+    assert scan(clean) == (1, [])
+
+
+@pytest.mark.skipif(shutil.which("hipcc") is None, reason="hipcc not installed")
+def test_chain_t_listing_is_clean(tmp_path):
+    from isa_inflight_check import scan
+    out = tmp_path / "chain_t.s"
+    subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only",
+                    os.path.join(ROOT, "dynhor_amd", "csrc", "chain_t.hip"), "-o", str(out)], check=True, timeout=600)
+    text = out.read_text()
+    n_reads, found = scan(text.split("\n"))
+    assert n_reads > 1000, "the listing does not look like the chain kernel"
+    assert not found, found[:5]
+    assert "ScratchSize: 0" in text, "the chain kernel must not spill (a spilled in-flight register is the same hazard)"

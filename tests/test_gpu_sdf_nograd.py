@@ -16,7 +16,7 @@ def _run_nograd(hiplib, flat, pts):
     return out
 
 
-@pytest.mark.parametrize("npts", [1, 127, 128, 129, 1000, 32768 + 5])
+@pytest.mark.parametrize("npts", [1, 127, 128, 129, 1000, 32768 + 5, 100003])
 @pytest.mark.parametrize("jitter", [0.0, 0.05])
 def test_sdf_nograd_matches_oracle(hiplib, npts, jitter):
     dev = torch.device("cuda:0")
