@@ -13,9 +13,11 @@
 //   * weight pieces enter the CU ONCE per 128 points (4 waves share them) through an LDS ring filled by LDS-DMA
 //     (buffer_load_dwordx4 ... lds, 24 KB per 16-deep k-step, dealt singly between MFMAs), one raw s_barrier per k-step.
 // Arms: this chain, its bare MFMA + ring stream (no epilogue), and the tile16.h loop (same 8 x [256 x 256] layers, softplus, data
-// kept O(1) with random signs in every arm -- collapsed activations raise the clock by 20 %).  Results, the earlier forms of this
-// file (compiler-allocated accumulators: 240 vs 214 TFLOP/s) and why the design is not in the product yet:
-// profiles/r03_ab_register_resident_chain.json.
+// kept O(1) with random signs in every arm -- collapsed activations raise the clock by 20 %).  Results and the earlier forms of this
+// file: profiles/r03_ab_register_resident_chain.json.  The product kernels built from the -DTC_BUILTIN form (compiler-allocated
+// accumulators, LDS-DMA dealt singly): dynhor_amd/csrc/chain_t.hip; this file stays as the timing study (its values are NOT
+// checked against a reference -- the product kernels' are, and bring-up found two inline-asm hazards this micro shares in
+// principle: scripts/isa_inflight_check.py).
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 tchain_micro.hip -o tchain_micro
 #include "../../dynhor_amd/csrc/tile16.h"
 #include <cstdio>
@@ -71,10 +73,11 @@ __device__ __forceinline__ void epi_only(const f32x16& x, Pieces (&out)[2], EpiS
 }
 
 // The two accumulator sets are HAND-ALLOCATED accumulator-file registers (set 0 = a[0:127], set 1 = a[128:255]; m-tile m of a set
-// = 16 registers from base + 16 m): hipcc cannot be told to keep a value in the accumulator file and it moves tuples between the
-// files with v_accvgpr_read / _write, which cost ~60 cycles EACH on gfx950 (measured here: 128 reads in one clump = 8.2 k cycles).
-// MFMAs and the LDS stash writes therefore name the registers literally; the compiler never sees them (clobber list below; the
-// build is checked for compiler-made v_accvgpr_* = none).
+// = 16 registers from base + 16 m): hipcc cannot be told to keep a value in the accumulator file and moves tuples between the
+// files with v_accvgpr_read / _write.  (An early reading of this micro priced those at ~60 cycles each; that was the clumped LDS-DMA
+// issue cost -- profiles/r03_ab_register_resident_chain.json -- and this hand-allocated arm measured SLOWER than the
+// compiler-allocated one, 225 vs 234-240 TFLOP/s.)  MFMAs and the LDS stash writes name the registers literally; the compiler
+// never sees them (clobber list below).
 #define TC_ALL_AGPRS "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15", "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31", "a32", "a33", "a34", "a35", "a36", "a37", "a38", "a39", "a40", "a41", "a42", "a43", "a44", "a45", "a46", "a47", "a48", "a49", "a50", "a51", "a52", "a53", "a54", "a55", "a56", "a57", "a58", "a59", "a60", "a61", "a62", "a63", "a64", "a65", "a66", "a67", "a68", "a69", "a70", "a71", "a72", "a73", "a74", "a75", "a76", "a77", "a78", "a79", "a80", "a81", "a82", "a83", "a84", "a85", "a86", "a87", "a88", "a89", "a90", "a91", "a92", "a93", "a94", "a95", "a96", "a97", "a98", "a99", "a100", "a101", "a102", "a103", "a104", "a105", "a106", "a107", "a108", "a109", "a110", "a111", "a112", "a113", "a114", "a115", "a116", "a117", "a118", "a119", "a120", "a121", "a122", "a123", "a124", "a125", "a126", "a127", "a128", "a129", "a130", "a131", "a132", "a133", "a134", "a135", "a136", "a137", "a138", "a139", "a140", "a141", "a142", "a143", "a144", "a145", "a146", "a147", "a148", "a149", "a150", "a151", "a152", "a153", "a154", "a155", "a156", "a157", "a158", "a159", "a160", "a161", "a162", "a163", "a164", "a165", "a166", "a167", "a168", "a169", "a170", "a171", "a172", "a173", "a174", "a175", "a176", "a177", "a178", "a179", "a180", "a181", "a182", "a183", "a184", "a185", "a186", "a187", "a188", "a189", "a190", "a191", "a192", "a193", "a194", "a195", "a196", "a197", "a198", "a199", "a200", "a201", "a202", "a203", "a204", "a205", "a206", "a207", "a208", "a209", "a210", "a211", "a212", "a213", "a214", "a215", "a216", "a217", "a218", "a219", "a220", "a221", "a222", "a223", "a224", "a225", "a226", "a227", "a228", "a229", "a230", "a231", "a232", "a233", "a234", "a235", "a236", "a237", "a238", "a239", "a240", "a241", "a242", "a243", "a244", "a245", "a246", "a247", "a248", "a249", "a250", "a251", "a252", "a253", "a254", "a255"
 // -DTC_BUILTIN: the compiler allocates both accumulator sets (f32x16 arrays, __builtin_amdgcn_mfma) and reads finished values
 // with v_accvgpr_read pairs inside the epilogue steps -- the form that measured 237-240 TFLOP/s with the DMA in a clump

@@ -1,0 +1,65 @@
+"""The register-resident chains' weight stream (csrc/layout.h PACKT): every bf16x8 of it, decoded on the host, must hold the
+effective weights W = g v / |v| at the position the header documents -- stage order lin0 (3 k-steps), lin1-3 (16 each), lin4 (14
+of lin3's output + 3 of the embedding, both scaled 1/sqrt 2), lin5-7, lin8 rows 1..256; bf16x8 index ((stage*8 + M)*3 + piece)*64 +
+lane = W[32 M + (lane & 31)][k], slot i <-> input feature 16 s + 8 (i/4) + 4 (lane >> 5) + (i % 4); then the ten bias rows."""
+import math
+
+import pytest
+import torch
+
+from tests.util import flat_from_oracle, randomized_models
+
+pytestmark = pytest.mark.gpu
+
+
+def test_tstream_holds_the_effective_weights_where_layout_h_says(hiplib):
+    from dynhor_amd import _lib
+    dev = torch.device("cuda:0")
+    sdf, col, var = randomized_models(seed=5, device=dev, jitter=0.05)
+    flat = flat_from_oracle(sdf, var, col)
+    packed = torch.empty(hiplib.dh_packed_floats(), device=dev)
+    _lib.check(hiplib.dh_pack_weights(_lib.ptr(flat), _lib.ptr(packed), _lib.stream()))
+    torch.cuda.synchronize()
+    n_stage, stage_floats = 132, 8 * 3 * 64 * 4
+    bias0 = packed.numel() - 10 * 256
+    stream0 = bias0 - n_stage * stage_floats
+    pieces = packed[stream0:bias0].view(torch.bfloat16).view(n_stage, 8, 3, 64, 8).float()      # stage, M, piece, lane, slot
+    w = (pieces[:, :, 0] + pieces[:, :, 1] + pieces[:, :, 2]).cpu()                              # [stage, M, lane, slot]
+    sd = {k: v.detach().double().cpu() for k, v in sdf.state_dict().items()}
+    W = {}
+    for l in range(9):
+        v, g = sd["lin%d.weight_v" % l], sd["lin%d.weight_g" % l].reshape(-1)
+        W[l] = g[:, None] * v / v.norm(dim=1, keepdim=True)
+    # (layer, k-steps, first row, first input column, valid input columns, scale) in stream order
+    jobs = [(0, 3, 0, 0, 39, 1.0), (1, 16, 0, 0, 256, 1.0), (2, 16, 0, 0, 256, 1.0), (3, 16, 0, 0, 256, 1.0),
+            (4, 14, 0, 0, 217, 1 / math.sqrt(2)), (4, 3, 0, 217, 39, 1 / math.sqrt(2)),
+            (5, 16, 0, 0, 256, 1.0), (6, 16, 0, 0, 256, 1.0), (7, 16, 0, 0, 256, 1.0), (8, 16, 1, 0, 256, 1.0)]
+    lane = torch.arange(64)
+    slot = torch.arange(8)
+    stage = 0
+    worst = 0.0
+    for l, nk, row0, col0, ncol, scale in jobs:
+        rows_valid = W[l].shape[0] - row0
+        for s in range(nk):
+            k = 16 * s + 8 * (slot[None, :] // 4) + 4 * (lane[:, None] // 32) + (slot[None, :] % 4)             # [lane, slot]
+            for M in range(8):
+                o = 32 * M + (lane % 32)                                                                        # [lane]
+                ref = torch.zeros(64, 8, dtype=torch.float64)
+                ok = (o[:, None] < rows_valid) & (k < ncol)
+                oo = (o[:, None] + row0).expand(64, 8)[ok]
+                kk = (k + col0)[ok]
+                ref[ok] = scale * W[l][oo, kk]
+                err = (w[stage, M].double() - ref).abs().max().item()
+                worst = max(worst, err)
+                assert err < 2e-6, (l, s, M, err)
+            stage += 1
+    assert stage == n_stage
+    print("max |stream - W| = %.2e" % worst)
+    # bias rows 0..7, lin8's effective row 0, lin8's bias rows 1..256
+    b = packed[bias0:].view(10, 256).double().cpu()
+    for l in range(8):
+        ref = torch.zeros(256, dtype=torch.float64)
+        ref[:sd["lin%d.bias" % l].numel()] = sd["lin%d.bias" % l]
+        assert (b[l] - ref).abs().max() < 1e-7
+    assert (b[8] - W[8][0]).abs().max() < 2e-6
+    assert (b[9] - sd["lin8.bias"][1:]).abs().max() < 1e-7
