@@ -43,9 +43,8 @@ struct TPieces { u32x4 p[3]; };                  // one k-step of the activation
 struct TFrag { u32x4 p[3]; };                    // one m-tile's weight (A) fragments of a k-step
 struct TAcc { f32x16 s[2][T_NM]; };
 // epilogue state.  b = the pair's biases (the next pair's are read into the same registers right after their last use).  Training
-// kernel only: w = lin8 row-0 weights of the pair, dot = this lane's partial sdf, patch_wr = the lane's write address in the patch,
-// hd = pair 0's activations on their way to the patch
-struct TEpi { f32x2 x, t, e, u, b, w, hd; float dot0, dot1; unsigned bias_addr, patch_wr; };
+// kernel only: patch_wr = the lane's write address in the patch, hd = pair 0's activations on their way to the patch
+struct TEpi { f32x2 x, t, e, u, b, hd; unsigned bias_addr, patch_wr; };
 // saving an m-tile as a native tile (tile.h): patch_rd = the lane's read address in the patch, v = two float4 in flight, rsrc =
 // buffer descriptor of the native tile (wave-uniform; zero records when the tile does not exist -- ragged last tile -- so the
 // hardware drops the stores), loff = the lane's byte offset in it (its half of the tile and its lane slot)
@@ -109,55 +108,39 @@ __device__ __forceinline__ void t_bias_read_w(f32x2& dst, unsigned addr) {
 // one micro-step of the epilogue of m-tile M whose 16 finished values are x: pair j = STEP / 12 = values 2j, 2j+1 -> u32 j % 4 of
 // the pieces of k-step half j / 4.  12 steps of 2-4 vector ops: + bias, -|x| c, exp2, 1 + e, log2, max, fma, then the 3-way split.
 // Step 1 also issues the bias read of the next pair; after the last pair that of the next m-tile's first pair -- only if NEXT
-// says that m-tile's epilogue will run.  EXPOSED: outside the MFMA stream, blocking reads.  SAVE (training kernel): the pair's
-// activations also go to the transposition patch; DOT (training kernel, lin7's output): and into lin8's row 0 (its weights sit
-// one bias row further, read beside the bias pair).
-template <int M, int STEP, bool NEXT, bool EXPOSED, bool SAVE, bool DOT>
+// says that m-tile's epilogue will run.  (m-tile 0's epilogue runs outside the MFMA stream: t_epi_exposed.)  SAVE (training
+// kernel): the pair's activations also go to the transposition patch.
+template <int M, int STEP, bool NEXT, bool SAVE>
 __device__ __forceinline__ void t_epi_step(const f32x16& x, TPieces (&out)[2], TEpi& st) {
     constexpr int j = STEP / 12, s = STEP % 12, half = j / 4, q = j % 4, r0 = 2 * j;
     constexpr int PW = (8 * (r0 / 4) + r0 % 4) * T_PATCH_LD * 4;           // patch row of value r0 (this lane's 4 h rows are in patch_wr)
     if constexpr (s == 0) { st.x[0] = x[r0] + st.b[0]; }
     else if constexpr (s == 1) {
         st.x[1] = x[r0 + 1] + st.b[1];
-        if constexpr (EXPOSED) {
-            if constexpr (j < 7) t_bias_read_w<M, j + 1>(st.b, st.bias_addr);
-            else if constexpr (NEXT) t_bias_read_w<M + 1, 0>(st.b, st.bias_addr);
-        } else {
-            if constexpr (j < 7) t_bias_read<M, j + 1>(st.b, st.bias_addr);
-            else if constexpr (NEXT) t_bias_read<M + 1, 0>(st.b, st.bias_addr);
-        }
+        if constexpr (j < 7) t_bias_read<M, j + 1>(st.b, st.bias_addr);
+        else if constexpr (NEXT) t_bias_read<M + 1, 0>(st.b, st.bias_addr);
     }
     else if constexpr (s == 2) { st.t[0] = -fabsf(st.x[0]) * (SOFTPLUS_BETA * 1.44269504088896f); st.t[1] = -fabsf(st.x[1]) * (SOFTPLUS_BETA * 1.44269504088896f); }
     else if constexpr (s == 3) { st.e[0] = __builtin_amdgcn_exp2f(st.t[0]); st.e[1] = __builtin_amdgcn_exp2f(st.t[1]); }
     else if constexpr (s == 4) {
         st.e[0] = 1.f + st.e[0]; st.e[1] = 1.f + st.e[1];
-        if constexpr (SAVE && !EXPOSED && j == 1) t_lds_write_b32<0>(st.patch_wr, st.hd[0]);                    // pair 0's, deferred (below)
+        if constexpr (SAVE && j == 1) t_lds_write_b32<0>(st.patch_wr, st.hd[0]);                    // pair 0's, deferred (below)
     }
     else if constexpr (s == 5) {
         st.e[0] = __builtin_amdgcn_logf(st.e[0]); st.e[1] = __builtin_amdgcn_logf(st.e[1]);
-        if constexpr (SAVE && !EXPOSED && j == 1) t_lds_write_b32<T_PATCH_LD * 4>(st.patch_wr, st.hd[1]);
+        if constexpr (SAVE && j == 1) t_lds_write_b32<T_PATCH_LD * 4>(st.patch_wr, st.hd[1]);
     }
     else if constexpr (s == 6) { st.t[0] = fmaxf(st.x[0], 0.f); st.t[1] = fmaxf(st.x[1], 0.f); }
     else if constexpr (s == 7) {
         st.x[0] = fmaf(st.e[0], 0.69314718055995f / SOFTPLUS_BETA, st.t[0]); st.x[1] = fmaf(st.e[1], 0.69314718055995f / SOFTPLUS_BETA, st.t[1]);
-        // dealt under a k-step, pair 0 is finished in group 0 while the PREVIOUS m-tile's patch is still being read (its last two
-        // float4 leave in group 1, slots 2-3): pair 0's two values wait in hd until pair 1's steps 4 and 5 (group 1, slots 4-5)
-        if constexpr (SAVE && !EXPOSED && j == 0) st.hd = st.x;
+        // pair 0 is finished in group 0 while the PREVIOUS m-tile's patch is still being read (its last two float4 leave in group
+        // 1, slots 2-3): pair 0's two values wait in hd until pair 1's steps 4 and 5 (group 1, slots 4-5)
+        if constexpr (SAVE && j == 0) st.hd = st.x;
         else if constexpr (SAVE) t_lds_write_b32<PW>(st.patch_wr, st.x[0]);
-        if constexpr (DOT) { st.dot0 = fmaf(st.x[0], st.w[0], st.dot0); st.dot1 = fmaf(st.x[1], st.w[1], st.dot1); }
     }
     else if constexpr (s == 8) {
-        if constexpr (SAVE && (EXPOSED || j > 0)) t_lds_write_b32<PW + T_PATCH_LD * 4>(st.patch_wr, st.x[1]);
+        if constexpr (SAVE && j > 0) t_lds_write_b32<PW + T_PATCH_LD * 4>(st.patch_wr, st.x[1]);
         const unsigned h = pack_bf16x2(st.x); out[half].p[0][q] = h; st.u = unpack_bf16x2(h);
-        if constexpr (DOT) {            // the next pair's row-0 weights (this pair's were last used in step 7)
-            if constexpr (EXPOSED) {
-                if constexpr (j < 7) t_bias_read_w<M, j + 1, 1024>(st.w, st.bias_addr);
-                else if constexpr (NEXT) t_bias_read_w<M + 1, 0, 1024>(st.w, st.bias_addr);
-            } else {
-                if constexpr (j < 7) t_bias_read<M, j + 1, 1024>(st.w, st.bias_addr);
-                else if constexpr (NEXT) t_bias_read<M + 1, 0, 1024>(st.w, st.bias_addr);
-            }
-        }
     }
     else if constexpr (s == 9) { st.x[0] -= st.u[0]; st.x[1] -= st.u[1]; }
     else if constexpr (s == 10) { const unsigned h = pack_bf16x2(st.x); out[half].p[1][q] = h; st.u = unpack_bf16x2(h); }
@@ -218,12 +201,12 @@ __device__ __forceinline__ void t_mfma_step(TAcc& A, const TFrag (&a)[2], const 
 // What is dealt under one k-step's MFMAs (compile-time): the accumulator set NB it writes; the epilogue m-tile EM of the OTHER
 // set (-1: none) and which half EH of its 96 micro-steps; ENEXT: m-tile EM + 1 follows; SM (training kernel): the m-tile whose
 // patch is complete -- two of its float4 are read in group 0 and stored in group 1, the other two read in group 1 and stored in
-// group 2 (-1: none); DOT: see t_epi_step
-template <class C_, int NB_, int EM_, int EH_, bool ENEXT_, int SM_, bool DOT_>
+// group 2 (-1: none)
+template <class C_, int NB_, int EM_, int EH_, bool ENEXT_, int SM_>
 struct TK {
     using C = C_;
     static constexpr int NB = NB_, EM = EM_, EH = EH_, SM = SM_;
-    static constexpr bool ENEXT = ENEXT_, DOT = DOT_;
+    static constexpr bool ENEXT = ENEXT_;
 };
 // the 12 MFMAs of group G, each followed by its share of the dealt work; DA / DB: the LDS-DMA piece issued after MFMA 3 / 9 (-1: none)
 template <class K, int G, int DA, int DB, int I>
@@ -240,7 +223,7 @@ __device__ __forceinline__ void t_group_steps(TAcc& A, const TFrag (&a)[2], cons
             if constexpr (G == 2 && I < 2) { t_save_store<K::SM, I + 2>(sv); __builtin_amdgcn_sched_barrier(0); }
         }
         if constexpr (K::EM >= 0 && K::EM < T_NM) {
-            t_epi_step<K::EM, K::EH * 48 + 12 * G + I, K::ENEXT, false, K::C::TRAIN, K::DOT>(A.s[1 - K::NB][K::EM], bn, st);
+            t_epi_step<K::EM, K::EH * 48 + 12 * G + I, K::ENEXT, K::C::TRAIN>(A.s[1 - K::NB][K::EM], bn, st);
             __builtin_amdgcn_sched_barrier(0);
         }
         t_group_steps<K, G, DA, DB, I + 1>(A, a, b, bn, st, R, sv);
@@ -279,28 +262,44 @@ __device__ __forceinline__ void t_kstep(TAcc& A, const TPieces& b, TPieces (&bn)
     __builtin_amdgcn_sched_barrier(0);
 }
 template <class C, int NB>
-using TBare = TK<C, NB, -1, 0, false, -1, false>;
+using TBare = TK<C, NB, -1, 0, false, -1>;
 
 template <int NB>
 __device__ __forceinline__ void t_zero(TAcc& A) {
     DH_UNROLL for (int m = 0; m < T_NM; ++m) DH_UNROLL for (int r = 0; r < 16; ++r) A.s[NB][m][r] = 0.f;
 }
-template <int M, int I, int N, bool SAVE, bool DOT>
-__device__ __forceinline__ void t_epi_only(const f32x16& x, TPieces (&out)[2], TEpi& st) {
-    if constexpr (I < N) {
-        t_epi_step<M, I, true, true, SAVE, DOT>(x, out, st);
-        t_epi_only<M, I + 1, N, SAVE, DOT>(x, out, st);
+// the one exposed epilogue of a layer: m-tile 0 of the source set, outside the MFMA stream -- the same arithmetic as t_epi_step, its
+// sixteen biases fetched with ONE LDS latency; leaves m-tile 1's first pair in st.b
+template <bool SAVE>
+__device__ __forceinline__ void t_epi_exposed(const f32x16& x, TPieces (&out)[2], TEpi& st) {
+    f32x4 bb[4];
+    t_lds_read4_w<0, 32, 64, 96>(bb[0], bb[1], bb[2], bb[3], st.bias_addr);
+    DH_UNROLL for (int j = 0; j < 8; ++j) {
+        const int g = j / 2, i0 = 2 * (j % 2), r0 = 2 * j, half = j / 4, q = j % 4;
+        f32x2 v;
+        v[0] = softplus100(x[r0] + bb[g][i0]);
+        v[1] = softplus100(x[r0 + 1] + bb[g][i0 + 1]);
+        if constexpr (SAVE) {
+            const unsigned a = st.patch_wr + (8 * (r0 / 4) + r0 % 4) * T_PATCH_LD * 4;
+            asm volatile("ds_write_b32 %0, %1\n\tds_write_b32 %0, %2 offset:%3" ::"v"(a), "v"(v[0]), "v"(v[1]), "n"(T_PATCH_LD * 4) : "memory");
+        }
+        const unsigned h = pack_bf16x2(v);
+        const f32x2 r1 = v - unpack_bf16x2(h);
+        const unsigned m = pack_bf16x2(r1);
+        const f32x2 r2 = r1 - unpack_bf16x2(m);
+        out[half].p[0][q] = h; out[half].p[1][q] = m; out[half].p[2][q] = pack_bf16x2(r2);
     }
+    t_bias_read_w<1, 0>(st.b, st.bias_addr);
 }
 // k-steps 2M, 2M+1 (input pieces = the epilogue of m-tile M of the source set) with the epilogue of m-tile M+1 dealt under them
 // and (training kernel) m-tile M saved; MEND: m-tiles of the source the layer consumes (8; the skip layer takes 7 of lin3's)
-template <class C, int NB, int M, int MEND, bool DOT>
+template <class C, int NB, int M, int MEND>
 __device__ __forceinline__ void t_mpair(TAcc& A, TPieces (&bA)[2], TPieces (&bB)[2], TEpi& st, TFrag (&a0)[2], TFrag (&a1)[2], TRing& R, TSave& sv) {
     if constexpr (M < MEND) {
         constexpr int EM = M + 1 < MEND ? M + 1 : -1;
         constexpr bool EN = M + 2 < MEND;                 // m-tile EM + 1 will have its epilogue dealt too
-        using K0 = TK<C, NB, EM, 0, EN, M, DOT>;
-        using K1 = TK<C, NB, EM, 1, EN, -1, DOT>;
+        using K0 = TK<C, NB, EM, 0, EN, M>;
+        using K1 = TK<C, NB, EM, 1, EN, -1>;
         if constexpr (M % 2 == 0) {
             t_kstep<K0>(A, bA[0], bB, st, a0, a1, R, sv);
             t_kstep<K1>(A, bA[1], bB, st, a0, a1, R, sv);
@@ -308,21 +307,19 @@ __device__ __forceinline__ void t_mpair(TAcc& A, TPieces (&bA)[2], TPieces (&bB)
             t_kstep<K0>(A, bB[0], bA, st, a0, a1, R, sv);
             t_kstep<K1>(A, bB[1], bA, st, a0, a1, R, sv);
         }
-        t_mpair<C, NB, M + 1, MEND, DOT>(A, bA, bB, st, a0, a1, R, sv);
+        t_mpair<C, NB, M + 1, MEND>(A, bA, bB, st, a0, a1, R, sv);
     }
 }
 // the main part of a layer: accumulates MEND * 32 input features into set NB from the finished set 1 - NB, whose bias row is
 // at bias_row (LDS byte address, + 16 h); training kernel: the source layer's activations go to the native tile sv.base points at
-template <class C, int NB, int MEND, bool DOT = false>
+template <class C, int NB, int MEND>
 __device__ __forceinline__ void t_layer(TAcc& A, TPieces (&bA)[2], TPieces (&bB)[2], TEpi& st, TFrag (&a0)[2], TFrag (&a1)[2], TRing& R, TSave& sv,
                                         unsigned bias_row) {
     t_zero<NB>(A);
     st.bias_addr = bias_row;
-    t_bias_read_w<0, 0>(st.b, st.bias_addr);
-    if constexpr (DOT) t_bias_read_w<0, 0, 1024>(st.w, st.bias_addr);
-    t_epi_only<0, 0, 96, C::TRAIN, DOT>(A.s[1 - NB][0], bA, st);      // the one exposed epilogue of a layer: m-tile 0 (leaves m-tile 1's first pair in b[0])
+    t_epi_exposed<C::TRAIN>(A.s[1 - NB][0], bA, st);
     __builtin_amdgcn_sched_barrier(0);
-    t_mpair<C, NB, 0, MEND, DOT>(A, bA, bB, st, a0, a1, R, sv);
+    t_mpair<C, NB, 0, MEND>(A, bA, bB, st, a0, a1, R, sv);
 }
 
 // Embedding image of the wave's 32 points in its private LDS rows: [x, sin(2^k x), cos(2^k x)]_{k<6}, zero padded to 48
@@ -372,7 +369,7 @@ __device__ __forceinline__ void t_store_eaux(unsigned col_addr, int fl, __amdgpu
     }
 }
 
-// lin8 row 0 on softplus(lin7 + bias): this lane's 128 features of its point (accumulator set 1)   [no-grad kernel]
+// lin8 row 0 on softplus(lin7 + bias): this lane's 128 features of its point (accumulator set 1)
 template <int M>
 __device__ __forceinline__ void t_final_dot(const TAcc& A, unsigned bias_base, float& s0, float& s1) {
     if constexpr (M < T_NM) {
@@ -410,6 +407,18 @@ __device__ __forceinline__ void t_store_feat(const TAcc& A, unsigned bias_base, 
     }
 }
 
+// this lane's point of the tile, and the NEXT tile's coordinates into xn (fetched while the tile's last exposed section runs: a load
+// issued at a tile's start would be waited for at once, behind every LDS-DMA in flight).  The index is formed from a value the
+// compiler cannot hoist: as a loop invariant it is a 64-bit register pair that gets spilled, and a scratch reload inside the
+// stream waits for every LDS-DMA in flight.
+__device__ __forceinline__ int64_t t_next_points(const float* __restrict__ pts, int64_t npts, int64_t tile, int lp, float (&xn)[3]) {
+    asm volatile("" : "+v"(lp));
+    const int64_t gp = tile * T_PTS + lp, gq = gp + (int64_t)gridDim.x * T_PTS;
+    xn[0] = xn[1] = xn[2] = 0.f;
+    if (gq < npts) { xn[0] = pts[gq * 3 + 0]; xn[1] = pts[gq * 3 + 1]; xn[2] = pts[gq * 3 + 2]; }
+    return gp;
+}
+
 #ifdef DH_T_DEBUG
 // development build: the raw accumulators (pre-bias) of layer dbg_layer as [npts][256]
 template <int NB>
@@ -418,7 +427,7 @@ __device__ __forceinline__ void t_dump(const TAcc& A, float* dbg, int64_t gp, in
     DH_UNROLL for (int m = 0; m < T_NM; ++m)
         DH_UNROLL for (int r = 0; r < 16; ++r) dbg[gp * 256 + 32 * m + 8 * (r / 4) + 4 * h + (r % 4)] = A.s[NB][m][r];
 }
-#define T_DUMP(NB, L) if (dbg_layer == (L)) t_dump<NB>(A, dbg, gp, npts, h)
+#define T_DUMP(NB, L) if (dbg_layer == (L)) t_dump<NB>(A, dbg, tile * T_PTS + wave * 32 + p, npts, h)
 #define T_DBG_PARAMS , float* dbg, int dbg_layer
 #else
 #define T_DUMP(NB, L)
@@ -468,15 +477,12 @@ __device__ __forceinline__ void sdf_chain_t_body(const void* __restrict__ stream
     __builtin_amdgcn_sched_barrier(0);
 
     const int64_t ntiles = (npts + T_PTS - 1) / T_PTS, ntiles64 = (npts + TM - 1) / TM;
-    // a tile's points are fetched while the previous tile's last exposed section runs (a load issued at the tile's start would
-    // be waited for at once, behind every LDS-DMA in flight)
     float xn[3] = {0.f, 0.f, 0.f};
     {
         const int64_t g0 = (int64_t)blockIdx.x * T_PTS + wave * 32 + p;
         if (g0 < npts) { xn[0] = pts[g0 * 3 + 0]; xn[1] = pts[g0 * 3 + 1]; xn[2] = pts[g0 * 3 + 2]; }
     }
     _Pragma("unroll 1") for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const int64_t gp = tile * T_PTS + wave * 32 + p;
         // training kernel: this wave's half (m = wave & 1) of native tile tile64; lane part of every native address
         const int64_t tile64 = 2 * tile + (wave >> 1);
         const char* act_tile = nullptr;                 // act[0]'s native tile; act[l] is l * lstride further
@@ -529,28 +535,23 @@ __device__ __forceinline__ void sdf_chain_t_body(const void* __restrict__ stream
                 T_DUMP(0, 4);
             }
         }
+        // lin8 row 0 (the sdf) on softplus(lin7 + bias): per lane 128 features of its point, the two half-waves add up.  The training
+        // kernel does this too, before lin8's rows 1..256 consume set 1 (forming row 0 inside that layer's dealt epilogue needs two
+        // more in-flight LDS registers, and those were the first thing the compiler spilled)
         {
-            const int64_t gq = gp + (int64_t)gridDim.x * T_PTS;
-            xn[0] = xn[1] = xn[2] = 0.f;
-            if (gq < npts) { xn[0] = pts[gq * 3 + 0]; xn[1] = pts[gq * 3 + 1]; xn[2] = pts[gq * 3 + 2]; }
-        }
-        if constexpr (C::TRAIN) {
-            // lin8 rows 1..256 from softplus(lin7 + bias) into set 0; its epilogue saves act[7] and forms row 0 (the sdf) on the way
-            st.dot0 = st.dot1 = 0.f;
-            sv.rsrc = t_tile_rsrc(act_tile + 7 * lstride, tile_ok, TILE_F * 4);
-            t_layer<C, 0, 8, true>(A, bA, bB, st, a0, a1, R, sv, bias_base + 7 * 1024);
-            float s = st.dot0 + st.dot1;
-            s += __shfl_xor(s, 32);
-            if (h == 0 && gp < npts) sdf_out[gp] = s + b8_0[0];
-            sv.rsrc = t_tile_rsrc(feat + tile64 * TILE_F, tile_ok, TILE_F * 4);
-            t_store_feat<0>(A, bias_base, st, sv);
-        } else {
-            // lin8 row 0 on softplus(lin7 + bias): per lane 128 features of its point, the two half-waves add up
+            const int64_t gp = t_next_points(pts, npts, tile, wave * 32 + p, xn);
             float s0 = 0.f, s1 = 0.f;
             t_final_dot<0>(A, bias_base, s0, s1);
             float s = s0 + s1;
             s += __shfl_xor(s, 32);
             if (h == 0 && gp < npts) sdf_out[gp] = s + b8_0[0];
+        }
+        if constexpr (C::TRAIN) {
+            // lin8 rows 1..256 from softplus(lin7 + bias) into set 0 (its epilogue saves act[7]), then the feature tile
+            sv.rsrc = t_tile_rsrc(act_tile + 7 * lstride, tile_ok, TILE_F * 4);
+            t_layer<C, 0, 8>(A, bA, bB, st, a0, a1, R, sv, bias_base + 7 * 1024);
+            sv.rsrc = t_tile_rsrc(feat + tile64 * TILE_F, tile_ok, TILE_F * 4);
+            t_store_feat<0>(A, bias_base, st, sv);
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the ring runs ahead of the last tile: let its DMAs land before the LDS goes away
