@@ -1,5 +1,6 @@
-// Register-resident ("transposed") SDF chain, forward only: sdf_nograd_t_kernel   (round 3; scripts/micro/tchain_micro.hip is the
-// timing study this kernel is built from, profiles/r03_ab_register_resident_chain.json its record).
+// Register-resident ("transposed") SDF forward chains: sdf_nograd_t_kernel (sdf only) and sdf_fwd_train_t_kernel (sdf + every tile
+// the backward pass needs)   (round 3; scripts/micro/tchain_micro.hip is the timing study they are built from,
+// profiles/r03_ab_register_resident_chain.json its record, profiles/r03_ab_chain_t.json the A/B against the tile16.h kernels).
 //
 //   out^T[feature][point] = W[feature][k] * act^T[k][point]: the WEIGHTS are the MFMA A operand, the activations the B operand.  A
 //   wave owns 32 points (the MFMA's column axis = its lane & 31) and ALL 256 features of a layer: 8 accumulators (m-tiles) of
@@ -12,10 +13,12 @@
 //   while the epilogue of m-tile M + 1 of layer l - 1 is dealt, one micro-step per MFMA, under k-steps 2 M, 2 M + 1 of layer l
 //   (which need only m-tile M).  Only m-tile 0's epilogue is exposed.
 //   Weights enter the CU once per 128 points: an LDS ring of 24 KB stages (one 16-deep k-step of all 256 output features, three
-//   bf16 pieces) filled by LDS-DMA (buffer_load ... lds) dealt singly between MFMAs, one raw s_barrier per k-step; the 116
-//   stages of the network (3 + 16 + 16 + 16 + (14 + 3) + 16 + 16 + 16) are one cyclic stream, so the ring never drains between
-//   layers or tiles.  The per-layer biases and lin8's row 0 sit in LDS (9 KB); the embedding's 24 values per lane are kept
-//   in a wave-private LDS stash for the skip layer.
+//   bf16 pieces) filled by LDS-DMA (buffer_load ... lds) dealt singly between MFMAs, one raw s_barrier per k-step; the stages
+//   of the network (3 + 16 + 16 + 16 + (14 + 3) + 16 + 16 + 16 = 116; + 16 of lin8's rows 1..256 in the training kernel) are
+//   one cyclic stream, so the ring never drains between layers or tiles.  The per-layer biases and lin8's row 0 sit in LDS
+//   (10 KB); the embedding image of a wave's 32 points stays in LDS for the skip layer.
+//   The training kernel writes the tiles of sdf_fwd_train_kernel (tile.h native layout, 64 points): an m-tile's activations are
+//   transposed through a wave-private LDS patch (lane-per-point -> four consecutive points per lane) on their way out.
 // Arithmetic: the same six bf16 products per fp32 product, smallest terms first, as tile16.h.
 #include "mlp_common.h"
 #include "kernels.h"
