@@ -28,7 +28,7 @@ struct DwJobs { DwJob j[16]; int n; };
 #define DW_GROUPS 8
 #endif
 #ifndef DW_AUX_COST
-#define DW_AUX_COST 10.0
+#define DW_AUX_COST 8.0
 #endif
 struct DwGroups { int n; int job0[DW_GROUPS + 1]; int wg0[DW_GROUPS + 1]; int64_t off0[DW_GROUPS + 1]; };
 __device__ __forceinline__ int dw_group_of(const DwGroups& Gp, int g) {
@@ -556,7 +556,8 @@ static DwGroups build_dw_groups(const DwJobs& J, int G) {
     const int ng = DW_GROUPS < G ? DW_GROUPS : (G < 1 ? 1 : G);
     double cost[16], total = 0.0;
     // cost of a job per tile: a main job (64 KB + 64 KB of operands, 48 MFMAs per wave and 16 points) = 16; an aux job (64 KB +
-    // 16 KB, a quarter of the MFMAs) is bound by its bytes = 10; two operand pairs = twice
+    // 16 KB, a quarter of the MFMAs) is bound by its bytes: DW_AUX_COST, measured (8 ... 12 swept, profiles/r03_ab_dw_job_groups.json);
+    // two operand pairs = twice
     for (int j = 0; j < J.n; ++j) { cost[j] = (J.j[j].nb == 8 ? 16.0 : (double)DW_AUX_COST) * (J.j[j].A2 ? 2 : 1); total += cost[j]; }
     // greedy contiguous partition: close a group when its cost reaches the running target
     Gp.n = ng; Gp.job0[0] = 0;
