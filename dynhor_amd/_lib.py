@@ -36,6 +36,19 @@ SIGNATURES = {
     "dh_weight_grads_gemm": (_i32, [_i64, _vp, _vp]),
     "dh_weight_grads_fold": (_i32, [_vp, _vp, _i64, _vp, _vp, _vp]),
     "dh_mlp_backward": (_i32, [_vp, _vp, _vp, _i64] + [_vp] * 7),
+    # the same stages with the arithmetic passed explicitly (no process-global state)
+    "dh_sdf_nograd_ex": (_i32, [_i32, _vp, _vp, _i64, _vp, _vp]),
+    "dh_mlp_forward_ex": (_i32, [_i32, _vp, _vp, _vp, _i32, _i64, _vp, _vp, _vp, _vp, _vp]),
+    "dh_sdf_forward_ex": (_i32, [_i32, _vp, _vp, _i64, _vp, _vp, _vp]),
+    "dh_sdf_gradient_ex": (_i32, [_i32, _vp, _vp, _i64, _vp, _vp, _i32, _vp]),
+    "dh_color_forward_ex": (_i32, [_i32, _vp, _vp, _vp, _i32, _vp, _i64, _vp, _vp, _i32, _vp]),
+    "dh_color_backward_ex": (_i32, [_i32, _vp, _vp, _vp, _i64, _vp, _vp, _vp]),
+    "dh_sdf_tangent_ex": (_i32, [_i32, _vp, _vp, _vp, _i64, _vp, _vp]),
+    "dh_sdf_backward_ex": (_i32, [_i32, _vp, _vp, _i64, _vp, _vp]),
+    "dh_color_backward_rays_ex": (_i32, [_i32, _vp, _vp, _vp, _vp, _i32, _i64, _vp, _vp, _vp, _vp, _vp]),
+    "dh_sdf_backward_rays_ex": (_i32, [_i32, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp]),
+    "dh_weight_grads_gemm_ex": (_i32, [_i32, _i64, _vp, _vp]),
+    "dh_mlp_backward_ex": (_i32, [_i32, _vp, _vp, _vp, _i64] + [_vp] * 7),
     "dh_adam_step": (_i32, [_vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _i64, _f32, _vp]),
     "dh_hashgrid_entries": (_i64, []),
     "dh_hashgrid_level": (_i32, [_i32, ctypes.POINTER(_f32), ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint32),
@@ -91,12 +104,19 @@ def lib():
     return _LIB
 
 
-ARITH_SPLIT_BF16, ARITH_FP32_MFMA = 0, 1
+ARITH_SPLIT_BF16, ARITH_FP32_MFMA, ARITH_SPLIT_F16 = 0, 1, 2
+ARITH_DEFAULT = ARITH_SPLIT_F16
+ARITH_NAMES = {"split_f16": ARITH_SPLIT_F16, "split_bf16": ARITH_SPLIT_BF16, "fp32_mfma": ARITH_FP32_MFMA}
 
 # stage (StageTimer / bench.py name) -> HIP kernel that runs it, per arithmetic mode.  bench.py's roofline block and
 # scripts/make_traffic_json.py (rocprofv3 PMC -> HBM bytes per launch) both read THIS table, so a renamed or removed kernel
 # cannot leave a stale entry behind.
 STAGE_KERNELS = {
+    ARITH_SPLIT_F16: {"weight_grads_gemm": "dw_f16x2_kernel", "sdf_forward": "sdf_fwd_train_h_kernel",
+                      "sdf_gradient": "sdf_grad_h_kernel", "color_forward": "color_fwd_h_kernel",
+                      "color_backward": "color_bwd_h_kernel", "sdf_tangent": "sdf_tangent_h_kernel",
+                      "sdf_backward": "sdf_bwd_h_kernel", "sdf_nograd_coarse": "sdf_nograd_h_kernel",
+                      "sdf_nograd_fine": "sdf_nograd_h_kernel"},
     ARITH_SPLIT_BF16: {"weight_grads_gemm": "dw_bf16x3_kernel", "sdf_forward": "sdf_fwd_train_t_kernel",
                        "sdf_gradient": "sdf_grad_s_kernel", "color_forward": "color_fwd_s_kernel",
                        "color_backward": "color_bwd_s_kernel", "sdf_tangent": "sdf_tangent_s_kernel",
@@ -114,7 +134,8 @@ HASH_STAGE_LAUNCHES = {"hash_weight_grads": ["small_dw_kernel", "small_dw_reduce
 
 
 def set_arithmetic(mode: int):
-    """dh_set_arithmetic: 0 = split-bf16 kernels (shipping), 1 = native fp32-MFMA twins.  Process-wide."""
+    """dh_set_arithmetic: the DEFAULT arithmetic of the entry points without an arithmetic argument (2 = two-piece fp16 split,
+    shipping; 0 = three-piece bf16 split; 1 = native fp32-MFMA twins).  Process-wide; the renderers pass theirs per call."""
     check(lib().dh_set_arithmetic(int(mode)))
 
 

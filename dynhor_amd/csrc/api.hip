@@ -9,23 +9,24 @@ using namespace dh;
 
 namespace dh {
 // the library's only process-global state (include/dynhor_hip.h "Conventions")
-static int g_arith = DH_ARITH_SPLIT_BF16;
+static int g_arith = DH_ARITH_SPLIT_F16;
 static int g_hash_scatter = 0;
-bool arith_fp32() { return __atomic_load_n(&g_arith, __ATOMIC_RELAXED) == DH_ARITH_FP32_MFMA; }
 int hash_scatter_mode() { return __atomic_load_n(&g_hash_scatter, __ATOMIC_RELAXED); }
 }  // namespace dh
 
 namespace {
 inline bool misaligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) != 0; }
+inline bool bad_arith(int a) { return a != DH_ARITH_SPLIT_BF16 && a != DH_ARITH_FP32_MFMA && a != DH_ARITH_SPLIT_F16; }
+inline int cur_arith() { return __atomic_load_n(&dh::g_arith, __ATOMIC_RELAXED); }
 constexpr int DEFAULT_GRID = 256 * 2;   // persistent workgroups: all that are co-resident (two 64-point tiles per CU)
 }  // namespace
 
 extern "C" {
 
-int dh_version(void) { return 2; }
+int dh_version(void) { return 3; }
 
 int dh_set_arithmetic(int mode) {
-    if (mode != DH_ARITH_SPLIT_BF16 && mode != DH_ARITH_FP32_MFMA) return DH_ERR_BAD_ARG;
+    if (bad_arith(mode)) return DH_ERR_BAD_ARG;
     __atomic_store_n(&dh::g_arith, mode, __ATOMIC_RELAXED);
     return DH_OK;
 }
@@ -48,7 +49,7 @@ const char* dh_strerror(int status) {
 }
 
 int64_t dh_num_params(void) { return N_PARAMS; }
-int64_t dh_packed_floats(void) { return PACKT.total; }
+int64_t dh_packed_floats(void) { return PACKH.total; }
 
 int dh_param_layout(int net, int layer, int64_t* bias_off, int64_t* g_off, int64_t* v_off, int* out_dim, int* in_dim) {
     if (!bias_off || !g_off || !v_off || !out_dim || !in_dim) return DH_ERR_BAD_ARG;
@@ -73,11 +74,11 @@ int dh_pack_weights(const float* params, float* packed, void* stream) {
     return launch_pack_weights(params, packed, static_cast<hipStream_t>(stream));
 }
 
-int dh_sdf_nograd(const float* packed, const float* pts, int64_t npts, float* sdf, void* stream) {
-    if (npts < 0) return DH_ERR_BAD_ARG;
+int dh_sdf_nograd_ex(int arithmetic, const float* packed, const float* pts, int64_t npts, float* sdf, void* stream) {
+    if (npts < 0 || bad_arith(arithmetic)) return DH_ERR_BAD_ARG;
     if (npts == 0) return DH_OK;
     if (!packed || !pts || !sdf || misaligned16(packed)) return DH_ERR_BAD_ARG;
-    return launch_sdf_nograd(packed, pts, npts, sdf, DEFAULT_GRID, static_cast<hipStream_t>(stream));
+    return launch_sdf_nograd(packed, pts, npts, sdf, DEFAULT_GRID, arithmetic, static_cast<hipStream_t>(stream));
 }
 
 int dh_workspace_floats(int64_t npts, int64_t* infer_floats, int64_t* fwd_floats, int64_t* total_floats) {
@@ -89,89 +90,94 @@ int dh_workspace_floats(int64_t npts, int64_t* infer_floats, int64_t* fwd_floats
     return DH_OK;
 }
 
-int dh_sdf_forward(const float* packed, const float* pts, int64_t npts, float* ws, float* sdf, void* stream) {
+int dh_sdf_forward_ex(int arithmetic, const float* packed, const float* pts, int64_t npts, float* ws, float* sdf, void* stream) {
+    if (bad_arith(arithmetic)) return DH_ERR_BAD_ARG;
     if (npts <= 0) return npts == 0 ? DH_OK : DH_ERR_BAD_ARG;
     if (!packed || !pts || !ws || !sdf || misaligned16(packed) || misaligned16(ws)) return DH_ERR_BAD_ARG;
     const Workspace w = carve_workspace(ws, npts);
-    return launch_sdf_fwd_train(packed, pts, npts, sdf, w.feat, w.act, w.eaux, DEFAULT_GRID, static_cast<hipStream_t>(stream));
+    return launch_sdf_fwd_train(packed, pts, npts, sdf, w.feat, w.act, w.eaux, w.absmax, DEFAULT_GRID, arithmetic, static_cast<hipStream_t>(stream));
 }
 
-int dh_sdf_gradient(const float* packed, const float* pts, int64_t npts, float* ws, float* normals, int save, void* stream) {
+int dh_sdf_gradient_ex(int arithmetic, const float* packed, const float* pts, int64_t npts, float* ws, float* normals, int save,
+                       void* stream) {
+    if (bad_arith(arithmetic)) return DH_ERR_BAD_ARG;
     if (npts <= 0) return npts == 0 ? DH_OK : DH_ERR_BAD_ARG;
     if (!packed || !pts || !ws || !normals || misaligned16(packed) || misaligned16(ws)) return DH_ERR_BAD_ARG;
     const Workspace w = carve_workspace(ws, npts);
     if (save < 0 || save > 2) return DH_ERR_BAD_ARG;
-    return launch_sdf_grad(packed, pts, npts, w.act, w.asave, normals, save, w.gesave, DEFAULT_GRID, static_cast<hipStream_t>(stream));
+    return launch_sdf_grad(packed, pts, npts, w.act, w.asave, normals, save, w.gesave, w.absmax, DEFAULT_GRID, arithmetic,
+                           static_cast<hipStream_t>(stream));
 }
 
-int dh_color_forward(const float* packed, const float* pts, const float* dirs, int n_per_ray, const float* normals,
-                     int64_t npts, float* ws, float* color, int save, void* stream) {
-    if (npts < 0 || n_per_ray <= 0) return DH_ERR_BAD_ARG;
+int dh_color_forward_ex(int arithmetic, const float* packed, const float* pts, const float* dirs, int n_per_ray, const float* normals,
+                        int64_t npts, float* ws, float* color, int save, void* stream) {
+    if (npts < 0 || n_per_ray <= 0 || bad_arith(arithmetic)) return DH_ERR_BAD_ARG;
     if (npts == 0) return DH_OK;
     if (!packed || !pts || !dirs || !normals || !ws || !color || misaligned16(packed) || misaligned16(ws)) return DH_ERR_BAD_ARG;
     const Workspace w = carve_workspace(ws, npts);
-    return launch_color_fwd(packed, pts, dirs, n_per_ray, normals, w.feat, npts, color, w.cact, w.caux, save, DEFAULT_GRID,
-                            static_cast<hipStream_t>(stream));
+    return launch_color_fwd(packed, pts, dirs, n_per_ray, normals, w.feat, npts, color, w.cact, w.caux, save, w.absmax, DEFAULT_GRID,
+                            arithmetic, static_cast<hipStream_t>(stream));
 }
 
-int dh_mlp_forward(const float* packed, const float* pts, const float* dirs, int n_per_ray, int64_t npts, float* ws,
-                   float* sdf, float* normals, float* color, void* stream) {
-    int rc = dh_sdf_forward(packed, pts, npts, ws, sdf, stream);
+int dh_mlp_forward_ex(int arithmetic, const float* packed, const float* pts, const float* dirs, int n_per_ray, int64_t npts, float* ws,
+                      float* sdf, float* normals, float* color, void* stream) {
+    int rc = dh_sdf_forward_ex(arithmetic, packed, pts, npts, ws, sdf, stream);
     if (rc) return rc;
-    rc = dh_sdf_gradient(packed, pts, npts, ws, normals, 1, stream);
+    rc = dh_sdf_gradient_ex(arithmetic, packed, pts, npts, ws, normals, 1, stream);
     if (rc) return rc;
-    return dh_color_forward(packed, pts, dirs, n_per_ray, normals, npts, ws, color, 1, stream);
+    return dh_color_forward_ex(arithmetic, packed, pts, dirs, n_per_ray, normals, npts, ws, color, 1, stream);
 }
 
-int dh_color_backward(const float* packed, const float* colors, const float* d_colors, int64_t npts, float* ws,
-                      float* d_normals, void* stream) {
-    if (npts <= 0) return DH_ERR_BAD_ARG;
+int dh_color_backward_ex(int arithmetic, const float* packed, const float* colors, const float* d_colors, int64_t npts, float* ws,
+                         float* d_normals, void* stream) {
+    if (npts <= 0 || bad_arith(arithmetic)) return DH_ERR_BAD_ARG;
     if (!packed || !colors || !d_colors || !ws || !d_normals || misaligned16(packed) || misaligned16(ws)) return DH_ERR_BAD_ARG;
     const Workspace w = carve_workspace(ws, npts);
-    return launch_color_bwd(packed, colors, d_colors, npts, w.cact, w.czbar, w.featbar, d_normals, w.tpart, DEFAULT_GRID,
-                            static_cast<hipStream_t>(stream));
+    return launch_color_bwd(packed, colors, d_colors, npts, w.cact, w.czbar, w.featbar, d_normals, w.tpart, w.absmax, DEFAULT_GRID,
+                            arithmetic, static_cast<hipStream_t>(stream));
 }
 
-int dh_sdf_tangent(const float* packed, const float* pts, const float* d_normals, int64_t npts, float* ws, void* stream) {
-    if (npts <= 0) return DH_ERR_BAD_ARG;
+int dh_sdf_tangent_ex(int arithmetic, const float* packed, const float* pts, const float* d_normals, int64_t npts, float* ws,
+                      void* stream) {
+    if (npts <= 0 || bad_arith(arithmetic)) return DH_ERR_BAD_ARG;
     if (!packed || !pts || !d_normals || !ws || misaligned16(packed) || misaligned16(ws)) return DH_ERR_BAD_ARG;
     const Workspace w = carve_workspace(ws, npts);
-    return launch_sdf_tangent(packed, pts, d_normals, npts, w.act, w.asave, w.t0aux, w.tsave, w.rsave, w.tpart, DEFAULT_GRID,
-                              static_cast<hipStream_t>(stream));
+    return launch_sdf_tangent(packed, pts, d_normals, npts, w.act, w.asave, w.t0aux, w.tsave, w.rsave, w.tpart, w.absmax, DEFAULT_GRID,
+                              arithmetic, static_cast<hipStream_t>(stream));
 }
 
-int dh_sdf_backward(const float* packed, const float* d_sdf, int64_t npts, float* ws, void* stream) {
-    if (npts <= 0) return DH_ERR_BAD_ARG;
+int dh_sdf_backward_ex(int arithmetic, const float* packed, const float* d_sdf, int64_t npts, float* ws, void* stream) {
+    if (npts <= 0 || bad_arith(arithmetic)) return DH_ERR_BAD_ARG;
     if (!packed || !d_sdf || !ws || misaligned16(packed) || misaligned16(ws)) return DH_ERR_BAD_ARG;
     const Workspace w = carve_workspace(ws, npts);
-    return launch_sdf_bwd(packed, d_sdf, npts, w.act, w.rsave, w.featbar, w.zbar, w.tpart, DEFAULT_GRID,
+    return launch_sdf_bwd(packed, d_sdf, npts, w.act, w.rsave, w.featbar, w.zbar, w.tpart, w.absmax, DEFAULT_GRID, arithmetic,
                           static_cast<hipStream_t>(stream));
 }
 
-int dh_color_backward_rays(const float* packed, const float* colors, const float* d_colors, const float* dirs, int n_per_ray,
-                           int64_t npts, float* ws, float* d_normals, float* d_pts, float* d_dirs_pts, void* stream) {
-    if (npts <= 0 || n_per_ray <= 0) return DH_ERR_BAD_ARG;
+int dh_color_backward_rays_ex(int arithmetic, const float* packed, const float* colors, const float* d_colors, const float* dirs,
+                              int n_per_ray, int64_t npts, float* ws, float* d_normals, float* d_pts, float* d_dirs_pts, void* stream) {
+    if (npts <= 0 || n_per_ray <= 0 || bad_arith(arithmetic)) return DH_ERR_BAD_ARG;
     if (!packed || !colors || !d_colors || !dirs || !ws || !d_normals || !d_pts || !d_dirs_pts || misaligned16(packed) || misaligned16(ws))
         return DH_ERR_BAD_ARG;
     const Workspace w = carve_workspace(ws, npts);
     return launch_color_bwd_rays(packed, colors, d_colors, dirs, n_per_ray, npts, w.cact, w.czbar, w.featbar, d_normals, w.tpart,
-                                 d_pts, d_dirs_pts, DEFAULT_GRID, static_cast<hipStream_t>(stream));
+                                 d_pts, d_dirs_pts, w.absmax, DEFAULT_GRID, arithmetic, static_cast<hipStream_t>(stream));
 }
 
-int dh_sdf_backward_rays(const float* packed, const float* d_sdf, const float* pts, const float* d_normals, int64_t npts,
-                         float* ws, float* d_pts, void* stream) {
-    if (npts <= 0) return DH_ERR_BAD_ARG;
+int dh_sdf_backward_rays_ex(int arithmetic, const float* packed, const float* d_sdf, const float* pts, const float* d_normals,
+                            int64_t npts, float* ws, float* d_pts, void* stream) {
+    if (npts <= 0 || bad_arith(arithmetic)) return DH_ERR_BAD_ARG;
     if (!packed || !d_sdf || !pts || !d_normals || !ws || !d_pts || misaligned16(packed) || misaligned16(ws)) return DH_ERR_BAD_ARG;
     const Workspace w = carve_workspace(ws, npts);
     return launch_sdf_bwd_rays(packed, d_sdf, pts, d_normals, npts, w.act, w.rsave, w.featbar, w.gesave, w.zbar, w.tpart, d_pts,
-                               DEFAULT_GRID, static_cast<hipStream_t>(stream));
+                               w.absmax, DEFAULT_GRID, arithmetic, static_cast<hipStream_t>(stream));
 }
 
-int dh_weight_grads_gemm(int64_t npts, float* ws, void* stream) {
-    if (npts <= 0) return DH_ERR_BAD_ARG;
+int dh_weight_grads_gemm_ex(int arithmetic, int64_t npts, float* ws, void* stream) {
+    if (npts <= 0 || bad_arith(arithmetic)) return DH_ERR_BAD_ARG;
     if (!ws || misaligned16(ws)) return DH_ERR_BAD_ARG;
     const Workspace w = carve_workspace(ws, npts);
-    return launch_weight_grads_gemm(w, w.slabs, DW_G, static_cast<hipStream_t>(stream));
+    return launch_weight_grads_gemm(w, w.slabs, DW_G, arithmetic, static_cast<hipStream_t>(stream));
 }
 
 int dh_weight_grads_fold(const float* packed, const float* params, int64_t npts, float* ws, float* grad_flat, void* stream) {
@@ -181,18 +187,61 @@ int dh_weight_grads_fold(const float* packed, const float* params, int64_t npts,
     return launch_weight_grads_fold(w, w.slabs, w.tred, DW_G, DW_NS, params, packed, grad_flat, static_cast<hipStream_t>(stream));
 }
 
+int dh_mlp_backward_ex(int arithmetic, const float* packed, const float* params, const float* pts, int64_t npts, float* ws,
+                       const float* colors, const float* d_sdf, float* d_normals, const float* d_colors, float* grad_flat,
+                       void* stream) {
+    int rc = dh_color_backward_ex(arithmetic, packed, colors, d_colors, npts, ws, d_normals, stream);
+    if (rc) return rc;
+    rc = dh_sdf_tangent_ex(arithmetic, packed, pts, d_normals, npts, ws, stream);
+    if (rc) return rc;
+    rc = dh_sdf_backward_ex(arithmetic, packed, d_sdf, npts, ws, stream);
+    if (rc) return rc;
+    rc = dh_weight_grads_gemm_ex(arithmetic, npts, ws, stream);
+    if (rc) return rc;
+    return dh_weight_grads_fold(packed, params, npts, ws, grad_flat, stream);
+}
+
+// the entry points without an arithmetic argument: the process default (dh_set_arithmetic)
+int dh_sdf_nograd(const float* packed, const float* pts, int64_t npts, float* sdf, void* stream) {
+    return dh_sdf_nograd_ex(cur_arith(), packed, pts, npts, sdf, stream);
+}
+int dh_sdf_forward(const float* packed, const float* pts, int64_t npts, float* ws, float* sdf, void* stream) {
+    return dh_sdf_forward_ex(cur_arith(), packed, pts, npts, ws, sdf, stream);
+}
+int dh_sdf_gradient(const float* packed, const float* pts, int64_t npts, float* ws, float* normals, int save, void* stream) {
+    return dh_sdf_gradient_ex(cur_arith(), packed, pts, npts, ws, normals, save, stream);
+}
+int dh_color_forward(const float* packed, const float* pts, const float* dirs, int n_per_ray, const float* normals,
+                     int64_t npts, float* ws, float* color, int save, void* stream) {
+    return dh_color_forward_ex(cur_arith(), packed, pts, dirs, n_per_ray, normals, npts, ws, color, save, stream);
+}
+int dh_mlp_forward(const float* packed, const float* pts, const float* dirs, int n_per_ray, int64_t npts, float* ws,
+                   float* sdf, float* normals, float* color, void* stream) {
+    return dh_mlp_forward_ex(cur_arith(), packed, pts, dirs, n_per_ray, npts, ws, sdf, normals, color, stream);
+}
+int dh_color_backward(const float* packed, const float* colors, const float* d_colors, int64_t npts, float* ws,
+                      float* d_normals, void* stream) {
+    return dh_color_backward_ex(cur_arith(), packed, colors, d_colors, npts, ws, d_normals, stream);
+}
+int dh_sdf_tangent(const float* packed, const float* pts, const float* d_normals, int64_t npts, float* ws, void* stream) {
+    return dh_sdf_tangent_ex(cur_arith(), packed, pts, d_normals, npts, ws, stream);
+}
+int dh_sdf_backward(const float* packed, const float* d_sdf, int64_t npts, float* ws, void* stream) {
+    return dh_sdf_backward_ex(cur_arith(), packed, d_sdf, npts, ws, stream);
+}
+int dh_color_backward_rays(const float* packed, const float* colors, const float* d_colors, const float* dirs, int n_per_ray,
+                           int64_t npts, float* ws, float* d_normals, float* d_pts, float* d_dirs_pts, void* stream) {
+    return dh_color_backward_rays_ex(cur_arith(), packed, colors, d_colors, dirs, n_per_ray, npts, ws, d_normals, d_pts, d_dirs_pts, stream);
+}
+int dh_sdf_backward_rays(const float* packed, const float* d_sdf, const float* pts, const float* d_normals, int64_t npts,
+                         float* ws, float* d_pts, void* stream) {
+    return dh_sdf_backward_rays_ex(cur_arith(), packed, d_sdf, pts, d_normals, npts, ws, d_pts, stream);
+}
+int dh_weight_grads_gemm(int64_t npts, float* ws, void* stream) { return dh_weight_grads_gemm_ex(cur_arith(), npts, ws, stream); }
 int dh_mlp_backward(const float* packed, const float* params, const float* pts, int64_t npts, float* ws,
                     const float* colors, const float* d_sdf, float* d_normals, const float* d_colors, float* grad_flat,
                     void* stream) {
-    int rc = dh_color_backward(packed, colors, d_colors, npts, ws, d_normals, stream);
-    if (rc) return rc;
-    rc = dh_sdf_tangent(packed, pts, d_normals, npts, ws, stream);
-    if (rc) return rc;
-    rc = dh_sdf_backward(packed, d_sdf, npts, ws, stream);
-    if (rc) return rc;
-    rc = dh_weight_grads_gemm(npts, ws, stream);
-    if (rc) return rc;
-    return dh_weight_grads_fold(packed, params, npts, ws, grad_flat, stream);
+    return dh_mlp_backward_ex(cur_arith(), packed, params, pts, npts, ws, colors, d_sdf, d_normals, d_colors, grad_flat, stream);
 }
 
 int dh_gen_rays(const uint8_t* rgb, const int8_t* label, const uint8_t* normal, const float* R, const float* T,

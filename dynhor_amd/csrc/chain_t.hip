@@ -19,35 +19,59 @@
 //   (10 KB); the embedding image of a wave's 32 points stays in LDS for the skip layer.
 //   The training kernel writes the tiles of sdf_fwd_train_kernel (tile.h native layout, 64 points): an m-tile's activations are
 //   transposed through a wave-private LDS patch (lane-per-point -> four consecutive points per lane) on their way out.
-// Arithmetic: the same six bf16 products per fp32 product, smallest terms first, as tile16.h.
+// Arithmetic (template parameter AR): TArB3 = the same six bf16 products per fp32 product, smallest terms first, as tile16.h;
+// TArH2 (round 4) = tile16h.h's two fp16 pieces / three products: a stage is 16 KB (two pieces), the chain carries its activations
+// scaled by H2_XS = 16 (bias rows pre-scaled, softplus evaluated in the scaled variable: same operation count, bit-identical
+// values after the exact division by 16 on the way to a saved tile), the weights by the linear's power of two (its reciprocal
+// multiplies the accumulator in the epilogue's first fma), and the dealt epilogue runs two micro-steps per MFMA.
 #include "mlp_common.h"
+#include "tile16h.h"
 #include "kernels.h"
 
 namespace dh {
 
 constexpr int T_NM = 8;                          // 32-feature m-tiles of a 256-wide layer
-constexpr int T_STAGE_BYTES = T_NM * 3 * 1024;   // one k-step of weight pieces: 8 m-tiles x 3 pieces x 1 KiB fragments
-constexpr int T_DMA = T_NM * 3 / 4;              // 6 LDS-DMA instructions per wave and k-step
 constexpr int T_PTS = 128;                       // points per workgroup tile
-constexpr int T_BIAS_BYTES = 10 * 1024;          // layout.h PACKT.bias10
+struct TArB3 {                                   // three bf16 pieces, six products
+    static constexpr bool H = false;
+    static constexpr int NP = 3, NPROD = 6;
+    static constexpr int STAGE_BYTES = T_NM * 3 * 1024;      // one k-step of weight pieces: 8 m-tiles x 3 pieces x 1 KiB fragments
+    static constexpr int DMA = T_NM * 3 / 4;                 // 6 LDS-DMA instructions per wave and k-step
+    static constexpr int BIAS_BYTES = 10 * 1024;             // layout.h PACKT.bias10
+    static constexpr int pw[6] = {2, 1, 0, 1, 0, 0}, px[6] = {0, 1, 2, 0, 1, 0};      // smallest terms first (tile16.h mfma6)
+    static __device__ __forceinline__ f32x16 mfma(const u32x4& a, const u32x4& b, const f32x16& c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    }
+};
+struct TArH2 {                                   // two fp16 pieces, three products (tile16h.h)
+    static constexpr bool H = true;
+    static constexpr int NP = 2, NPROD = 3;
+    static constexpr int STAGE_BYTES = T_NM * 2 * 1024;
+    static constexpr int DMA = T_NM * 2 / 4;                 // 4
+    static constexpr int BIAS_BYTES = 11 * 1024;             // layout.h PACKH.bias11
+    static constexpr int pw[3] = {1, 0, 0}, px[3] = {0, 1, 0};                        // w_lo x_hi, w_hi x_lo, w_hi x_hi
+    static __device__ __forceinline__ f32x16 mfma(const u32x4& a, const u32x4& b, const f32x16& c) { return mfma_h(a, b, c); }
+};
 constexpr int T_EMB_LD = 52;                     // floats per point of the embedding image (48 + pad: b128 reads of 16 rows conflict free)
 constexpr int T_EMB_BYTES = 32 * T_EMB_LD * 4;   // per wave: its 32 points x [39 embedding values, zero padded to 48]
 constexpr int T_PATCH_LD = 40;                   // floats per feature row of the transposition patch (4 * 40 % 64 == 32: the two half-waves' writes hit different banks)
 constexpr int T_PATCH_BYTES = 32 * T_PATCH_LD * 4;
-static_assert(T_STREAM_STAGES_TRAIN * T_STAGE_BYTES == PACKT_STREAM_FLOATS * 4, "layout.h PACKT");
+static_assert(T_STREAM_STAGES_TRAIN * TArB3::STAGE_BYTES == PACKT_STREAM_FLOATS * 4, "layout.h PACKT");
+static_assert(T_STREAM_STAGES_TRAIN * TArH2::STAGE_BYTES == PACKTH_STREAM_FLOATS * 4, "layout.h PACKH");
 
 // NSTAGE ring slots / DEPTH k-steps in flight (NSTAGE >= DEPTH + 2: the barrier sits mid-step); STAGES: length of the cyclic
 // weight stream (the no-grad kernel stops before lin8's rows 1..256)
-struct TCfgNoGrad { static constexpr bool TRAIN = false; static constexpr int NSTAGE = 5, DEPTH = 3, STAGES = T_STREAM_STAGES_NOGRAD; };
-struct TCfgTrain { static constexpr bool TRAIN = true; static constexpr int NSTAGE = 4, DEPTH = 2, STAGES = T_STREAM_STAGES_TRAIN; };
-template <class C> constexpr int t_lds_bytes() { return C::NSTAGE * T_STAGE_BYTES + T_BIAS_BYTES + 4 * T_EMB_BYTES + (C::TRAIN ? 4 * T_PATCH_BYTES : 0); }
+template <class AR_> struct TCfgNoGrad { using AR = AR_; static constexpr bool TRAIN = false; static constexpr int NSTAGE = 5, DEPTH = 3, STAGES = T_STREAM_STAGES_NOGRAD; };
+template <class AR_> struct TCfgTrain { using AR = AR_; static constexpr bool TRAIN = true; static constexpr int NSTAGE = AR_::H ? 5 : 4, DEPTH = AR_::H ? 3 : 2, STAGES = T_STREAM_STAGES_TRAIN; };
+template <class C> constexpr int t_lds_bytes() { return C::NSTAGE * C::AR::STAGE_BYTES + C::AR::BIAS_BYTES + 4 * T_EMB_BYTES + (C::TRAIN ? 4 * T_PATCH_BYTES : 0); }
 
-struct TPieces { u32x4 p[3]; };                  // one k-step of the activation (B) operand: 3 bf16x8 pieces
-struct TFrag { u32x4 p[3]; };                    // one m-tile's weight (A) fragments of a k-step
+template <class AR> struct TPieces { u32x4 p[AR::NP]; };      // one k-step of the activation (B) operand
+template <class AR> struct TFrag { u32x4 p[AR::NP]; };        // one m-tile's weight (A) fragments of a k-step
 struct TAcc { f32x16 s[2][T_NM]; };
 // epilogue state.  b = the pair's biases (the next pair's are read into the same registers right after their last use).  Training
 // kernel only: patch_wr = the lane's write address in the patch, hd = pair 0's activations on their way to the patch
-struct TEpi { f32x2 x, t, e, u, b, hd; unsigned bias_addr, patch_wr; };
+// (TArH2: isw = 1 / S_w of the layer whose accumulators the epilogue reads)
+struct TEpi { f32x2 x, t, e, u, b, hd; unsigned bias_addr, patch_wr; float isw; };
 // saving an m-tile as a native tile (tile.h): patch_rd = the lane's read address in the patch, v = two float4 in flight, rsrc =
 // buffer descriptor of the native tile (wave-uniform; zero records when the tile does not exist -- ragged last tile -- so the
 // hardware drops the stores), loff = the lane's byte offset in it (its half of the tile and its lane slot)
@@ -113,8 +137,47 @@ __device__ __forceinline__ void t_bias_read_w(f32x2& dst, unsigned addr) {
 // Step 1 also issues the bias read of the next pair; after the last pair that of the next m-tile's first pair -- only if NEXT
 // says that m-tile's epilogue will run.  (m-tile 0's epilogue runs outside the MFMA stream: t_epi_exposed.)  SAVE (training
 // kernel): the pair's activations also go to the transposition patch.
+// TArH2's micro-steps, two per MFMA.  The pair lives in the scaled variable zs = 16 z:  16 softplus(z) = max(zs, 0) +
+// (16 ln2 / beta) log2(1 + exp2(-|zs| beta log2e / 16)); the accumulator carries 16 S_w (W x), the bias row 16 b.  Split: convert,
+// two residuals, convert.  SAVE: the activation itself (x 1/16, exact) goes to the patch in steps 10 / 11 -- behind the last read
+// of the previous m-tile's patch (group 1, MFMA slots 2-3 = pair 1's steps 4..7); pair 0's waits in hd until pair 1's steps 8 / 9.
 template <int M, int STEP, bool NEXT, bool SAVE>
-__device__ __forceinline__ void t_epi_step(const f32x16& x, TPieces (&out)[2], TEpi& st) {
+__device__ __forceinline__ void t_epi_step_h(const f32x16& x, TPieces<TArH2> (&out)[2], TEpi& st) {
+    constexpr int j = STEP / 12, s = STEP % 12, half = j / 4, q = j % 4, r0 = 2 * j;
+    constexpr int PW = (8 * (r0 / 4) + r0 % 4) * T_PATCH_LD * 4;
+    constexpr float C2 = SOFTPLUS_BETA * 1.44269504088896f / H2_XS, C7 = H2_XS * 0.69314718055995f / SOFTPLUS_BETA;
+    if constexpr (s == 0) { st.x[0] = fmaf(x[r0], st.isw, st.b[0]); }
+    else if constexpr (s == 1) {
+        st.x[1] = fmaf(x[r0 + 1], st.isw, st.b[1]);
+        if constexpr (j < 7) t_bias_read<M, j + 1>(st.b, st.bias_addr);
+        else if constexpr (NEXT) t_bias_read<M + 1, 0>(st.b, st.bias_addr);
+    }
+    else if constexpr (s == 2) { st.t[0] = -fabsf(st.x[0]) * C2; st.t[1] = -fabsf(st.x[1]) * C2; }
+    else if constexpr (s == 3) { st.e[0] = __builtin_amdgcn_exp2f(st.t[0]); st.e[1] = __builtin_amdgcn_exp2f(st.t[1]); }
+    else if constexpr (s == 4) { st.e[0] = 1.f + st.e[0]; st.e[1] = 1.f + st.e[1]; }
+    else if constexpr (s == 5) { st.e[0] = __builtin_amdgcn_logf(st.e[0]); st.e[1] = __builtin_amdgcn_logf(st.e[1]); }
+    else if constexpr (s == 6) { st.t[0] = fmaxf(st.x[0], 0.f); st.t[1] = fmaxf(st.x[1], 0.f); }
+    else if constexpr (s == 7) { st.x[0] = fmaf(st.e[0], C7, st.t[0]); st.x[1] = fmaf(st.e[1], C7, st.t[1]); }
+    else if constexpr (s == 8) {
+        const unsigned h = pack_f16x2(st.x); out[half].p[0][q] = h; st.u = resid_f16x2(st.x, h);
+        if constexpr (SAVE && j == 1) t_lds_write_b32<0>(st.patch_wr, st.hd[0]);                    // pair 0's, deferred
+    }
+    else if constexpr (s == 9) {
+        out[half].p[1][q] = pack_f16x2(st.u);
+        if constexpr (SAVE && j == 1) t_lds_write_b32<T_PATCH_LD * 4>(st.patch_wr, st.hd[1]);
+    }
+    else if constexpr (s == 10) {
+        if constexpr (SAVE) {
+            st.t[0] = st.x[0] * (1.f / H2_XS); st.t[1] = st.x[1] * (1.f / H2_XS);
+            if constexpr (j == 0) st.hd = st.t;
+            else t_lds_write_b32<PW>(st.patch_wr, st.t[0]);
+        }
+    }
+    else { if constexpr (SAVE && j > 0) t_lds_write_b32<PW + T_PATCH_LD * 4>(st.patch_wr, st.t[1]); }
+}
+template <class AR, int M, int STEP, bool NEXT, bool SAVE>
+__device__ __forceinline__ void t_epi_step(const f32x16& x, TPieces<AR> (&out)[2], TEpi& st) {
+    if constexpr (AR::H) { t_epi_step_h<M, STEP, NEXT, SAVE>(x, out, st); return; } else {
     constexpr int j = STEP / 12, s = STEP % 12, half = j / 4, q = j % 4, r0 = 2 * j;
     constexpr int PW = (8 * (r0 / 4) + r0 % 4) * T_PATCH_LD * 4;           // patch row of value r0 (this lane's 4 h rows are in patch_wr)
     if constexpr (s == 0) { st.x[0] = x[r0] + st.b[0]; }
@@ -148,6 +211,7 @@ __device__ __forceinline__ void t_epi_step(const f32x16& x, TPieces (&out)[2], T
     else if constexpr (s == 9) { st.x[0] -= st.u[0]; st.x[1] -= st.u[1]; }
     else if constexpr (s == 10) { const unsigned h = pack_bf16x2(st.x); out[half].p[1][q] = h; st.u = unpack_bf16x2(h); }
     else { st.x[0] -= st.u[0]; st.x[1] -= st.u[1]; out[half].p[2][q] = pack_bf16x2(st.x); }
+    }
 }
 
 struct TRing {
@@ -163,25 +227,30 @@ struct TRing {
 // One LDS-DMA of the stage being issued: fragment wave + 4 i (1 KiB: 64 lanes x 16 B)
 template <class C, int I>
 __device__ __forceinline__ void t_ring_issue_one(TRing& R) {
+    constexpr int SB = C::AR::STAGE_BYTES;
     const unsigned frag = R.wave + 4 * I;
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(R.rsrc, (__attribute__((address_space(3))) void*)(R.lds + R.is_slot * T_STAGE_BYTES + frag * 1024),
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(R.rsrc, (__attribute__((address_space(3))) void*)(R.lds + R.is_slot * SB + frag * 1024),
                                              16, R.lane * 16, R.is_goff + frag * 1024, 0, 0);
-    if constexpr (I == T_DMA - 1) {
+    if constexpr (I == C::AR::DMA - 1) {
         R.is_slot = (R.is_slot + 1 == C::NSTAGE) ? 0 : R.is_slot + 1;
-        R.is_goff = (R.is_goff + T_STAGE_BYTES == (unsigned)(C::STAGES * T_STAGE_BYTES)) ? 0 : R.is_goff + T_STAGE_BYTES;
+        R.is_goff = (R.is_goff + SB == (unsigned)(C::STAGES * SB)) ? 0 : R.is_goff + SB;
     }
+}
+template <class C, int I, int N>
+__device__ __forceinline__ void t_ring_issue_range(TRing& R) {
+    if constexpr (I < N) { t_ring_issue_one<C, I>(R); t_ring_issue_range<C, I + 1, N>(R); }
 }
 template <class C>
 __device__ __forceinline__ void t_ring_advance_read(TRing& R) {
     R.rd_slot = (R.rd_slot + 1 == C::NSTAGE) ? 0 : R.rd_slot + 1;
-    R.rd_addr = R.lds_base + R.rd_slot * T_STAGE_BYTES + R.lane * 16;
+    R.rd_addr = R.lds_base + R.rd_slot * C::AR::STAGE_BYTES + R.lane * 16;
 }
-template <int G>
-__device__ __forceinline__ void t_read_group(TFrag (&a)[2], unsigned addr) {
+template <class AR, int G>
+__device__ __forceinline__ void t_read_group(TFrag<AR> (&a)[2], unsigned addr) {
     DH_UNROLL for (int t = 0; t < 2; ++t) {
-        a[t].p[0] = t_lds_b128<((2 * G + 0) * 3 + 0) * 1024>(addr + t * 3072);
-        a[t].p[1] = t_lds_b128<((2 * G + 0) * 3 + 1) * 1024>(addr + t * 3072);
-        a[t].p[2] = t_lds_b128<((2 * G + 0) * 3 + 2) * 1024>(addr + t * 3072);
+        a[t].p[0] = t_lds_b128<(2 * G * AR::NP + 0) * 1024>(addr + t * AR::NP * 1024);
+        a[t].p[1] = t_lds_b128<(2 * G * AR::NP + 1) * 1024>(addr + t * AR::NP * 1024);
+        if constexpr (AR::NP == 3) a[t].p[2] = t_lds_b128<(2 * G * AR::NP + 2) * 1024>(addr + t * AR::NP * 1024);
     }
 }
 
@@ -193,13 +262,11 @@ __device__ __forceinline__ void t_save_store(const TSave& sv) {
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, sv.v[R4 & 1]), sv.rsrc, sv.loff + 4 * t_native_off(M, R4), 0, 2);     // nt, as DH_TILE_ST
 }
 
-// MFMA I (0..11) of group G (m-tiles 2G, 2G+1) into set NB: product-major, consecutive MFMAs hit different accumulators
-template <int NB, int G, int I>
-__device__ __forceinline__ void t_mfma_step(TAcc& A, const TFrag (&a)[2], const TPieces& b) {
-    constexpr int pw[6] = {2, 1, 0, 1, 0, 0}, px[6] = {0, 1, 2, 0, 1, 0};      // smallest terms first (tile16.h mfma6)
+// MFMA I (0 .. 2 NPROD - 1) of group G (m-tiles 2G, 2G+1) into set NB: product-major, consecutive MFMAs hit different accumulators
+template <class AR, int NB, int G, int I>
+__device__ __forceinline__ void t_mfma_step(TAcc& A, const TFrag<AR> (&a)[2], const TPieces<AR>& b) {
     constexpr int p = I / 2, t = I % 2, mt = 2 * G + t;
-    A.s[NB][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[t].p[pw[p]]), __builtin_bit_cast(bf16x8, b.p[px[p]]),
-                                                          A.s[NB][mt], 0, 0, 0);
+    A.s[NB][mt] = AR::mfma(a[t].p[AR::pw[p]], b.p[AR::px[p]], A.s[NB][mt]);
 }
 // What is dealt under one k-step's MFMAs (compile-time): the accumulator set NB it writes; the epilogue m-tile EM of the OTHER
 // set (-1: none) and which half EH of its 96 micro-steps; ENEXT: m-tile EM + 1 follows; SM (training kernel): the m-tile whose
@@ -211,13 +278,17 @@ struct TK {
     static constexpr int NB = NB_, EM = EM_, EH = EH_, SM = SM_;
     static constexpr bool ENEXT = ENEXT_;
 };
-// the 12 MFMAs of group G, each followed by its share of the dealt work; DA / DB: the LDS-DMA piece issued after MFMA 3 / 9 (-1: none)
+// the 2 NPROD MFMAs of group G, each followed by its share of the dealt work (12 / (2 NPROD) epilogue micro-steps); DA / DB: the
+// LDS-DMA piece issued after MFMA 3 / 9 (TArB3) or DA after MFMA 2 (TArH2)   (-1: none)
 template <class K, int G, int DA, int DB, int I>
-__device__ __forceinline__ void t_group_steps(TAcc& A, const TFrag (&a)[2], const TPieces& b, TPieces (&bn)[2], TEpi& st, TRing& R, TSave& sv) {
-    if constexpr (I < 12) {
-        t_mfma_step<K::NB, G, I>(A, a, b);
+__device__ __forceinline__ void t_group_steps(TAcc& A, const TFrag<typename K::C::AR> (&a)[2], const TPieces<typename K::C::AR>& b,
+                                              TPieces<typename K::C::AR> (&bn)[2], TEpi& st, TRing& R, TSave& sv) {
+    using AR = typename K::C::AR;
+    constexpr int NMF = 2 * AR::NPROD, EPS = 12 / NMF, DAI = AR::H ? 2 : 3;
+    if constexpr (I < NMF) {
+        t_mfma_step<AR, K::NB, G, I>(A, a, b);
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (I == 3 && DA >= 0) { t_ring_issue_one<typename K::C, DA>(R); __builtin_amdgcn_sched_barrier(0); }
+        if constexpr (I == DAI && DA >= 0) { t_ring_issue_one<typename K::C, DA>(R); __builtin_amdgcn_sched_barrier(0); }
         if constexpr (I == 9 && DB >= 0) { t_ring_issue_one<typename K::C, DB>(R); __builtin_amdgcn_sched_barrier(0); }
         if constexpr (K::C::TRAIN && K::SM >= 0 && I < 4) {
             if constexpr (G == 0 && I < 2) { t_lds_read<32 * I>(sv.v[I], sv.patch_rd); __builtin_amdgcn_sched_barrier(0); }
@@ -226,41 +297,46 @@ __device__ __forceinline__ void t_group_steps(TAcc& A, const TFrag (&a)[2], cons
             if constexpr (G == 2 && I < 2) { t_save_store<K::SM, I + 2>(sv); __builtin_amdgcn_sched_barrier(0); }
         }
         if constexpr (K::EM >= 0 && K::EM < T_NM) {
-            t_epi_step<K::EM, K::EH * 48 + 12 * G + I, K::ENEXT, K::C::TRAIN>(A.s[1 - K::NB][K::EM], bn, st);
+            t_epi_step<AR, K::EM, K::EH * 48 + 12 * G + EPS * I, K::ENEXT, K::C::TRAIN>(A.s[1 - K::NB][K::EM], bn, st);
+            if constexpr (EPS == 2) t_epi_step<AR, K::EM, K::EH * 48 + 12 * G + EPS * I + 1, K::ENEXT, K::C::TRAIN>(A.s[1 - K::NB][K::EM], bn, st);
             __builtin_amdgcn_sched_barrier(0);
         }
         t_group_steps<K, G, DA, DB, I + 1>(A, a, b, bn, st, R, sv);
     }
 }
 
-// one k-step: entering, a0 holds group 0's fragments; leaving, a0 holds group 0 of the NEXT stage of the stream
+// one k-step: entering, a0 holds group 0's fragments; leaving, a0 holds group 0 of the NEXT stage of the stream.
+// LDS-DMA pieces of the stage being issued: TArB3 6 per wave and k-step (3, 4 | 5 | barrier | 0, 1 | 2), TArH2 4 (2 | 3 | barrier | 0 | 1)
 template <class K>
-__device__ __forceinline__ void t_kstep(TAcc& A, const TPieces& b, TPieces (&bn)[2], TEpi& st, TFrag (&a0)[2], TFrag (&a1)[2], TRing& R, TSave& sv) {
+__device__ __forceinline__ void t_kstep(TAcc& A, const TPieces<typename K::C::AR>& b, TPieces<typename K::C::AR> (&bn)[2], TEpi& st,
+                                        TFrag<typename K::C::AR> (&a0)[2], TFrag<typename K::C::AR> (&a1)[2], TRing& R, TSave& sv) {
     using C = typename K::C;
-    t_read_group<1>(a1, R.rd_addr);
+    using AR = typename C::AR;
+    constexpr bool B3 = !AR::H;
+    t_read_group<AR, 1>(a1, R.rd_addr);
     __builtin_amdgcn_sched_barrier(0);
-    t_group_steps<K, 0, 3, 4, 0>(A, a0, b, bn, st, R, sv);        // pieces 3, 4 of the stage begun last k-step
+    t_group_steps<K, 0, B3 ? 3 : 2, B3 ? 4 : -1, 0>(A, a0, b, bn, st, R, sv);        // the second half of the stage begun last k-step
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
-    t_read_group<2>(a0, R.rd_addr);
+    t_read_group<AR, 2>(a0, R.rd_addr);
     __builtin_amdgcn_sched_barrier(0);
-    t_group_steps<K, 1, 5, -1, 0>(A, a1, b, bn, st, R, sv);       // piece 5: the stage is fully issued
+    t_group_steps<K, 1, B3 ? 5 : 3, -1, 0>(A, a1, b, bn, st, R, sv);                 // the stage is fully issued
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
     // the NEXT k-step's pieces: this wave's DMAs for it have landed once at most DEPTH-1 younger groups are outstanding (tile
     // stores in flight count too and only make the wait stricter); after the barrier everyone's have, and everyone has left the
     // previous k-step (its slot may be refilled)
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(T_DMA * (C::DEPTH - 1)) : "memory");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AR::DMA * (C::DEPTH - 1)) : "memory");
     asm volatile("s_barrier" ::: "memory");
-    t_read_group<3>(a1, R.rd_addr);
+    t_read_group<AR, 3>(a1, R.rd_addr);
     __builtin_amdgcn_sched_barrier(0);
-    t_group_steps<K, 2, 0, 1, 0>(A, a0, b, bn, st, R, sv);        // a new stage: its slot was freed by the barrier
+    t_group_steps<K, 2, 0, B3 ? 1 : -1, 0>(A, a0, b, bn, st, R, sv);                 // a new stage: its slot was freed by the barrier
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
     t_ring_advance_read<C>(R);
-    t_read_group<0>(a0, R.rd_addr);
+    t_read_group<AR, 0>(a0, R.rd_addr);
     __builtin_amdgcn_sched_barrier(0);
-    t_group_steps<K, 3, 2, -1, 0>(A, a1, b, bn, st, R, sv);
+    t_group_steps<K, 3, B3 ? 2 : 1, -1, 0>(A, a1, b, bn, st, R, sv);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
 }
@@ -271,33 +347,52 @@ template <int NB>
 __device__ __forceinline__ void t_zero(TAcc& A) {
     DH_UNROLL for (int m = 0; m < T_NM; ++m) DH_UNROLL for (int r = 0; r < 16; ++r) A.s[NB][m][r] = 0.f;
 }
+// 16 softplus(z) from zs = 16 z (TArH2's scaled variable; bit-identical to 16 * softplus100(z))
+__device__ __forceinline__ float softplus100_xs(float zs) {
+    const float e = __builtin_amdgcn_exp2f(-fabsf(zs) * (SOFTPLUS_BETA * 1.44269504088896f / H2_XS));
+    const float l = __builtin_amdgcn_logf(1.f + e);
+    return fmaf(l, H2_XS * 0.69314718055995f / SOFTPLUS_BETA, fmaxf(zs, 0.f));
+}
 // the one exposed epilogue of a layer: m-tile 0 of the source set, outside the MFMA stream -- the same arithmetic as t_epi_step, its
 // sixteen biases fetched with ONE LDS latency; leaves m-tile 1's first pair in st.b
-template <bool SAVE>
-__device__ __forceinline__ void t_epi_exposed(const f32x16& x, TPieces (&out)[2], TEpi& st) {
+template <class AR, bool SAVE>
+__device__ __forceinline__ void t_epi_exposed(const f32x16& x, TPieces<AR> (&out)[2], TEpi& st) {
     f32x4 bb[4];
     t_lds_read4_w<0, 32, 64, 96>(bb[0], bb[1], bb[2], bb[3], st.bias_addr);
     DH_UNROLL for (int j = 0; j < 8; ++j) {
         const int g = j / 2, i0 = 2 * (j % 2), r0 = 2 * j, half = j / 4, q = j % 4;
-        f32x2 v;
-        v[0] = softplus100(x[r0] + bb[g][i0]);
-        v[1] = softplus100(x[r0 + 1] + bb[g][i0 + 1]);
+        f32x2 v, sv2;
+        if constexpr (AR::H) {
+            v[0] = softplus100_xs(fmaf(x[r0], st.isw, bb[g][i0]));
+            v[1] = softplus100_xs(fmaf(x[r0 + 1], st.isw, bb[g][i0 + 1]));
+            sv2 = v * (1.f / H2_XS);
+        } else {
+            v[0] = softplus100(x[r0] + bb[g][i0]);
+            v[1] = softplus100(x[r0 + 1] + bb[g][i0 + 1]);
+            sv2 = v;
+        }
         if constexpr (SAVE) {
             const unsigned a = st.patch_wr + (8 * (r0 / 4) + r0 % 4) * T_PATCH_LD * 4;
-            asm volatile("ds_write_b32 %0, %1\n\tds_write_b32 %0, %2 offset:%3" ::"v"(a), "v"(v[0]), "v"(v[1]), "n"(T_PATCH_LD * 4) : "memory");
+            asm volatile("ds_write_b32 %0, %1\n\tds_write_b32 %0, %2 offset:%3" ::"v"(a), "v"(sv2[0]), "v"(sv2[1]), "n"(T_PATCH_LD * 4) : "memory");
         }
-        const unsigned h = pack_bf16x2(v);
-        const f32x2 r1 = v - unpack_bf16x2(h);
-        const unsigned m = pack_bf16x2(r1);
-        const f32x2 r2 = r1 - unpack_bf16x2(m);
-        out[half].p[0][q] = h; out[half].p[1][q] = m; out[half].p[2][q] = pack_bf16x2(r2);
+        if constexpr (AR::H) {
+            const unsigned h = pack_f16x2(v);
+            out[half].p[0][q] = h; out[half].p[1][q] = pack_f16x2(resid_f16x2(v, h));
+        } else {
+            const unsigned h = pack_bf16x2(v);
+            const f32x2 r1 = v - unpack_bf16x2(h);
+            const unsigned m = pack_bf16x2(r1);
+            const f32x2 r2 = r1 - unpack_bf16x2(m);
+            out[half].p[0][q] = h; out[half].p[1][q] = m; out[half].p[2][q] = pack_bf16x2(r2);
+        }
     }
     t_bias_read_w<1, 0>(st.b, st.bias_addr);
 }
 // k-steps 2M, 2M+1 (input pieces = the epilogue of m-tile M of the source set) with the epilogue of m-tile M+1 dealt under them
 // and (training kernel) m-tile M saved; MEND: m-tiles of the source the layer consumes (8; the skip layer takes 7 of lin3's)
 template <class C, int NB, int M, int MEND>
-__device__ __forceinline__ void t_mpair(TAcc& A, TPieces (&bA)[2], TPieces (&bB)[2], TEpi& st, TFrag (&a0)[2], TFrag (&a1)[2], TRing& R, TSave& sv) {
+__device__ __forceinline__ void t_mpair(TAcc& A, TPieces<typename C::AR> (&bA)[2], TPieces<typename C::AR> (&bB)[2], TEpi& st,
+                                        TFrag<typename C::AR> (&a0)[2], TFrag<typename C::AR> (&a1)[2], TRing& R, TSave& sv) {
     if constexpr (M < MEND) {
         constexpr int EM = M + 1 < MEND ? M + 1 : -1;
         constexpr bool EN = M + 2 < MEND;                 // m-tile EM + 1 will have its epilogue dealt too
@@ -316,11 +411,13 @@ __device__ __forceinline__ void t_mpair(TAcc& A, TPieces (&bA)[2], TPieces (&bB)
 // the main part of a layer: accumulates MEND * 32 input features into set NB from the finished set 1 - NB, whose bias row is
 // at bias_row (LDS byte address, + 16 h); training kernel: the source layer's activations go to the native tile sv.base points at
 template <class C, int NB, int MEND>
-__device__ __forceinline__ void t_layer(TAcc& A, TPieces (&bA)[2], TPieces (&bB)[2], TEpi& st, TFrag (&a0)[2], TFrag (&a1)[2], TRing& R, TSave& sv,
-                                        unsigned bias_row) {
+__device__ __forceinline__ void t_layer(TAcc& A, TPieces<typename C::AR> (&bA)[2], TPieces<typename C::AR> (&bB)[2], TEpi& st,
+                                        TFrag<typename C::AR> (&a0)[2], TFrag<typename C::AR> (&a1)[2], TRing& R, TSave& sv,
+                                        unsigned bias_row, float isw) {
     t_zero<NB>(A);
     st.bias_addr = bias_row;
-    t_epi_exposed<C::TRAIN>(A.s[1 - NB][0], bA, st);
+    st.isw = isw;
+    t_epi_exposed<typename C::AR, C::TRAIN>(A.s[1 - NB][0], bA, st);
     __builtin_amdgcn_sched_barrier(0);
     t_mpair<C, NB, 0, MEND>(A, bA, bB, st, a0, a1, R, sv);
 }
@@ -345,18 +442,25 @@ __device__ __forceinline__ void t_embed_rows(const float (&x)[3], unsigned row, 
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 }
-// 8 fp32 of one k-step (this lane's slots i = 0..7) -> pieces
-__device__ __forceinline__ TPieces t_split8(const f32x4& lo, const f32x4& hi) {
-    const Bf3 b = split3(lo, hi);
-    TPieces r;
-    DH_UNROLL for (int p = 0; p < 3; ++p) r.p[p] = __builtin_bit_cast(u32x4, b.p[p]);
+// 8 fp32 of one k-step (this lane's slots i = 0..7) -> pieces (TArH2: of 16 x the values)
+template <class AR>
+__device__ __forceinline__ TPieces<AR> t_split8(const f32x4& lo, const f32x4& hi) {
+    TPieces<AR> r;
+    if constexpr (AR::H) {
+        const H2 b = split2(lo * H2_XS, hi * H2_XS);
+        r.p[0] = b.p[0]; r.p[1] = b.p[1];
+    } else {
+        const Bf3 b = split3(lo, hi);
+        DH_UNROLL for (int p = 0; p < 3; ++p) r.p[p] = __builtin_bit_cast(u32x4, b.p[p]);
+    }
     return r;
 }
 // the three k-steps of the embedding as B pieces: lane (p, h) holds features 16 s + 8 g + 4 h + (0..3), g = 0, 1 of k-step s
-__device__ __forceinline__ void t_embed_pieces(unsigned row_h, TPieces& e0, TPieces& e1, TPieces& e2) {
-    e0 = t_split8(t_lds_read_w<0>(row_h), t_lds_read_w<32>(row_h));
-    e1 = t_split8(t_lds_read_w<64>(row_h), t_lds_read_w<96>(row_h));
-    e2 = t_split8(t_lds_read_w<128>(row_h), t_lds_read_w<160>(row_h));
+template <class AR>
+__device__ __forceinline__ void t_embed_pieces(unsigned row_h, TPieces<AR>& e0, TPieces<AR>& e1, TPieces<AR>& e2) {
+    e0 = t_split8<AR>(t_lds_read_w<0>(row_h), t_lds_read_w<32>(row_h));
+    e1 = t_split8<AR>(t_lds_read_w<64>(row_h), t_lds_read_w<96>(row_h));
+    e2 = t_split8<AR>(t_lds_read_w<128>(row_h), t_lds_read_w<160>(row_h));
 }
 // training kernel: the wave's half of the aux native tile ([64 x 64], tile.h aux_store_native) from the embedding image: lane L's
 // float4 (t, r4) = column 32 t + (L & 31) of points 8 r4 + 4 (L >> 5) + (0..3).  col_addr = image + (4 (L>>5) rows, column L&31)
@@ -373,30 +477,39 @@ __device__ __forceinline__ void t_store_eaux(unsigned col_addr, int fl, __amdgpu
 }
 
 // lin8 row 0 on softplus(lin7 + bias): this lane's 128 features of its point (accumulator set 1)
-template <int M>
-__device__ __forceinline__ void t_final_dot(const TAcc& A, unsigned bias_base, float& s0, float& s1) {
+// TArH2: isw = 1 / S_w of lin7; the sums come out 16 x (the caller divides)
+template <class AR, int M>
+__device__ __forceinline__ void t_final_dot(const TAcc& A, unsigned bias_base, float isw, float& s0, float& s1) {
     if constexpr (M < T_NM) {
         f32x4 bb[4], ww[4];
         t_lds_read4_w<7 * 1024 + 4 * (32 * M), 7 * 1024 + 4 * (32 * M + 8), 7 * 1024 + 4 * (32 * M + 16), 7 * 1024 + 4 * (32 * M + 24)>(bb[0], bb[1], bb[2], bb[3], bias_base);
         t_lds_read4_w<8 * 1024 + 4 * (32 * M), 8 * 1024 + 4 * (32 * M + 8), 8 * 1024 + 4 * (32 * M + 16), 8 * 1024 + 4 * (32 * M + 24)>(ww[0], ww[1], ww[2], ww[3], bias_base);
         DH_UNROLL for (int r4 = 0; r4 < 4; ++r4) {
-            s0 = fmaf(softplus100(A.s[1][M][4 * r4 + 0] + bb[r4][0]), ww[r4][0], s0);
-            s1 = fmaf(softplus100(A.s[1][M][4 * r4 + 1] + bb[r4][1]), ww[r4][1], s1);
-            s0 = fmaf(softplus100(A.s[1][M][4 * r4 + 2] + bb[r4][2]), ww[r4][2], s0);
-            s1 = fmaf(softplus100(A.s[1][M][4 * r4 + 3] + bb[r4][3]), ww[r4][3], s1);
+            if constexpr (AR::H) {
+                s0 = fmaf(softplus100_xs(fmaf(A.s[1][M][4 * r4 + 0], isw, bb[r4][0])), ww[r4][0], s0);
+                s1 = fmaf(softplus100_xs(fmaf(A.s[1][M][4 * r4 + 1], isw, bb[r4][1])), ww[r4][1], s1);
+                s0 = fmaf(softplus100_xs(fmaf(A.s[1][M][4 * r4 + 2], isw, bb[r4][2])), ww[r4][2], s0);
+                s1 = fmaf(softplus100_xs(fmaf(A.s[1][M][4 * r4 + 3], isw, bb[r4][3])), ww[r4][3], s1);
+            } else {
+                s0 = fmaf(softplus100(A.s[1][M][4 * r4 + 0] + bb[r4][0]), ww[r4][0], s0);
+                s1 = fmaf(softplus100(A.s[1][M][4 * r4 + 1] + bb[r4][1]), ww[r4][1], s1);
+                s0 = fmaf(softplus100(A.s[1][M][4 * r4 + 2] + bb[r4][2]), ww[r4][2], s0);
+                s1 = fmaf(softplus100(A.s[1][M][4 * r4 + 3] + bb[r4][3]), ww[r4][3], s1);
+            }
         }
-        t_final_dot<M + 1>(A, bias_base, s0, s1);
+        t_final_dot<AR, M + 1>(A, bias_base, isw, s0, s1);
     }
 }
 // training kernel: lin8 rows 1..256 (accumulator set 0) + their bias (row 9) -> the feature tile, m-tile by m-tile through the patch
+// (fs: 1 for TArB3; 1 / (16 S_w) of lin8 for TArH2)
 template <int M>
-__device__ __forceinline__ void t_store_feat(const TAcc& A, unsigned bias_base, const TEpi& st, TSave& sv) {
+__device__ __forceinline__ void t_store_feat(const TAcc& A, unsigned bias_base, const TEpi& st, TSave& sv, float fs) {
     if constexpr (M < T_NM) {
         f32x4 bb[4];
         t_lds_read4_w<9 * 1024 + 4 * (32 * M), 9 * 1024 + 4 * (32 * M + 8), 9 * 1024 + 4 * (32 * M + 16), 9 * 1024 + 4 * (32 * M + 24)>(bb[0], bb[1], bb[2], bb[3], bias_base);
         DH_UNROLL for (int g = 0; g < 4; ++g)
             DH_UNROLL for (int i = 0; i < 4; ++i) {
-                const float v = A.s[0][M][4 * g + i] + bb[g][i];
+                const float v = fmaf(A.s[0][M][4 * g + i], fs, bb[g][i]);
                 const unsigned a = st.patch_wr + (8 * g + i) * T_PATCH_LD * 4;
                 asm volatile("ds_write_b32 %0, %1" ::"v"(a), "v"(v) : "memory");
             }
@@ -406,7 +519,7 @@ __device__ __forceinline__ void t_store_feat(const TAcc& A, unsigned bias_base, 
         t_save_store<M, 0>(sv); t_save_store<M, 1>(sv);
         sv.v[0] = o[2]; sv.v[1] = o[3];
         t_save_store<M, 2>(sv); t_save_store<M, 3>(sv);
-        t_store_feat<M + 1>(A, bias_base, st, sv);
+        t_store_feat<M + 1>(A, bias_base, st, sv, fs);
     }
 }
 
@@ -449,33 +562,37 @@ __device__ __forceinline__ void sdf_chain_t_body(const void* __restrict__ stream
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = lane >> 5, p = lane & 31;
-    float* lbias = reinterpret_cast<float*>(lds + C::NSTAGE * T_STAGE_BYTES);
-    for (int i = tid; i < T_BIAS_BYTES / 4; i += 256) lbias[i] = bias10[i];
+    using AR = typename C::AR;
+    constexpr int SB = AR::STAGE_BYTES, BB = AR::BIAS_BYTES;
+    float* lbias = reinterpret_cast<float*>(lds + C::NSTAGE * SB);
+    for (int i = tid; i < BB / 4; i += 256) lbias[i] = bias10[i];
+    // TArH2: 1 / S_w of lin0..lin8 (row 10 of the table; scalar loads, before any LDS-DMA is in flight)
+    float isw[N_SDF];
+    DH_UNROLL for (int l = 0; l < N_SDF; ++l) isw[l] = AR::H ? bias10[10 * 256 + l] : 1.f;
     TRing R;
     R.lds = lds; R.lds_base = (unsigned)(uintptr_t)lds; R.wave = wave; R.lane = lane;
-    R.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(stream), 0, C::STAGES * T_STAGE_BYTES, 0x00020000);
+    R.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(stream), 0, C::STAGES * SB, 0x00020000);
     R.is_goff = 0; R.is_slot = 0; R.rd_slot = 0; R.rd_addr = R.lds_base + lane * 16;
-    const unsigned bias_base = R.lds_base + C::NSTAGE * T_STAGE_BYTES + 16 * h;
-    const unsigned emb_wave = R.lds_base + C::NSTAGE * T_STAGE_BYTES + T_BIAS_BYTES + wave * T_EMB_BYTES;
+    const unsigned bias_base = R.lds_base + C::NSTAGE * SB + 16 * h;
+    const unsigned emb_wave = R.lds_base + C::NSTAGE * SB + BB + wave * T_EMB_BYTES;
     const unsigned emb_row = emb_wave + p * (T_EMB_LD * 4);
     TAcc A;
-    TPieces bA[2], bB[2];
+    TPieces<AR> bA[2], bB[2];
     TEpi st;
+    st.isw = 1.f;
     TSave sv;
-    TFrag a0[2], a1[2];
+    TFrag<AR> a0[2], a1[2];
     if constexpr (C::TRAIN) {
-        const unsigned patch = R.lds_base + C::NSTAGE * T_STAGE_BYTES + T_BIAS_BYTES + 4 * T_EMB_BYTES + wave * T_PATCH_BYTES;
+        const unsigned patch = R.lds_base + C::NSTAGE * SB + BB + 4 * T_EMB_BYTES + wave * T_PATCH_BYTES;
         st.patch_wr = patch + (4 * h * T_PATCH_LD + p) * 4;
         sv.patch_rd = patch + (p * T_PATCH_LD + 4 * h) * 4;
     }
-    // ring prologue: DEPTH full stages + the first 3 pieces of the next (the steady state enters a k-step with 3 of 6 issued)
-    for (int d = 0; d < C::DEPTH; ++d) {
-        t_ring_issue_one<C, 0>(R); t_ring_issue_one<C, 1>(R); t_ring_issue_one<C, 2>(R); t_ring_issue_one<C, 3>(R); t_ring_issue_one<C, 4>(R); t_ring_issue_one<C, 5>(R);
-    }
-    t_ring_issue_one<C, 0>(R); t_ring_issue_one<C, 1>(R); t_ring_issue_one<C, 2>(R);
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(T_DMA * (C::DEPTH - 1) + 3) : "memory");
+    // ring prologue: DEPTH full stages + the first half of the next (the steady state enters a k-step with half a stage issued)
+    for (int d = 0; d < C::DEPTH; ++d) t_ring_issue_range<C, 0, AR::DMA>(R);
+    t_ring_issue_range<C, 0, AR::DMA / 2>(R);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AR::DMA * (C::DEPTH - 1) + AR::DMA / 2) : "memory");
     __syncthreads();                                  // stage 0 has landed for every wave; the bias table is written
-    t_read_group<0>(a0, R.rd_addr);
+    t_read_group<AR, 0>(a0, R.rd_addr);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
 
@@ -498,7 +615,7 @@ __device__ __forceinline__ void sdf_chain_t_body(const void* __restrict__ stream
         {   // embedding
             const float x[3] = {xn[0], xn[1], xn[2]};
             t_embed_rows(x, emb_row, h);
-            t_embed_pieces(emb_row + 16 * h, bA[0], bA[1], bB[0]);
+            t_embed_pieces<AR>(emb_row + 16 * h, bA[0], bA[1], bB[0]);
             if constexpr (C::TRAIN)
                 t_store_eaux<0>(emb_wave + (4 * h * T_EMB_LD + p) * 4, p, t_tile_rsrc(eaux + tile64 * AUXT_F, tile_ok, AUXT_F * 4), sv.loff);
         }
@@ -512,25 +629,25 @@ __device__ __forceinline__ void sdf_chain_t_body(const void* __restrict__ stream
         _Pragma("unroll 1") for (int q = 0; q < 2; ++q) {
             // (the training kernel saves the SOURCE layer of each call: act[4q], act[4q+1], act[4q+2], act[3])
             if constexpr (C::TRAIN) sv.rsrc = t_tile_rsrc(act_tile + (4 * q + 0) * lstride, tile_ok, TILE_F * 4);
-            t_layer<C, 1, 8>(A, bA, bB, st, a0, a1, R, sv, bias_base + (4 * q + 0) * 1024);        // lin1 / lin5
+            t_layer<C, 1, 8>(A, bA, bB, st, a0, a1, R, sv, bias_base + (4 * q + 0) * 1024, q ? isw[4] : isw[0]);        // lin1 / lin5
             T_DUMP(1, 4 * q + 1);
             if constexpr (C::TRAIN) sv.rsrc = t_tile_rsrc(act_tile + (4 * q + 1) * lstride, tile_ok, TILE_F * 4);
-            t_layer<C, 0, 8>(A, bA, bB, st, a0, a1, R, sv, bias_base + (4 * q + 1) * 1024);        // lin2 / lin6
+            t_layer<C, 0, 8>(A, bA, bB, st, a0, a1, R, sv, bias_base + (4 * q + 1) * 1024, q ? isw[5] : isw[1]);        // lin2 / lin6
             T_DUMP(0, 4 * q + 2);
             if constexpr (C::TRAIN) sv.rsrc = t_tile_rsrc(act_tile + (4 * q + 2) * lstride, tile_ok, TILE_F * 4);
-            t_layer<C, 1, 8>(A, bA, bB, st, a0, a1, R, sv, bias_base + (4 * q + 2) * 1024);        // lin3 / lin7
+            t_layer<C, 1, 8>(A, bA, bB, st, a0, a1, R, sv, bias_base + (4 * q + 2) * 1024, q ? isw[6] : isw[2]);        // lin3 / lin7
             T_DUMP(1, 4 * q + 3);
             if (q == 0) {
                 // lin4: 14 k-steps of lin3's output (217 valid features: the packer zeroes the rest), then the embedding again
                 if constexpr (C::TRAIN) sv.rsrc = t_tile_rsrc(act_tile + 3 * lstride, tile_ok, TILE_F * 4);
-                t_layer<C, 0, 7>(A, bA, bB, st, a0, a1, R, sv, bias_base + 3 * 1024);
+                t_layer<C, 0, 7>(A, bA, bB, st, a0, a1, R, sv, bias_base + 3 * 1024, isw[3]);
                 if constexpr (C::TRAIN) {
                     // columns 224..255 of lin3's tile: its rows 217.. have zero weights and bias, the activation is softplus(0)
                     const float c0 = 0.69314718055995f / SOFTPLUS_BETA;
                     sv.v[0] = sv.v[1] = f32x4{c0, c0, c0, c0};
                     t_save_store<7, 0>(sv); t_save_store<7, 1>(sv); t_save_store<7, 2>(sv); t_save_store<7, 3>(sv);
                 }
-                t_embed_pieces(emb_row + 16 * h, bA[0], bA[1], bB[0]);
+                t_embed_pieces<AR>(emb_row + 16 * h, bA[0], bA[1], bB[0]);
                 __builtin_amdgcn_sched_barrier(0);
                 t_kstep<TBare<C, 0>>(A, bA[0], bB, st, a0, a1, R, sv);
                 t_kstep<TBare<C, 0>>(A, bA[1], bB, st, a0, a1, R, sv);
@@ -544,66 +661,78 @@ __device__ __forceinline__ void sdf_chain_t_body(const void* __restrict__ stream
         {
             const int64_t gp = t_next_points(pts, npts, tile, wave * 32 + p, xn);
             float s0 = 0.f, s1 = 0.f;
-            t_final_dot<0>(A, bias_base, s0, s1);
-            float s = s0 + s1;
+            t_final_dot<AR, 0>(A, bias_base, isw[7], s0, s1);
+            float s = (s0 + s1) * (AR::H ? 1.f / H2_XS : 1.f);
             s += __shfl_xor(s, 32);
             if (h == 0 && gp < npts) sdf_out[gp] = s + b8_0[0];
         }
         if constexpr (C::TRAIN) {
             // lin8 rows 1..256 from softplus(lin7 + bias) into set 0 (its epilogue saves act[7]), then the feature tile
             sv.rsrc = t_tile_rsrc(act_tile + 7 * lstride, tile_ok, TILE_F * 4);
-            t_layer<C, 0, 8>(A, bA, bB, st, a0, a1, R, sv, bias_base + 7 * 1024);
+            t_layer<C, 0, 8>(A, bA, bB, st, a0, a1, R, sv, bias_base + 7 * 1024, isw[7]);
             sv.rsrc = t_tile_rsrc(feat + tile64 * TILE_F, tile_ok, TILE_F * 4);
-            t_store_feat<0>(A, bias_base, st, sv);
+            t_store_feat<0>(A, bias_base, st, sv, AR::H ? isw[8] * (1.f / H2_XS) : 1.f);
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the ring runs ahead of the last tile: let its DMAs land before the LDS goes away
 }
 
 // (the weight stream is passed as const void*: a bf16 vector type in a kernel's signature leaves rocprofv3 unable to demangle its name)
+#ifdef DH_T_DEBUG
+#define T_DBG_FWD , dbg, dbg_layer
+#else
+#define T_DBG_FWD
+#endif
 __global__ __launch_bounds__(256, 1) void sdf_nograd_t_kernel(const void* __restrict__ stream, const float* __restrict__ bias10,
                                                               const float* __restrict__ b8_0, const float* __restrict__ pts, int64_t npts,
                                                               float* __restrict__ sdf_out T_DBG_PARAMS) {
-#ifdef DH_T_DEBUG
-    sdf_chain_t_body<TCfgNoGrad>(stream, bias10, b8_0, pts, npts, sdf_out, nullptr, nullptr, nullptr, dbg, dbg_layer);
-#else
-    sdf_chain_t_body<TCfgNoGrad>(stream, bias10, b8_0, pts, npts, sdf_out, nullptr, nullptr, nullptr);
-#endif
+    sdf_chain_t_body<TCfgNoGrad<TArB3>>(stream, bias10, b8_0, pts, npts, sdf_out, nullptr, nullptr, nullptr T_DBG_FWD);
 }
 __global__ __launch_bounds__(256, 1) void sdf_fwd_train_t_kernel(const void* __restrict__ stream, const float* __restrict__ bias10,
                                                                  const float* __restrict__ b8_0, const float* __restrict__ pts, int64_t npts,
                                                                  float* __restrict__ sdf_out, float* __restrict__ feat, float* __restrict__ act,
                                                                  float* __restrict__ eaux T_DBG_PARAMS) {
-#ifdef DH_T_DEBUG
-    sdf_chain_t_body<TCfgTrain>(stream, bias10, b8_0, pts, npts, sdf_out, feat, act, eaux, dbg, dbg_layer);
-#else
-    sdf_chain_t_body<TCfgTrain>(stream, bias10, b8_0, pts, npts, sdf_out, feat, act, eaux);
-#endif
+    sdf_chain_t_body<TCfgTrain<TArB3>>(stream, bias10, b8_0, pts, npts, sdf_out, feat, act, eaux T_DBG_FWD);
+}
+// the two-piece fp16 arithmetic (DH_ARITH_SPLIT_F16): bias11 = layout.h PACKH.bias11
+__global__ __launch_bounds__(256, 1) void sdf_nograd_h_kernel(const void* __restrict__ stream, const float* __restrict__ bias11,
+                                                              const float* __restrict__ b8_0, const float* __restrict__ pts, int64_t npts,
+                                                              float* __restrict__ sdf_out T_DBG_PARAMS) {
+    sdf_chain_t_body<TCfgNoGrad<TArH2>>(stream, bias11, b8_0, pts, npts, sdf_out, nullptr, nullptr, nullptr T_DBG_FWD);
+}
+__global__ __launch_bounds__(256, 1) void sdf_fwd_train_h_kernel(const void* __restrict__ stream, const float* __restrict__ bias11,
+                                                                 const float* __restrict__ b8_0, const float* __restrict__ pts, int64_t npts,
+                                                                 float* __restrict__ sdf_out, float* __restrict__ feat, float* __restrict__ act,
+                                                                 float* __restrict__ eaux T_DBG_PARAMS) {
+    sdf_chain_t_body<TCfgTrain<TArH2>>(stream, bias11, b8_0, pts, npts, sdf_out, feat, act, eaux T_DBG_FWD);
 }
 
 #ifdef DH_T_DEBUG
 static float* g_dbg = nullptr;
 static int g_dbg_layer = -1;
 extern "C" void dh_dev_nograd_t_debug(float* dbg, int layer) { g_dbg = dbg; g_dbg_layer = layer; }
-#endif
-#ifdef DH_T_DEBUG
 #define T_DBG_ARGS , g_dbg, g_dbg_layer
 #else
 #define T_DBG_ARGS
 #endif
-int launch_sdf_nograd_t(const float* packed, const float* pts, int64_t npts, float* sdf, hipStream_t stream) {
+// h2: the two-piece fp16 arithmetic
+int launch_sdf_nograd_t(const float* packed, const float* pts, int64_t npts, float* sdf, bool h2, hipStream_t stream) {
     const int64_t ntiles = (npts + T_PTS - 1) / T_PTS;
     const int g = (int)(ntiles < 256 ? ntiles : 256);
-    hipLaunchKernelGGL(sdf_nograd_t_kernel, dim3(g), dim3(256), 0, stream, static_cast<const void*>(packed + PACKT.stream),
-                       packed + PACKT.bias10, packed + PACK.sdf_b8_0, pts, npts, sdf T_DBG_ARGS);
+    if (h2) hipLaunchKernelGGL(sdf_nograd_h_kernel, dim3(g), dim3(256), 0, stream, static_cast<const void*>(packed + PACKH.stream),
+                               packed + PACKH.bias11, packed + PACK.sdf_b8_0, pts, npts, sdf T_DBG_ARGS);
+    else hipLaunchKernelGGL(sdf_nograd_t_kernel, dim3(g), dim3(256), 0, stream, static_cast<const void*>(packed + PACKT.stream),
+                            packed + PACKT.bias10, packed + PACK.sdf_b8_0, pts, npts, sdf T_DBG_ARGS);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 int launch_sdf_fwd_train_t(const float* packed, const float* pts, int64_t npts, float* sdf, float* feat, float* act, float* eaux,
-                           hipStream_t stream) {
+                           bool h2, hipStream_t stream) {
     const int64_t ntiles = (npts + T_PTS - 1) / T_PTS;
     const int g = (int)(ntiles < 256 ? ntiles : 256);
-    hipLaunchKernelGGL(sdf_fwd_train_t_kernel, dim3(g), dim3(256), 0, stream, static_cast<const void*>(packed + PACKT.stream),
-                       packed + PACKT.bias10, packed + PACK.sdf_b8_0, pts, npts, sdf, feat, act, eaux T_DBG_ARGS);
+    if (h2) hipLaunchKernelGGL(sdf_fwd_train_h_kernel, dim3(g), dim3(256), 0, stream, static_cast<const void*>(packed + PACKH.stream),
+                               packed + PACKH.bias11, packed + PACK.sdf_b8_0, pts, npts, sdf, feat, act, eaux T_DBG_ARGS);
+    else hipLaunchKernelGGL(sdf_fwd_train_t_kernel, dim3(g), dim3(256), 0, stream, static_cast<const void*>(packed + PACKT.stream),
+                            packed + PACKT.bias10, packed + PACK.sdf_b8_0, pts, npts, sdf, feat, act, eaux T_DBG_ARGS);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 

@@ -6,7 +6,7 @@
 // v_mfma_f32_32x32x16_bf16 operand), so operands leave HBM as 1 KiB coalesced wave loads.  8 waves per workgroup,
 // split-K over tiles across gridDim.x persistent workgroups, slabs reduced in slab_reduce_kernel / fold_kernel
 // (deterministic: no float atomics).
-#include "tile16.h"
+#include "tile16h.h"
 #include "kernels.h"
 #include "workspace.h"
 
@@ -17,6 +17,7 @@ struct DwJob {
     const float* A2; const float* B2;      // optional second (A,B) pair accumulated into the same output
     int64_t off;                           // float offset of this job's [256 x nb*32] slab inside a split's slab block
     int nb;                                // 8: B is a main native tile; 2: B is an aux native tile
+    int sa1, sb1, sa2, sb2;                // two-piece fp16 kernel: the operands' workspace.h absmax class (-1: the constant H2_XS)
 };
 struct DwJobs { DwJob j[16]; int n; };
 // Job groups (round 3): the persistent workgroups are dealt to DW_GROUPS groups of consecutive jobs, group k getting a share of
@@ -354,6 +355,179 @@ __device__ __forceinline__ void dw_body_pieces(const DwJob& J, int64_t t0, int64
         }
 }
 
+// ---------------------------------------------------------------- two-piece fp16 variant (DH_ARITH_SPLIT_F16; tile16h.h)
+// dw_body_pieces with two fp16 pieces per value and three products: 24 MFMAs per wave and k-pair instead of 48, a 32 KiB piece
+// image per k-pair instead of 48.  Operand scales: every operand class has ONE power-of-two scale per launch -- from the class's
+// per-launch maximum that the kernels writing the tiles posted (workspace.h absmax; scaled maximum in [256, 512)), or the constant
+// H2_XS for softplus outputs and embeddings -- applied as the raw values are split.  A job with two operand pairs runs pair 0 over
+// all its tiles first; at the change-over the accumulators are multiplied by the ratio of the two pairs' scale products (a power
+// of two: exact), and the slab is written divided by the last pair's.
+constexpr int DWH_TILE = 2 * 1024;
+constexpr int DWH_BUF = 16 * DWH_TILE;
+struct DwScales { float a[2], b[2]; };
+__device__ __forceinline__ float dw_class_scale(const unsigned* __restrict__ absmax, int cls) {
+    return cls < 0 ? H2_XS : __builtin_bit_cast(float, pow2_scale_bits(absmax[cls * ABSMAX_STRIDE], H2_AT));
+}
+template <int I, int JB>
+__device__ __forceinline__ void dw_half_steps_h(f32x16 (&acc)[2][4], const H2 (&a)[2], const H2 (&b)[2], H2 (&pc)[MT],
+                                                const RawA& raw, SplitStateH& st) {
+    if constexpr (I < 12) {
+        constexpr int pa[3] = {0, 1, 0}, pb[3] = {1, 0, 0};
+        constexpr int p = I / 4, ii = (I % 4) / 2, j = I % 2;
+        __builtin_amdgcn_s_setprio(1);
+        acc[ii][JB + j] = mfma_h(a[ii].p[pa[p]], b[j].p[pb[p]], acc[ii][JB + j]);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        split_step_h<I, true>(pc, raw, st);
+        __builtin_amdgcn_sched_barrier(0);
+        dw_half_steps_h<I + 1, JB>(acc, a, b, pc, raw, st);
+    }
+}
+template <int NB>
+__device__ __forceinline__ void dw_body_pieces_h(const DwJob& J, const DwScales& sc, int64_t t0, int64_t t1, float* __restrict__ out,
+                                                 int wave, int lane, char* lds) {
+    constexpr int KQ = MT * 4;
+    constexpr int BT = (NB == 8) ? TILE_F : AUXT_F;
+    constexpr int NA = DwShape<NB>::NA, NBW = DwShape<NB>::NBW;
+    f32x16 acc[NA][NBW];
+    DH_UNROLL for (int i = 0; i < NA; ++i) DH_UNROLL for (int j = 0; j < NBW; ++j) DH_UNROLL for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int T = (int)(t1 - t0);
+    const int npairs = J.A2 ? 2 : 1;
+    const int NP1 = T * (KQ / 2);                         // k-pairs of one operand pair
+    const int NP = npairs * NP1;
+    const bool has_b = NB == 8 || wave < 2;
+    struct Raw { f32x4 a0, a1, b0, b1; float sa, sb; };
+    int ld_pair = 0, ld_kp = 0;
+    int64_t ld_tile = t0;
+    auto load = [&](Raw& r) {
+        const float* A = ld_pair ? J.A2 : J.A1;
+        const float* Bm = ld_pair ? J.B2 : J.B1;
+        r.sa = sc.a[ld_pair]; r.sb = sc.b[ld_pair];
+        const int kq = 2 * ld_kp, m = kq >> 2, r4 = kq & 3;
+        const f32x4* ga = reinterpret_cast<const f32x4*>(A + ld_tile * TILE_F) + ((((wave >> 1) * MT + m) * 2 + (wave & 1)) * 4 + r4) * 64 + lane;
+        r.a0 = __builtin_nontemporal_load(ga); r.a1 = __builtin_nontemporal_load(ga + 64);
+        if (has_b) {
+            const int bn = (NB == 8) ? wave : (wave & 1);
+            const int bi = (NB == 8) ? ((((bn >> 1) * MT + m) * 2 + (bn & 1)) * 4 + r4) : ((m * 2 + bn) * 4 + r4);
+            const f32x4* gb = reinterpret_cast<const f32x4*>(Bm + ld_tile * BT) + bi * 64 + lane;
+            r.b0 = __builtin_nontemporal_load(gb); r.b1 = __builtin_nontemporal_load(gb + 64);
+        }
+        if (++ld_kp == KQ / 2) {
+            ld_kp = 0;
+            if (++ld_tile == t1) { ld_tile = t0; if (++ld_pair == npairs) ld_pair = 0; }    // past the end: wrap (harmless re-read)
+        }
+    };
+    auto publish_a = [&](const Raw& r, int par) {
+        char* base = lds + par * DWH_BUF + lane * 16;
+        const H2 pa = split2(r.a0 * r.sa, r.a1 * r.sa);
+        DH_UNROLL for (int p = 0; p < 2; ++p) *reinterpret_cast<u32x4*>(base + wave * DWH_TILE + p * 1024) = pa.p[p];
+    };
+    auto publish_b = [&](const Raw& r, int par) {
+        char* base = lds + par * DWH_BUF + lane * 16;
+        if (has_b) {
+            const H2 pb = split2(r.b0 * r.sb, r.b1 * r.sb);
+            const int bn = (NB == 8) ? wave : (wave & 1);
+            DH_UNROLL for (int p = 0; p < 2; ++p) *reinterpret_cast<u32x4*>(base + (8 + bn) * DWH_TILE + p * 1024) = pb.p[p];
+        }
+    };
+    auto piece = [&](int par, int tile) {
+        H2 f;
+        const char* base = lds + par * DWH_BUF + tile * DWH_TILE + lane * 16;
+        DH_UNROLL for (int p = 0; p < 2; ++p) f.p[p] = *reinterpret_cast<const u32x4*>(base + p * 1024);
+        return f;
+    };
+    if (NP > 0) {
+        Raw r0, r1;
+        load(r0);
+        load(r1);
+        __builtin_amdgcn_sched_barrier(0);
+        publish_a(r0, 0);
+        publish_b(r0, 0);
+        load(r0);                                          // pair 2 in flight
+        __syncthreads();
+        constexpr int H = NBW / 2;
+        auto step = [&](int par, Raw& nxt) {
+            if constexpr (NB == 8) {
+                H2 a[2], b[2];
+                H2 pc[MT];
+                RawA raw;
+                SplitStateH st;
+                char* wbase = lds + (par ^ 1) * DWH_BUF + lane * 16;
+                DH_UNROLL for (int ii = 0; ii < 2; ++ii) a[ii] = piece(par, (wave >> 1) * 2 + ii);
+                DH_UNROLL for (int j = 0; j < 2; ++j) b[j] = piece(par, 8 + (wave & 1) * 4 + j);
+                raw.lo[0] = nxt.a0; raw.hi[0] = nxt.a1; st.sc = nxt.sa;
+                __builtin_amdgcn_sched_barrier(0);
+                dw_half_steps_h<0, 0>(acc, a, b, pc, raw, st);
+                DH_UNROLL for (int p = 0; p < 2; ++p) *reinterpret_cast<u32x4*>(wbase + wave * DWH_TILE + p * 1024) = pc[0].p[p];
+                DH_UNROLL for (int j = 0; j < 2; ++j) b[j] = piece(par, 8 + (wave & 1) * 4 + 2 + j);
+                raw.lo[0] = nxt.b0; raw.hi[0] = nxt.b1; st.sc = nxt.sb;
+                __builtin_amdgcn_sched_barrier(0);
+                dw_half_steps_h<0, 2>(acc, a, b, pc, raw, st);
+                DH_UNROLL for (int p = 0; p < 2; ++p) *reinterpret_cast<u32x4*>(wbase + (8 + wave) * DWH_TILE + p * 1024) = pc[0].p[p];
+                __builtin_amdgcn_sched_barrier(0);
+                load(nxt);
+                __builtin_amdgcn_sched_barrier(0);
+                __syncthreads();
+                return;
+            }
+            H2 a[NA], b[H];
+            DH_UNROLL for (int ii = 0; ii < NA; ++ii) a[ii] = piece(par, (NB == 8) ? ((wave >> 1) * 2 + ii) : wave);
+            DH_UNROLL for (int j = 0; j < H; ++j) b[j] = piece(par, 8 + ((NB == 8) ? ((wave & 1) * 4 + j) : j));
+            __builtin_amdgcn_sched_barrier(0);
+            publish_a(nxt, par ^ 1);
+            DH_UNROLL for (int ii = 0; ii < NA; ++ii)
+                DH_UNROLL for (int j = 0; j < H; ++j) acc[ii][j] = mfma3(a[ii], b[j], acc[ii][j]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (H < NBW) {
+                DH_UNROLL for (int j = 0; j < H; ++j) b[j] = piece(par, 8 + ((NB == 8) ? ((wave & 1) * 4 + H + j) : (H + j)));
+            }
+            publish_b(nxt, par ^ 1);
+            DH_UNROLL for (int ii = 0; ii < NA; ++ii)
+                DH_UNROLL for (int j = 0; j < H; ++j) acc[ii][H + j] = mfma3(a[ii], b[j], acc[ii][H + j]);
+            __builtin_amdgcn_sched_barrier(0);
+            load(nxt);
+            __builtin_amdgcn_sched_barrier(0);
+            __syncthreads();
+        };
+        const float ratio = npairs == 2 ? (sc.a[1] * sc.b[1]) / (sc.a[0] * sc.b[0]) : 1.f;       // powers of two: exact
+        int p = 0;
+        for (; p + 1 < NP; p += 2) {
+            if (npairs == 2 && p == NP1) {               // NP1 is even: the change-over falls on a step(0) boundary
+                DH_UNROLL for (int i = 0; i < NA; ++i) DH_UNROLL for (int j = 0; j < NBW; ++j) DH_UNROLL for (int r = 0; r < 16; ++r) acc[i][j][r] *= ratio;
+            }
+            step(0, r1);
+            step(1, r0);
+        }
+        if (p < NP) step(0, r1);
+    }
+    const float inv = 1.f / (sc.a[npairs - 1] * sc.b[npairs - 1]);
+    DH_UNROLL for (int i = 0; i < NA; ++i)
+        DH_UNROLL for (int j = 0; j < NBW; ++j) {
+            const int ot = (NB == 8) ? ((wave >> 1) * 2 + i) : wave;
+            const int nt = (NB == 8) ? ((wave & 1) * 4 + j) : j;
+            float* o = out + ((int64_t)ot * NB + nt) * 1024 + lane;
+            DH_UNROLL for (int r = 0; r < 16; ++r) o[r * 64] = acc[i][j][r] * inv;
+        }
+}
+
+__global__ __launch_bounds__(512, 1) void dw_f16x2_kernel(DwJobs jobs, DwGroups groups, int64_t ntiles, float* __restrict__ slabs,
+                                                          int64_t gstride, const unsigned* __restrict__ absmax) {
+    __shared__ __attribute__((aligned(16))) char pieces[2 * DWH_BUF];
+    const int g = blockIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int k = dw_group_of(groups, g), gl = g - groups.wg0[k], gc = groups.wg0[k + 1] - groups.wg0[k];
+    const int64_t t0 = ntiles * gl / gc, t1 = ntiles * (gl + 1) / gc;
+    float* base = slabs + (int64_t)g * gstride;
+    for (int job = groups.job0[k]; job < groups.job0[k + 1]; ++job) {
+        const DwJob J = jobs.j[job];
+        DwScales sc;
+        sc.a[0] = dw_class_scale(absmax, J.sa1); sc.b[0] = dw_class_scale(absmax, J.sb1);
+        sc.a[1] = dw_class_scale(absmax, J.sa2); sc.b[1] = dw_class_scale(absmax, J.sb2);
+        if (J.nb == 8) dw_body_pieces_h<8>(J, sc, t0, t1, base + J.off, wave, lane, pieces);
+        else dw_body_pieces_h<2>(J, sc, t0, t1, base + J.off, wave, lane, pieces);
+    }
+}
+
 __global__ __launch_bounds__(512, 1) void dw_bf16x3_kernel(DwJobs jobs, DwGroups groups, int64_t ntiles, float* __restrict__ slabs,
                                                            int64_t gstride) {
     __shared__ __attribute__((aligned(16))) char pieces[2 * DWP_BUF];
@@ -536,17 +710,25 @@ static void build_dw_jobs(const Workspace& w, float* red, DwJobs& J, SlabPtrs& S
     for (int j = 0; j < 15; ++j) { J.j[j].nb = DW_NBS[j]; J.j[j].off = off; S.out[j] = red + off; S.nb[j] = DW_NBS[j]; off += (int64_t)8 * DW_NBS[j] * 1024; }
     J.n = 15;
     auto T_ = [&](float* base, int idx) { return base + (int64_t)idx * nt * TILE_F; };
+    auto C_ = [&](int j, int sa1, int sb1, int sa2, int sb2) { J.j[j].sa1 = sa1; J.j[j].sb1 = sb1; J.j[j].sa2 = sa2; J.j[j].sb2 = sb2; };
     J.j[0].A1 = T_(w.zbar, 0); J.j[0].B1 = w.eaux; J.j[0].A2 = T_(w.asave, 0); J.j[0].B2 = w.t0aux;
+    C_(0, ABSMAX_ZBAR + 0, -1, ABSMAX_ASAVE + 0, ABSMAX_T0AUX);
     for (int l = 1; l <= 7; ++l) {
         J.j[l].A1 = T_(w.zbar, l); J.j[l].B1 = T_(w.act, l - 1);
         J.j[l].A2 = T_(w.asave, l); J.j[l].B2 = T_(w.tsave, l - 1);
+        C_(l, ABSMAX_ZBAR + l, -1, ABSMAX_ASAVE + l, ABSMAX_TSAVE + l - 1);
     }
     J.j[8].A1 = T_(w.zbar, 4); J.j[8].B1 = w.eaux; J.j[8].A2 = T_(w.asave, 4); J.j[8].B2 = w.t0aux;
+    C_(8, ABSMAX_ZBAR + 4, -1, ABSMAX_ASAVE + 4, ABSMAX_T0AUX);
     J.j[9].A1 = w.featbar; J.j[9].B1 = T_(w.act, 7); J.j[9].A2 = nullptr; J.j[9].B2 = nullptr;
+    C_(9, ABSMAX_FEATBAR, -1, -1, -1);
     J.j[10].A1 = T_(w.czbar, 0); J.j[10].B1 = w.feat; J.j[10].A2 = nullptr; J.j[10].B2 = nullptr;
+    C_(10, ABSMAX_CZBAR + 0, ABSMAX_FEAT, -1, -1);
     J.j[11].A1 = T_(w.czbar, 0); J.j[11].B1 = w.caux; J.j[11].A2 = nullptr; J.j[11].B2 = nullptr;
+    C_(11, ABSMAX_CZBAR + 0, -1, -1, -1);
     for (int l = 1; l <= 3; ++l) {
         J.j[11 + l].A1 = T_(w.czbar, l); J.j[11 + l].B1 = T_(w.cact, l - 1); J.j[11 + l].A2 = nullptr; J.j[11 + l].B2 = nullptr;
+        C_(11 + l, ABSMAX_CZBAR + l, ABSMAX_CACT + l - 1, -1, -1);
     }
 }
 
@@ -585,13 +767,15 @@ static DwGroups build_dw_groups(const DwJobs& J, int G) {
 }
 
 // stage 1: the split-K weight-gradient GEMMs (one kernel)
-int launch_weight_grads_gemm(const Workspace& w, float* slabs, int G, hipStream_t st) {
+int launch_weight_grads_gemm(const Workspace& w, float* slabs, int G, int arith, hipStream_t st) {
     const int64_t gstride = dw_gstride();
     DwJobs J{};
     SlabPtrs S{};
     build_dw_jobs(w, slabs + (int64_t)G * gstride, J, S);
     const DwGroups Gp = build_dw_groups(J, G);
-    if (arith_fp32()) hipLaunchKernelGGL(dw_lds_kernel, dim3(G), dim3(512), 0, st, J, Gp, w.ntiles, slabs, gstride);
+    if (arith == ARITH_FP32) hipLaunchKernelGGL(dw_lds_kernel, dim3(G), dim3(512), 0, st, J, Gp, w.ntiles, slabs, gstride);
+    else if (arith == ARITH_F16) hipLaunchKernelGGL(dw_f16x2_kernel, dim3(G), dim3(512), 0, st, J, Gp, w.ntiles, slabs, gstride,
+                                                    reinterpret_cast<const unsigned*>(w.absmax));
     else hipLaunchKernelGGL(dw_bf16x3_kernel, dim3(G), dim3(512), 0, st, J, Gp, w.ntiles, slabs, gstride);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }

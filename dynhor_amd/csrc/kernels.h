@@ -6,26 +6,42 @@
 
 namespace dh {
 
-// arithmetic mode of the MLP GEMMs (dh_set_arithmetic, include/dynhor_hip.h): false = split-bf16 (shipping), true = native
-// fp32 MFMA.  One process-global word, read at every launch.
-bool arith_fp32();
+// arithmetic of the MLP GEMMs (include/dynhor_hip.h dh_arithmetic): passed to every launch function; the entry points without an
+// arithmetic argument pass the process default (dh_set_arithmetic)
+enum : int { ARITH_BF16 = 0, ARITH_FP32 = 1, ARITH_F16 = 2 };
 int hash_scatter_mode();
 
 int launch_pack_weights(const float* params, float* packed, hipStream_t stream);
 
 // MLP chains (kernels_mlp.hip).  npts is padded by the caller to a multiple of 128 for saved buffers.
-int launch_sdf_nograd(const float* packed, const float* pts, int64_t npts, float* sdf, int grid, hipStream_t stream);
-int launch_sdf_nograd_t(const float* packed, const float* pts, int64_t npts, float* sdf, hipStream_t stream);   // chain_t.hip
+int launch_sdf_nograd(const float* packed, const float* pts, int64_t npts, float* sdf, int grid, int arith, hipStream_t stream);
+int launch_sdf_nograd_t(const float* packed, const float* pts, int64_t npts, float* sdf, bool h2, hipStream_t stream);   // chain_t.hip
 int launch_sdf_fwd_train_t(const float* packed, const float* pts, int64_t npts, float* sdf, float* feat, float* act, float* eaux,
-                           hipStream_t stream);
+                           bool h2, hipStream_t stream);
 
+// (absmax: workspace.h -- the two-piece fp16 kernels post the per-launch maxima of their saved-tile classes there)
 int launch_sdf_fwd_train(const float* packed, const float* pts, int64_t npts, float* sdf, float* feat, float* act,
-                         float* eaux, int grid, hipStream_t stream);
+                         float* eaux, float* absmax, int grid, int arith, hipStream_t stream);
 int launch_sdf_grad(const float* packed, const float* pts, int64_t npts, const float* act, float* asave, float* normals,
-                    int save, float* gesave, int grid, hipStream_t stream);
+                    int save, float* gesave, float* absmax, int grid, int arith, hipStream_t stream);
 int launch_color_fwd(const float* packed, const float* pts, const float* dirs, int n_per_ray, const float* normals,
-                     const float* feat, int64_t npts, float* color, float* cact, float* caux, int save, int grid,
-                     hipStream_t stream);
+                     const float* feat, int64_t npts, float* color, float* cact, float* caux, int save, float* absmax, int grid,
+                     int arith, hipStream_t stream);
+// kernels_mlp_h.hip (two-piece fp16)
+int launch_sdf_grad_h(const float* packed, const float* pts, int64_t npts, const float* act, float* asave, float* normals,
+                      int save, float* gesave, unsigned* absmax, int grid, hipStream_t stream);
+int launch_color_fwd_h(const float* packed, const float* pts, const float* dirs, int n_per_ray, const float* normals,
+                       const float* feat, int64_t npts, float* color, float* cact, float* caux, int save, unsigned* absmax,
+                       int grid, hipStream_t stream);
+int launch_color_bwd_h(const float* packed, const float* colors, const float* d_colors, const float* dirs, int n_per_ray,
+                       int64_t npts, const float* cact, float* czbar, float* featbar, float* d_normals, float* tpart,
+                       float* d_pts, float* d_dirs_pts, unsigned* absmax, int grid, hipStream_t st);
+int launch_sdf_tangent_h(const float* packed, const float* pts, const float* d_normals, int64_t npts, const float* act,
+                         const float* asave, float* t0aux, float* tsave, float* rsave, float* tpart, unsigned* absmax, int grid,
+                         hipStream_t st);
+int launch_sdf_bwd_h(const float* packed, const float* d_sdf, const float* pts, const float* d_normals, int64_t npts,
+                     const float* act, const float* rsave, const float* featbar, const float* gesave, float* zbar, float* tpart,
+                     float* d_pts, unsigned* absmax, int grid, hipStream_t st);
 
 // per-ray kernels (kernels_ray.hip)
 int launch_gen_rays(const uint8_t* rgb, const int8_t* label, const uint8_t* normal, const float* R, const float* T,
@@ -66,20 +82,21 @@ int launch_corr_loss(const float* rays_o, const float* rays_d, const float* z, c
 
 // backward chains (kernels_mlp_bwd.hip) and weight gradients (dw.hip)
 int launch_color_bwd(const float* packed, const float* colors, const float* d_colors, int64_t npts, const float* cact,
-                     float* czbar, float* featbar, float* d_normals, float* tpart, int grid, hipStream_t st);
+                     float* czbar, float* featbar, float* d_normals, float* tpart, float* absmax, int grid, int arith, hipStream_t st);
 // pose-refinement variants (split-bf16 arithmetic only): additionally the adjoints w.r.t. the sample points / view directions
 int launch_color_bwd_rays(const float* packed, const float* colors, const float* d_colors, const float* dirs, int n_per_ray,
                           int64_t npts, const float* cact, float* czbar, float* featbar, float* d_normals, float* tpart,
-                          float* d_pts, float* d_dirs_pts, int grid, hipStream_t st);
+                          float* d_pts, float* d_dirs_pts, float* absmax, int grid, int arith, hipStream_t st);
 int launch_sdf_bwd_rays(const float* packed, const float* d_sdf, const float* pts, const float* d_normals, int64_t npts,
                         const float* act, const float* rsave, const float* featbar, const float* gesave, float* zbar,
-                        float* tpart, float* d_pts, int grid, hipStream_t st);
+                        float* tpart, float* d_pts, float* absmax, int grid, int arith, hipStream_t st);
 int launch_sdf_tangent(const float* packed, const float* pts, const float* d_normals, int64_t npts, const float* act,
-                       const float* asave, float* t0aux, float* tsave, float* rsave, float* tpart, int grid, hipStream_t st);
+                       const float* asave, float* t0aux, float* tsave, float* rsave, float* tpart, float* absmax, int grid, int arith,
+                       hipStream_t st);
 int launch_sdf_bwd(const float* packed, const float* d_sdf, int64_t npts, const float* act, const float* rsave,
-                   const float* featbar, float* zbar, float* tpart, int grid, hipStream_t st);
+                   const float* featbar, float* zbar, float* tpart, float* absmax, int grid, int arith, hipStream_t st);
 struct Workspace;
-int launch_weight_grads_gemm(const Workspace& w, float* slabs, int G, hipStream_t st);
+int launch_weight_grads_gemm(const Workspace& w, float* slabs, int G, int arith, hipStream_t st);
 int launch_weight_grads_fold(const Workspace& w, float* slabs, float* tred, int G, int nS, const float* params,
                              const float* packed, float* grad, hipStream_t st);
 

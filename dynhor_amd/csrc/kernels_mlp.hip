@@ -7,6 +7,7 @@
 #include "kernels.h"
 #include "mlp_common.h"
 #include "tile16.h"
+#include "workspace.h"
 
 
 namespace dh {
@@ -377,32 +378,35 @@ static inline int grid_for(int64_t npts, int grid) {
 }
 
 int launch_sdf_fwd_train(const float* packed, const float* pts, int64_t npts, float* sdf, float* feat, float* act,
-                         float* eaux, int grid, hipStream_t stream) {
-    if (!arith_fp32()) return launch_sdf_fwd_train_t(packed, pts, npts, sdf, feat, act, eaux, stream);
+                         float* eaux, float* absmax, int grid, int arith, hipStream_t stream) {
+    if (arith == ARITH_F16 && absmax) (void)hipMemsetAsync(absmax, 0, ABSMAX_FLOATS * sizeof(float), stream);    // workspace.h: the step's class maxima
+    if (arith != ARITH_FP32) return launch_sdf_fwd_train_t(packed, pts, npts, sdf, feat, act, eaux, arith == ARITH_F16, stream);
     hipLaunchKernelGGL(sdf_fwd_train_kernel, dim3(grid_for(npts, grid)), dim3(256), 0, stream, make_sdf_ptrs(packed), pts, npts, sdf, feat, act, eaux);
     return ok();
 }
 int launch_sdf_grad(const float* packed, const float* pts, int64_t npts, const float* act, float* asave, float* normals,
-                    int save, float* gesave, int grid, hipStream_t stream) {
-    // the reverse chain ships in its piece-plane form (one workgroup per CU): 1.68 vs 1.75 ms for split-on-fetch
-    if (arith_fp32()) hipLaunchKernelGGL(sdf_grad_kernel, dim3(grid_for(npts, grid)), dim3(256), 0, stream, make_sdf_ptrs(packed), pts, npts, act, asave, normals, save, gesave);
+                    int save, float* gesave, float* absmax, int grid, int arith, hipStream_t stream) {
+    if (arith == ARITH_F16) return launch_sdf_grad_h(packed, pts, npts, act, asave, normals, save, gesave, reinterpret_cast<unsigned*>(absmax), grid, stream);
+    if (arith == ARITH_FP32) hipLaunchKernelGGL(sdf_grad_kernel, dim3(grid_for(npts, grid)), dim3(256), 0, stream, make_sdf_ptrs(packed), pts, npts, act, asave, normals, save, gesave);
     else hipLaunchKernelGGL(sdf_grad_s_kernel, dim3(grid_for(npts, grid)), dim3(256), 0, stream, make_sdf16_ptrs(packed), pts, npts, act, asave, normals, save, gesave);
     return ok();
 }
 int launch_color_fwd(const float* packed, const float* pts, const float* dirs, int n_per_ray, const float* normals,
-                     const float* feat, int64_t npts, float* color, float* cact, float* caux, int save, int grid,
-                     hipStream_t stream) {
+                     const float* feat, int64_t npts, float* color, float* cact, float* caux, int save, float* absmax, int grid,
+                     int arith, hipStream_t stream) {
+    if (arith == ARITH_F16) return launch_color_fwd_h(packed, pts, dirs, n_per_ray, normals, feat, npts, color, cact, caux, save,
+                                                     reinterpret_cast<unsigned*>(absmax), grid, stream);
     const int g = grid_for(npts, grid);
-    if (arith_fp32()) hipLaunchKernelGGL(color_fwd_kernel, dim3(g), dim3(256), 0, stream, make_col_ptrs(packed), pts, dirs, n_per_ray, normals,
-                                         feat, npts, color, cact, caux, save);
+    if (arith == ARITH_FP32) hipLaunchKernelGGL(color_fwd_kernel, dim3(g), dim3(256), 0, stream, make_col_ptrs(packed), pts, dirs, n_per_ray, normals,
+                                                feat, npts, color, cact, caux, save);
     else hipLaunchKernelGGL(color_fwd_s_kernel, dim3(g), dim3(256), 0, stream, make_col16_ptrs(packed), pts, dirs, n_per_ray, normals,
                             feat, npts, color, cact, caux, save);
     return ok();
 }
 
-int launch_sdf_nograd(const float* packed, const float* pts, int64_t npts, float* sdf, int grid, hipStream_t stream) {
+int launch_sdf_nograd(const float* packed, const float* pts, int64_t npts, float* sdf, int grid, int arith, hipStream_t stream) {
     if (npts <= 0) return 0;
-    if (!arith_fp32()) return launch_sdf_nograd_t(packed, pts, npts, sdf, stream);
+    if (arith != ARITH_FP32) return launch_sdf_nograd_t(packed, pts, npts, sdf, arith == ARITH_F16, stream);
     hipLaunchKernelGGL(sdf_nograd_kernel, dim3(grid_for(npts, grid)), dim3(256), 0, stream, make_sdf_ptrs(packed), pts, npts, sdf);
     return ok();
 }

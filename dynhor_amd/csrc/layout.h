@@ -170,4 +170,47 @@ constexpr PackTOff make_packt_off() {
 }
 constexpr PackTOff PACKT = make_packt_off();
 
+
+// ---------------------------------------------------------------- two-piece fp16 packed weights (tile16h.h; round 4), appended after PACKT
+// Same job list and operand geometry as PACK16 with TWO fp16 pieces per value instead of three bf16 ones: W' = S_w W with S_w a
+// power of two chosen per linear from max |W| (pack.hip: the scaled maximum lies in [8, 16)), hi = fp16(W'), lo = fp16(W' - hi)
+// (the unscaled residual; fp16 subnormals carry it below 2^-14).  f16x8 (16 B) index ((kc*NT + nt)*2 + piece)*64 + lane.
+// `wabs`: one u32 per linear (sdf lin0..8, colour lin0..4) = the bits of max |W| (written by rowscale_kernel with atomicMax,
+// zeroed before it); packers and consumers derive S_w / 1/S_w from it with wscale_from_bits() below.
+// `stream` / `bias11`: chain_t.hip's H2 stream (132 stages x 8 m-tiles x 2 pieces = 16 KB per stage) and its bias table: rows
+// 0..7 = 16 x bias of lin0..lin7 (the H2 chain carries activations scaled by 16), row 8 = effective weight row 0 of lin8, row 9 =
+// lin8's bias rows 1..256 (unscaled), row 10 = 1/S_w of lin0..lin8 in its first nine floats.
+constexpr int64_t packh_floats(int nkc, int nt) { return (int64_t)nkc * nt * 2 * 64 * 4; }
+constexpr int64_t PACKTH_STREAM_FLOATS = (int64_t)T_STREAM_STAGES_TRAIN * 8 * 2 * 64 * 4;
+struct PackHOff {
+    int64_t sdf_fwd_main[N_SDF], sdf_fwd_aux[N_SDF], sdf_rev_main[N_SDF], sdf_rev_aux[N_SDF];
+    int64_t col_fwd_main[N_COL], col_fwd_aux0, col_rev_main[N_COL], col_rev_aux0;
+    int64_t wabs;                  // 16 u32
+    int64_t stream, bias11;
+    int64_t total;                 // end of the whole packed buffer
+};
+constexpr PackHOff make_packh_off() {
+    PackHOff p{};
+    int64_t o = PACKT.total;
+    for (int l = 0; l < N_SDF; ++l) {
+        p.sdf_fwd_main[l] = o; o += packh_floats(sdf_kc_main(l), 8);
+        p.sdf_fwd_aux[l] = o;  o += (l == 0 || l == 4) ? packh_floats(3, 8) : 0;
+        p.sdf_rev_main[l] = o; o += (l >= 1) ? packh_floats(16, 8) : 0;
+        p.sdf_rev_aux[l] = o;  o += (l == 0 || l == 4) ? packh_floats(16, 2) : 0;
+    }
+    for (int l = 0; l < N_COL; ++l) {
+        p.col_fwd_main[l] = o; o += (l < 4) ? packh_floats(16, 8) : 0;
+        p.col_rev_main[l] = o; o += (l < 4) ? packh_floats(16, 8) : 0;
+    }
+    p.col_fwd_aux0 = o; o += packh_floats(3, 8);
+    p.col_rev_aux0 = o; o += packh_floats(16, 2);
+    p.wabs = o; o += 16;
+    p.stream = o; o += PACKTH_STREAM_FLOATS;
+    p.bias11 = o; o += 11 * 256;
+    p.total = (o + 3) / 4 * 4;
+    return p;
+}
+constexpr PackHOff PACKH = make_packh_off();
+constexpr float H2_XS = 16.f;      // static power-of-two scale of O(1) operands (softplus / ReLU activations, embeddings, features)
+
 }  // namespace dh

@@ -10,9 +10,18 @@ constexpr int DW_G = 256;         // split-K factor of the weight-gradient GEMMs
 constexpr int DW_NS = 64;         // split factor of the tile-partial reduction
 int64_t dw_slab_floats(int G);   // per-tile partial-sum slots of 256 floats (bias grads, lin8 row 0, colour lin4)
 
+// absmax: per-launch maxima of the saved-tile classes whose scale the two-piece fp16 weight-gradient kernel needs (tile16h.h):
+// one u32 (the fp32 bits of the maximum |value|) per class, classes 64 words apart; zeroed by the training forward
+// (launch_sdf_fwd_train, DH_ARITH_SPLIT_F16), raised with atomicMax by the kernels that write the tiles.  Classes without a slot
+// (act, eaux, caux: softplus outputs / embeddings) are scaled by the constant H2_XS.
+enum : int { ABSMAX_ASAVE = 0, ABSMAX_ZBAR = 8, ABSMAX_TSAVE = 16, ABSMAX_T0AUX = 23, ABSMAX_FEATBAR = 24, ABSMAX_CZBAR = 25,
+             ABSMAX_CACT = 29, ABSMAX_FEAT = 33, ABSMAX_N = 34 };
+constexpr int ABSMAX_FLOATS = 64 * 64;
+
 struct Workspace {
     int64_t ntiles;
     float* base;
+    float* absmax;  // [64][64] u32, see above
     // forward (saved for backward)
     float* act;     // [8][nt][TILE_F]   inputs of SDF layers 1..8 (post-softplus)
     float* eaux;    // [nt][AUXT_F]      positional embedding (aux native)
@@ -41,6 +50,7 @@ inline Workspace carve_workspace(float* base, int64_t npts) {
     w.base = base;
     int64_t o = 0;
     auto take = [&](int64_t n) { float* p = base ? base + o : nullptr; o += n; return p; };
+    w.absmax = take(ABSMAX_FLOATS);
     w.act = take(8 * nt * TILE_F);
     w.eaux = take(nt * AUXT_F);
     w.feat = take(nt * TILE_F);

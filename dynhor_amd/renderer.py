@@ -106,9 +106,9 @@ class NeuSRenderer:
         self._ws = None
         self._ws_token = 0
         self.timer = StageTimer()
-        # dh_set_arithmetic is a host-side word of the library, read when a stage is LAUNCHED.  A renderer constructed with an
-        # explicit arithmetic (_lib.ARITH_SPLIT_BF16 / ARITH_FP32_MFMA) sets the word before each of its stage groups, so two
-        # renderers of one process can run different arithmetics (single-threaded hosts; None = leave the word alone).
+        # the arithmetic of this renderer's MLP stages (_lib.ARITH_SPLIT_F16 / ARITH_SPLIT_BF16 / ARITH_FP32_MFMA), passed with
+        # every launch through the `_ex` entry points: no process-global word is read, so renderers with different arithmetics
+        # can run side by side, also from different host threads.  None = the library's default at the time of each call.
         self.arithmetic = arithmetic
 
     def _make_store(self, sdf_network, deviation_network, color_network, device):
@@ -128,23 +128,21 @@ class NeuSRenderer:
 
     # ------------------------------------------------------------------ network stages (the model-family hooks;
     # hash_fields.HashNeuSRenderer overrides these three + _workspace_need)
-    def _select_arithmetic(self):
-        if self.arithmetic is not None and _lib.get_arithmetic() != self.arithmetic:
-            _lib.set_arithmetic(self.arithmetic)
+    def _arith(self) -> int:
+        return _lib.get_arithmetic() if self.arithmetic is None else int(self.arithmetic)
 
     def _net_sdf_nograd(self, tag, pts, n, out):
-        self._select_arithmetic()
-        self.timer(tag, _lib.lib().dh_sdf_nograd, _p(self.store.packed), _p(pts), n, _p(out), _lib.stream())
+        self.timer(tag, _lib.lib().dh_sdf_nograd_ex, self._arith(), _p(self.store.packed), _p(pts), n, _p(out), _lib.stream())
 
     def _net_forward(self, s, packed):
         """pts [P,3] -> s.sdf, s.normals (d sdf / d x), s.colors; saves what _net_backward needs in s.ws."""
         L, T = _lib.lib(), self.timer
         P = s.B * s.n
-        self._select_arithmetic()
-        T("sdf_forward", L.dh_sdf_forward, _p(packed), _p(s.pts), P, _p(s.ws), _p(s.sdf), _lib.stream())
+        ar = s.arith = self._arith()          # the backward of this forward runs in the same arithmetic
+        T("sdf_forward", L.dh_sdf_forward_ex, ar, _p(packed), _p(s.pts), P, _p(s.ws), _p(s.sdf), _lib.stream())
         save = 0 if s.infer_only else (2 if getattr(s, "ray_grads", False) else 1)
-        T("sdf_gradient", L.dh_sdf_gradient, _p(packed), _p(s.pts), P, _p(s.ws), _p(s.normals), save, _lib.stream())
-        T("color_forward", L.dh_color_forward, _p(packed), _p(s.pts), _p(s.rays_d), s.n, _p(s.normals), P, _p(s.ws),
+        T("sdf_gradient", L.dh_sdf_gradient_ex, ar, _p(packed), _p(s.pts), P, _p(s.ws), _p(s.normals), save, _lib.stream())
+        T("color_forward", L.dh_color_forward_ex, ar, _p(packed), _p(s.pts), _p(s.rays_d), s.n, _p(s.normals), P, _p(s.ws),
           _p(s.colors), save, _lib.stream())
 
     def _net_backward(self, s, d_sdf, d_normals, d_colors, grad):
@@ -152,21 +150,21 @@ class NeuSRenderer:
         also leaves s.d_pts [P,3] (d loss / d sample point) and s.d_dirs_pts [P,3] (d loss / d ray direction per point)."""
         L, T, st = _lib.lib(), self.timer, self.store
         P = s.B * s.n
-        self._select_arithmetic()
+        ar = s.arith
         if getattr(s, "ray_grads", False):
             s.d_pts = torch.empty(P, 3, device=s.pts.device)
             s.d_dirs_pts = torch.empty(P, 3, device=s.pts.device)
-            T("color_backward", L.dh_color_backward_rays, _p(st.packed), _p(s.colors), _p(d_colors), _p(s.rays_d), s.n, P, _p(s.ws),
+            T("color_backward", L.dh_color_backward_rays_ex, ar, _p(st.packed), _p(s.colors), _p(d_colors), _p(s.rays_d), s.n, P, _p(s.ws),
               _p(d_normals), _p(s.d_pts), _p(s.d_dirs_pts), _lib.stream())
-            T("sdf_tangent", L.dh_sdf_tangent, _p(st.packed), _p(s.pts), _p(d_normals), P, _p(s.ws), _lib.stream())
-            T("sdf_backward", L.dh_sdf_backward_rays, _p(st.packed), _p(d_sdf), _p(s.pts), _p(d_normals), P, _p(s.ws), _p(s.d_pts),
+            T("sdf_tangent", L.dh_sdf_tangent_ex, ar, _p(st.packed), _p(s.pts), _p(d_normals), P, _p(s.ws), _lib.stream())
+            T("sdf_backward", L.dh_sdf_backward_rays_ex, ar, _p(st.packed), _p(d_sdf), _p(s.pts), _p(d_normals), P, _p(s.ws), _p(s.d_pts),
               _lib.stream())
         else:
-            T("color_backward", L.dh_color_backward, _p(st.packed), _p(s.colors), _p(d_colors), P, _p(s.ws), _p(d_normals),
+            T("color_backward", L.dh_color_backward_ex, ar, _p(st.packed), _p(s.colors), _p(d_colors), P, _p(s.ws), _p(d_normals),
               _lib.stream())
-            T("sdf_tangent", L.dh_sdf_tangent, _p(st.packed), _p(s.pts), _p(d_normals), P, _p(s.ws), _lib.stream())
-            T("sdf_backward", L.dh_sdf_backward, _p(st.packed), _p(d_sdf), P, _p(s.ws), _lib.stream())
-        T("weight_grads_gemm", L.dh_weight_grads_gemm, P, _p(s.ws), _lib.stream())
+            T("sdf_tangent", L.dh_sdf_tangent_ex, ar, _p(st.packed), _p(s.pts), _p(d_normals), P, _p(s.ws), _lib.stream())
+            T("sdf_backward", L.dh_sdf_backward_ex, ar, _p(st.packed), _p(d_sdf), P, _p(s.ws), _lib.stream())
+        T("weight_grads_gemm", L.dh_weight_grads_gemm_ex, ar, P, _p(s.ws), _lib.stream())
         T("weight_grads_fold", L.dh_weight_grads_fold, _p(st.packed), _p(st.flat), P, _p(s.ws), _p(grad), _lib.stream())
 
     # ------------------------------------------------------------------ no-grad SDF queries

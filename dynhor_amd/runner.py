@@ -114,7 +114,7 @@ class Runner:
         ar = self.conf["model"].get("arithmetic")
         if ar is not None:
             from . import _lib
-            extra["arithmetic"] = {"split_bf16": _lib.ARITH_SPLIT_BF16, "fp32_mfma": _lib.ARITH_FP32_MFMA}[ar]
+            extra["arithmetic"] = _lib.ARITH_NAMES[ar]
         self.renderer = renderer_cls(self.nerf_outside, self.sdf_network, self.deviation_network, self.color_network,
                                      store=self.store, device=self.device, **self.conf["model"]["neus_renderer"], **extra)
         self.pose_refiner = None

@@ -11,11 +11,14 @@
  *   - the caller allocates everything (torch tensors); the library never allocates, frees or retains pointers.
  *   - `stream` is a hipStream_t passed as void*; kernels are enqueued on it, no implicit synchronisation.
  *   - return 0 on success or a negative dh_status; never throws, never exits.  Re-entrant: the library keeps no
- *     pointer and no per-call state.  Its ONLY process-global state is the two mode words set by dh_set_arithmetic() and
- *     dh_hash_set_scatter_mode() below (plain ints read at every launch; no environment variable is read anywhere).
- *   - arithmetic: every buffer that crosses this boundary is fp32.  Inside, the GEMMs form each fp32 product from bf16
- *     pieces on the bf16 matrix cores (3-way split of both operands, six MFMA products, fp32 accumulation: 2^-24
- *     relative, i.e. fp32 accuracy -- DESIGN.md section 3).
+ *     pointer and no per-call state.  Its ONLY process-global state is the two DEFAULT words set by dh_set_arithmetic() and
+ *     dh_hash_set_scatter_mode() below (plain ints; no environment variable is read anywhere).  Every MLP stage also has
+ *     an `_ex` entry point that takes the arithmetic as its first argument and reads no global at all: two host threads
+ *     (or two renderers) can run different arithmetics side by side through those.
+ *   - arithmetic: every buffer that crosses this boundary is fp32.  Inside, the GEMMs form each fp32 product from
+ *     low-precision pieces on the matrix cores with fp32 accumulation, to fp32 accuracy:
+ *     DH_ARITH_SPLIT_F16 (default since round 4) two fp16 pieces per operand and three MFMA products, the operands
+ *     scaled by powers of two; DH_ARITH_SPLIT_BF16 three bf16 pieces and six products.
  */
 #ifndef DYNHOR_HIP_H
 #define DYNHOR_HIP_H
@@ -36,11 +39,14 @@ typedef enum {
 int dh_version(void);
 const char* dh_strerror(int status);
 
-/* Arithmetic of every MLP GEMM, process-wide.  DH_ARITH_SPLIT_BF16 (default): the shipping kernels described above.
- * DH_ARITH_FP32_MFMA: the native v_mfma_f32_32x32x2_f32 twin of every kernel (1.34x slower; kept as the second,
- * independent arithmetic that tests/test_gpu_arithmetic_modes.py checks the first against).  Takes effect for launches
- * enqueued after the call; both sets read and write the same buffers (packed weights, workspace, outputs). */
-typedef enum { DH_ARITH_SPLIT_BF16 = 0, DH_ARITH_FP32_MFMA = 1 } dh_arithmetic;
+/* Arithmetic of the MLP GEMMs.  DH_ARITH_SPLIT_F16 (default): two-piece fp16 split, three products (csrc/tile16h.h).
+ * DH_ARITH_SPLIT_BF16: three-piece bf16 split, six products (csrc/tile16.h; the default of rounds 1-3).
+ * DH_ARITH_FP32_MFMA: the native v_mfma_f32_32x32x2_f32 twin of every kernel (the independent, exact-fp32 arithmetic that
+ * tests/test_gpu_arithmetic_modes.py checks the other two against).  All three read and write the same buffers (packed
+ * weights -- dh_pack_weights writes every layout --, workspace, outputs).  dh_set_arithmetic sets the DEFAULT used by the
+ * entry points that take no arithmetic argument (for launches enqueued after the call); the `_ex` entry points below
+ * ignore it. */
+typedef enum { DH_ARITH_SPLIT_BF16 = 0, DH_ARITH_FP32_MFMA = 1, DH_ARITH_SPLIT_F16 = 2 } dh_arithmetic;
 int dh_set_arithmetic(int mode);
 int dh_get_arithmetic(void);
 
@@ -109,6 +115,32 @@ int dh_sdf_backward_rays(const float* packed, const float* d_sdf, const float* p
                          float* ws, float* d_pts, void* stream);
 int dh_weight_grads_gemm(int64_t npts, float* ws, void* stream);
 int dh_weight_grads_fold(const float* packed, const float* params, int64_t npts, float* ws, float* grad_flat, void* stream);
+
+/* The same MLP stages with the arithmetic passed explicitly (a dh_arithmetic value; DH_ERR_BAD_ARG otherwise): no launch
+ * depends on process-global state (SURVEY.md section 8b "re-entrant; no global mutable state").  Arguments after the first
+ * are those of the entry point of the same name above.  (dh_pack_weights and dh_weight_grads_fold do not depend on the
+ * arithmetic.) */
+int dh_sdf_nograd_ex(int arithmetic, const float* packed, const float* pts, int64_t npts, float* sdf, void* stream);
+int dh_mlp_forward_ex(int arithmetic, const float* packed, const float* pts, const float* dirs, int n_per_ray, int64_t npts, float* ws,
+                      float* sdf, float* normals, float* color, void* stream);
+int dh_sdf_forward_ex(int arithmetic, const float* packed, const float* pts, int64_t npts, float* ws, float* sdf, void* stream);
+int dh_sdf_gradient_ex(int arithmetic, const float* packed, const float* pts, int64_t npts, float* ws, float* normals, int save,
+                       void* stream);
+int dh_color_forward_ex(int arithmetic, const float* packed, const float* pts, const float* dirs, int n_per_ray, const float* normals,
+                        int64_t npts, float* ws, float* color, int save, void* stream);
+int dh_mlp_backward_ex(int arithmetic, const float* packed, const float* params, const float* pts, int64_t npts, float* ws,
+                       const float* colors, const float* d_sdf, float* d_normals, const float* d_colors, float* grad_flat,
+                       void* stream);
+int dh_color_backward_ex(int arithmetic, const float* packed, const float* colors, const float* d_colors, int64_t npts, float* ws,
+                         float* d_normals, void* stream);
+int dh_sdf_tangent_ex(int arithmetic, const float* packed, const float* pts, const float* d_normals, int64_t npts, float* ws,
+                      void* stream);
+int dh_sdf_backward_ex(int arithmetic, const float* packed, const float* d_sdf, int64_t npts, float* ws, void* stream);
+int dh_color_backward_rays_ex(int arithmetic, const float* packed, const float* colors, const float* d_colors, const float* dirs,
+                              int n_per_ray, int64_t npts, float* ws, float* d_normals, float* d_pts, float* d_dirs_pts, void* stream);
+int dh_sdf_backward_rays_ex(int arithmetic, const float* packed, const float* d_sdf, const float* pts, const float* d_normals,
+                            int64_t npts, float* ws, float* d_pts, void* stream);
+int dh_weight_grads_gemm_ex(int arithmetic, int64_t npts, float* ws, void* stream);
 
 /* ---- per-ray stages ---------------------------------------------------------------------------------------
  * Mask-conditioned ray generation = upstream Dataset.gen_random_rays_at + near_far_from_sphere (App. A.8) under the
