@@ -119,7 +119,9 @@ def main():
     ap.add_argument("--frames", type=int, default=64)
     ap.add_argument("--family", choices=["neus", "hash"], default="neus",
                     help="neus = BASELINE.json configs[1] (the headline); hash = configs[3] (hash-grid encoding + shallow MLPs)")
-    ap.add_argument("--arithmetic", choices=["split_bf16", "fp32_mfma"], default="split_bf16")
+    ap.add_argument("--arithmetic", choices=["split_f16", "split_bf16", "fp32_mfma"], default="split_f16",
+                    help="split_f16 = two fp16 pieces / three MFMA products per fp32 product (shipping); split_bf16 = three bf16 "
+                         "pieces / six products (rounds 1-3); fp32_mfma = the native fp32-MFMA twins")
     ap.add_argument("--loss", choices=["cfg2", "full"], default="cfg2",
                     help="cfg2 = rgb + eikonal + mask + mono-normal (the headline config); full = BASELINE.json configs[4]'s loss "
                          "stack: additionally the dense-correspondence reprojection term on a quarter of the rays")
@@ -181,8 +183,7 @@ def main():
 
     from dynhor_amd import _lib
     from dynhor_amd.runner import Runner
-    arith = _lib.ARITH_FP32_MFMA if args.arithmetic == "fp32_mfma" else _lib.ARITH_SPLIT_BF16
-    _lib.set_arithmetic(arith)
+    arith = _lib.ARITH_NAMES[args.arithmetic]
     hash_family = args.family == "hash"
     full = args.loss == "full"
     conf = {"seq_name": "bench_synth", "exp_name": f"r{rank}",
@@ -190,7 +191,7 @@ def main():
                                         "correspondences": 2048 if full else 0}},
             "train": {"batch_size": args.rays_per_rank, "normal_weight": 0.05, "report_freq": 10 ** 9, "save_freq": 10 ** 9,
                       "val_freq": 0, "corr_weight": 0.1 if full else 0.0, "corr_fraction": 0.25},
-            "model": {"family": args.family, "hash_renderer": {"sampler": args.hash_sampler}}}
+            "model": {"family": args.family, "arithmetic": args.arithmetic, "hash_renderer": {"sampler": args.hash_sampler}}}
     runner = Runner(conf=conf, device=device, exp_root=os.path.join("/tmp", "dynhor_bench_exps"))
     B = runner.batch_size
     n_samples = runner.renderer.n_samples + runner.renderer.n_importance
@@ -335,17 +336,20 @@ def main():
             # peak of the dominant kernel's own instruction mix: every GEMM runs each fp32 product as 6 bf16 products (3-way
             # split of both operands, fp32 accumulate: 2^-24 relative) on v_mfma_f32_32x32x16_bf16, so the ceiling in
             # ALGORITHMIC (fp32-product) FLOP/s is the dense bf16 peak / 6; fp32_mfma runs v_mfma_f32_32x32x2_f32 (157.3 TFLOP/s)
-            split = arith == _lib.ARITH_SPLIT_BF16
-            peak = BF16_MFMA_PEAK_TFLOPS / 6.0 if split else FP32_MFMA_PEAK_TFLOPS
+            split = arith != _lib.ARITH_FP32_MFMA
+            nprod = {_lib.ARITH_SPLIT_F16: 3.0, _lib.ARITH_SPLIT_BF16: 6.0}.get(arith, 1.0)
+            peak = BF16_MFMA_PEAK_TFLOPS / nprod if split else FP32_MFMA_PEAK_TFLOPS
             traffic, tsrc = offline_traffic(dom, names[dom])
             roof = {"bound": "mfma", "kernel": names[dom], "stage": dom, "achieved": per_kernel[dom]["tflops"],
                     "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(per_kernel[dom]["tflops"] / peak, 4),
-                    "peak_basis": ("bf16 dense MFMA 2500 TFLOP/s / 6 split products per fp32 product" if split
+                    "peak_basis": (f"fp16 / bf16 dense MFMA 2500 TFLOP/s / {int(nprod)} split products per fp32 product" if split
                                    else "fp32 MFMA v_mfma_f32_32x32x2_f32"),
+                    "frac_of_six_product_peak": round(per_kernel[dom]["tflops"] / (BF16_MFMA_PEAK_TFLOPS / 6.0), 4),
                     "frac_of_fp32_mfma_peak": round(per_kernel[dom]["tflops"] / FP32_MFMA_PEAK_TFLOPS, 4),
                     "traffic": traffic, "traffic_source": tsrc, "avg_launch_ms": per_kernel[dom]["ms"],
                     "whole_step_tflops": round(value / world * FLOP_PER_RAY_TRAIN / 1e12, 2),
-                    "whole_step_frac_of_split_bf16_peak": round(value / world * FLOP_PER_RAY_TRAIN / 1e12 / (BF16_MFMA_PEAK_TFLOPS / 6.0), 4),
+                    "whole_step_frac_of_peak": round(value / world * FLOP_PER_RAY_TRAIN / 1e12 / peak, 4),
+                    "whole_step_frac_of_six_product_peak": round(value / world * FLOP_PER_RAY_TRAIN / 1e12 / (BF16_MFMA_PEAK_TFLOPS / 6.0), 4),
                     "whole_step_frac_of_fp32_mfma_peak": round(value / world * FLOP_PER_RAY_TRAIN / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4)}
             for k, v in per_kernel.items():
                 if "tflops" in v:
@@ -353,9 +357,12 @@ def main():
                     v["frac_of_peak"] = round(v["tflops"] / peak, 4)
             workload = (f"custom_shoes-shaped synthetic seq, 512x512, {B} rays x (64+64) samples per rank, "
                         "NeuS SDF(8x256, skip 4, softplus100) + colour(4x256) MLP, full training iteration")
-            arithmetic = ("fp32 everywhere, every GEMM on v_mfma_f32_32x32x2_f32 (--arithmetic fp32_mfma)" if not split else
-                          "fp32 in / fp32 out everywhere; GEMMs as 3-way bf16 split of both operands (6 MFMA "
-                          "products, fp32 accumulate: 2^-24 relative = fp32 accuracy)")
+            arithmetic = {"fp32_mfma": "fp32 everywhere, every GEMM on v_mfma_f32_32x32x2_f32 (--arithmetic fp32_mfma)",
+                          "split_bf16": "fp32 in / fp32 out everywhere; GEMMs as 3-way bf16 split of both operands (6 MFMA "
+                                        "products, fp32 accumulate: 2^-24 relative = fp32 accuracy; --arithmetic split_bf16)",
+                          "split_f16": "fp32 in / fp32 out everywhere; GEMMs as 2-way fp16 split of both operands scaled by powers of two "
+                                       "(3 MFMA products, fp32 accumulate: fp32 accuracy, measured 1.9e-7 vs fp64 against 2.3e-7 for "
+                                       "the exact fp32 MFMA)"}[args.arithmetic]
         out = {"metric": "training rays/sec", "value": round(value, 1), "unit": "rays/s", "n_gpus": world,
                "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
                "scaling": "weak" if args.rays_per_rank == 2048 else "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",

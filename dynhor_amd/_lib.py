@@ -21,6 +21,7 @@ SIGNATURES = {
     "dh_packed_floats": (_i64, []),
     "dh_param_layout": (_i32, [_i32, _i32, ctypes.POINTER(_i64), ctypes.POINTER(_i64), ctypes.POINTER(_i64),
                                ctypes.POINTER(_i32), ctypes.POINTER(_i32)]),
+    "dh_packed_section": (_i32, [_i32, ctypes.POINTER(_i64), ctypes.POINTER(_i64)]),
     "dh_pack_weights": (_i32, [_vp, _vp, _vp]),
     "dh_sdf_nograd": (_i32, [_vp, _vp, _i64, _vp, _vp]),
     "dh_workspace_floats": (_i32, [_i64, ctypes.POINTER(_i64), ctypes.POINTER(_i64), ctypes.POINTER(_i64)]),
@@ -163,6 +164,13 @@ def param_layout(net: int, layer: int):
     check(lib().dh_param_layout(net, layer, ctypes.byref(b), ctypes.byref(g), ctypes.byref(v),
                                 ctypes.byref(o), ctypes.byref(i)))
     return b.value, g.value, v.value, o.value, i.value
+
+
+def packed_section(section: int):
+    """(float offset, float count) of a section of the packed weight buffer (dh_packed_section)."""
+    o, n = _i64(), _i64()
+    check(lib().dh_packed_section(int(section), ctypes.byref(o), ctypes.byref(n)))
+    return o.value, n.value
 
 
 def workspace_floats(npts: int):

@@ -51,6 +51,19 @@ const char* dh_strerror(int status) {
 int64_t dh_num_params(void) { return N_PARAMS; }
 int64_t dh_packed_floats(void) { return PACKH.total; }
 
+int dh_packed_section(int section, int64_t* offset_floats, int64_t* n_floats) {
+    if (!offset_floats || !n_floats) return DH_ERR_BAD_ARG;
+    switch (section) {
+        case 0: *offset_floats = PACKT.stream; *n_floats = PACKT_STREAM_FLOATS; break;
+        case 1: *offset_floats = PACKT.bias10; *n_floats = 10 * 256; break;
+        case 2: *offset_floats = PACKH.stream; *n_floats = PACKTH_STREAM_FLOATS; break;
+        case 3: *offset_floats = PACKH.bias11; *n_floats = 11 * 256; break;
+        case 4: *offset_floats = PACKH.wabs; *n_floats = 16; break;
+        default: return DH_ERR_BAD_ARG;
+    }
+    return DH_OK;
+}
+
 int dh_param_layout(int net, int layer, int64_t* bias_off, int64_t* g_off, int64_t* v_off, int* out_dim, int* in_dim) {
     if (!bias_off || !g_off || !v_off || !out_dim || !in_dim) return DH_ERR_BAD_ARG;
     if (net == 0) {

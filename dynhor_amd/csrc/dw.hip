@@ -17,7 +17,9 @@ struct DwJob {
     const float* A2; const float* B2;      // optional second (A,B) pair accumulated into the same output
     int64_t off;                           // float offset of this job's [256 x nb*32] slab inside a split's slab block
     int nb;                                // 8: B is a main native tile; 2: B is an aux native tile
-    int sa1, sb1, sa2, sb2;                // two-piece fp16 kernel: the operands' workspace.h absmax class (-1: the constant H2_XS)
+    // two-piece fp16 kernel, per operand pair: the operands' workspace.h absmax class (launch-wide maximum; -1: the constant
+    // H2_XS) and, for the ONE heavy-tailed operand of the pair, its tmax class (per-tile maxima; -1: this operand is not the one)
+    int ca[2], cb[2], ha[2], hb[2];
 };
 struct DwJobs { DwJob j[16]; int n; };
 // Job groups (round 3): the persistent workgroups are dealt to DW_GROUPS groups of consecutive jobs, group k getting a share of
@@ -357,16 +359,36 @@ __device__ __forceinline__ void dw_body_pieces(const DwJob& J, int64_t t0, int64
 
 // ---------------------------------------------------------------- two-piece fp16 variant (DH_ARITH_SPLIT_F16; tile16h.h)
 // dw_body_pieces with two fp16 pieces per value and three products: 24 MFMAs per wave and k-pair instead of 48, a 32 KiB piece
-// image per k-pair instead of 48.  Operand scales: every operand class has ONE power-of-two scale per launch -- from the class's
-// per-launch maximum that the kernels writing the tiles posted (workspace.h absmax; scaled maximum in [256, 512)), or the constant
-// H2_XS for softplus outputs and embeddings -- applied as the raw values are split.  A job with two operand pairs runs pair 0 over
-// all its tiles first; at the change-over the accumulators are multiplied by the ratio of the two pairs' scale products (a power
-// of two: exact), and the slab is written divided by the last pair's.
+// image per k-pair instead of 48.  Operand scales (powers of two, applied as the raw values are split).  Every operand pair has
+// one heavy-tailed operand X (an adjoint or a tangent: a few sample points near the surface carry almost everything) and one
+// tame operand Y (activations, embeddings, reverse-chain values).  X is scaled tile by tile from the tile's own maximum (workspace.h
+// tmax: scaled maximum in [256, 512)) -- one launch-wide scale, set by one outlier, would push the typical tile into fp16's
+// subnormals (measured: 1.7e-4 on the gradient).  Y is scaled by its class scale (launch-wide maximum, workspace.h absmax, or the
+// constant H2_XS) TIMES S_X(launch) / S_X(tile) <= 1, so every product carries the same S_X(launch) S_Y; what Y loses below fp16's
+// range in a tile whose X is small is bounded by 2^-33 of the dominant tiles' products, well under the fp32 accumulator's own
+// rounding.  A job with two operand pairs runs pair 0 over all its tiles first; at the change-over the accumulators are
+// multiplied by the ratio of the two pairs' scale products (exact), and the slab is written divided by the last pair's.
 constexpr int DWH_TILE = 2 * 1024;
 constexpr int DWH_BUF = 16 * DWH_TILE;
-struct DwScales { float a[2], b[2]; };
+// per pair (plain scalars, selected with ?: -- an array indexed by the run-time pair number goes to scratch and turns the tile
+// maximum's load into a flat load): prod = S_X(launch) S_Y, also the tame operand's scale before the per-tile division; xt = the
+// heavy operand's per-tile maxima; heavy_a: X is A
+struct DwScales { float prod0, prod1; const unsigned* xt0; const unsigned* xt1; bool heavy_a0, heavy_a1; };
 __device__ __forceinline__ float dw_class_scale(const unsigned* __restrict__ absmax, int cls) {
     return cls < 0 ? H2_XS : __builtin_bit_cast(float, pow2_scale_bits(absmax[cls * ABSMAX_STRIDE], H2_AT));
+}
+__device__ __forceinline__ DwScales dw_job_scales(const DwJob& J, const unsigned* __restrict__ absmax, const unsigned* __restrict__ tmax,
+                                                  int64_t ntiles) {
+    DwScales s;
+    auto one = [&](int i, float& prod, const unsigned*& xt, bool& heavy_a) {
+        heavy_a = J.ha[i] >= 0;
+        const int hx = heavy_a ? J.ha[i] : J.hb[i];
+        xt = tmax + (int64_t)(hx < 0 ? 0 : hx) * ntiles;
+        prod = dw_class_scale(absmax, J.ca[i]) * dw_class_scale(absmax, J.cb[i]);
+    };
+    one(0, s.prod0, s.xt0, s.heavy_a0);
+    one(1, s.prod1, s.xt1, s.heavy_a1);
+    return s;
 }
 template <int I, int JB>
 __device__ __forceinline__ void dw_half_steps_h(f32x16 (&acc)[2][4], const H2 (&a)[2], const H2 (&b)[2], H2 (&pc)[MT],
@@ -402,7 +424,13 @@ __device__ __forceinline__ void dw_body_pieces_h(const DwJob& J, const DwScales&
     auto load = [&](Raw& r) {
         const float* A = ld_pair ? J.A2 : J.A1;
         const float* Bm = ld_pair ? J.B2 : J.B1;
-        r.sa = sc.a[ld_pair]; r.sb = sc.b[ld_pair];
+        {   // the tile's scales: X by its own maximum, Y by prod / S_X(tile)   (wave-uniform: scalar load + a few scalar ops)
+            const unsigned sxb = pow2_scale_bits((ld_pair ? sc.xt1 : sc.xt0)[ld_tile], H2_AT);
+            const float sx = __builtin_bit_cast(float, sxb), sy = (ld_pair ? sc.prod1 : sc.prod0) * __builtin_bit_cast(float, pow2_inv_bits(sxb));
+            const bool ha = ld_pair ? sc.heavy_a1 : sc.heavy_a0;
+            r.sa = ha ? sx : sy;
+            r.sb = ha ? sy : sx;
+        }
         const int kq = 2 * ld_kp, m = kq >> 2, r4 = kq & 3;
         const f32x4* ga = reinterpret_cast<const f32x4*>(A + ld_tile * TILE_F) + ((((wave >> 1) * MT + m) * 2 + (wave & 1)) * 4 + r4) * 64 + lane;
         r.a0 = __builtin_nontemporal_load(ga); r.a1 = __builtin_nontemporal_load(ga + 64);
@@ -489,7 +517,7 @@ __device__ __forceinline__ void dw_body_pieces_h(const DwJob& J, const DwScales&
             __builtin_amdgcn_sched_barrier(0);
             __syncthreads();
         };
-        const float ratio = npairs == 2 ? (sc.a[1] * sc.b[1]) / (sc.a[0] * sc.b[0]) : 1.f;       // powers of two: exact
+        const float ratio = npairs == 2 ? sc.prod1 / sc.prod0 : 1.f;       // powers of two: exact
         int p = 0;
         for (; p + 1 < NP; p += 2) {
             if (npairs == 2 && p == NP1) {               // NP1 is even: the change-over falls on a step(0) boundary
@@ -500,7 +528,7 @@ __device__ __forceinline__ void dw_body_pieces_h(const DwJob& J, const DwScales&
         }
         if (p < NP) step(0, r1);
     }
-    const float inv = 1.f / (sc.a[npairs - 1] * sc.b[npairs - 1]);
+    const float inv = 1.f / (npairs == 2 ? sc.prod1 : sc.prod0);
     DH_UNROLL for (int i = 0; i < NA; ++i)
         DH_UNROLL for (int j = 0; j < NBW; ++j) {
             const int ot = (NB == 8) ? ((wave >> 1) * 2 + i) : wave;
@@ -511,7 +539,8 @@ __device__ __forceinline__ void dw_body_pieces_h(const DwJob& J, const DwScales&
 }
 
 __global__ __launch_bounds__(512, 1) void dw_f16x2_kernel(DwJobs jobs, DwGroups groups, int64_t ntiles, float* __restrict__ slabs,
-                                                          int64_t gstride, const unsigned* __restrict__ absmax) {
+                                                          int64_t gstride, const unsigned* __restrict__ absmax,
+                                                          const unsigned* __restrict__ tmax) {
     __shared__ __attribute__((aligned(16))) char pieces[2 * DWH_BUF];
     const int g = blockIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -520,9 +549,7 @@ __global__ __launch_bounds__(512, 1) void dw_f16x2_kernel(DwJobs jobs, DwGroups 
     float* base = slabs + (int64_t)g * gstride;
     for (int job = groups.job0[k]; job < groups.job0[k + 1]; ++job) {
         const DwJob J = jobs.j[job];
-        DwScales sc;
-        sc.a[0] = dw_class_scale(absmax, J.sa1); sc.b[0] = dw_class_scale(absmax, J.sb1);
-        sc.a[1] = dw_class_scale(absmax, J.sa2); sc.b[1] = dw_class_scale(absmax, J.sb2);
+        const DwScales sc = dw_job_scales(J, absmax, tmax, ntiles);
         if (J.nb == 8) dw_body_pieces_h<8>(J, sc, t0, t1, base + J.off, wave, lane, pieces);
         else dw_body_pieces_h<2>(J, sc, t0, t1, base + J.off, wave, lane, pieces);
     }
@@ -710,25 +737,27 @@ static void build_dw_jobs(const Workspace& w, float* red, DwJobs& J, SlabPtrs& S
     for (int j = 0; j < 15; ++j) { J.j[j].nb = DW_NBS[j]; J.j[j].off = off; S.out[j] = red + off; S.nb[j] = DW_NBS[j]; off += (int64_t)8 * DW_NBS[j] * 1024; }
     J.n = 15;
     auto T_ = [&](float* base, int idx) { return base + (int64_t)idx * nt * TILE_F; };
-    auto C_ = [&](int j, int sa1, int sb1, int sa2, int sb2) { J.j[j].sa1 = sa1; J.j[j].sb1 = sb1; J.j[j].sa2 = sa2; J.j[j].sb2 = sb2; };
+    // operand classes of the two-piece fp16 kernel: (absmax class, tmax class) of A and B for each pair
+    auto C_ = [&](int j, int i, int ca, int ha, int cb, int hb) { J.j[j].ca[i] = ca; J.j[j].ha[i] = ha; J.j[j].cb[i] = cb; J.j[j].hb[i] = hb; };
+    for (int j = 0; j < 15; ++j) { C_(j, 0, -1, -1, -1, -1); C_(j, 1, -1, -1, -1, -1); }
     J.j[0].A1 = T_(w.zbar, 0); J.j[0].B1 = w.eaux; J.j[0].A2 = T_(w.asave, 0); J.j[0].B2 = w.t0aux;
-    C_(0, ABSMAX_ZBAR + 0, -1, ABSMAX_ASAVE + 0, ABSMAX_T0AUX);
+    C_(0, 0, ABSMAX_ZBAR + 0, TMAX_ZBAR + 0, -1, -1); C_(0, 1, ABSMAX_ASAVE + 0, -1, ABSMAX_T0AUX, TMAX_T0AUX);
     for (int l = 1; l <= 7; ++l) {
         J.j[l].A1 = T_(w.zbar, l); J.j[l].B1 = T_(w.act, l - 1);
         J.j[l].A2 = T_(w.asave, l); J.j[l].B2 = T_(w.tsave, l - 1);
-        C_(l, ABSMAX_ZBAR + l, -1, ABSMAX_ASAVE + l, ABSMAX_TSAVE + l - 1);
+        C_(l, 0, ABSMAX_ZBAR + l, TMAX_ZBAR + l, -1, -1); C_(l, 1, ABSMAX_ASAVE + l, -1, ABSMAX_TSAVE + l - 1, TMAX_TSAVE + l - 1);
     }
     J.j[8].A1 = T_(w.zbar, 4); J.j[8].B1 = w.eaux; J.j[8].A2 = T_(w.asave, 4); J.j[8].B2 = w.t0aux;
-    C_(8, ABSMAX_ZBAR + 4, -1, ABSMAX_ASAVE + 4, ABSMAX_T0AUX);
+    C_(8, 0, ABSMAX_ZBAR + 4, TMAX_ZBAR + 4, -1, -1); C_(8, 1, ABSMAX_ASAVE + 4, -1, ABSMAX_T0AUX, TMAX_T0AUX);
     J.j[9].A1 = w.featbar; J.j[9].B1 = T_(w.act, 7); J.j[9].A2 = nullptr; J.j[9].B2 = nullptr;
-    C_(9, ABSMAX_FEATBAR, -1, -1, -1);
+    C_(9, 0, ABSMAX_FEATBAR, TMAX_FEATBAR, -1, -1);
     J.j[10].A1 = T_(w.czbar, 0); J.j[10].B1 = w.feat; J.j[10].A2 = nullptr; J.j[10].B2 = nullptr;
-    C_(10, ABSMAX_CZBAR + 0, ABSMAX_FEAT, -1, -1);
+    C_(10, 0, ABSMAX_CZBAR + 0, TMAX_CZBAR + 0, ABSMAX_FEAT, -1);
     J.j[11].A1 = T_(w.czbar, 0); J.j[11].B1 = w.caux; J.j[11].A2 = nullptr; J.j[11].B2 = nullptr;
-    C_(11, ABSMAX_CZBAR + 0, -1, -1, -1);
+    C_(11, 0, ABSMAX_CZBAR + 0, TMAX_CZBAR + 0, -1, -1);
     for (int l = 1; l <= 3; ++l) {
         J.j[11 + l].A1 = T_(w.czbar, l); J.j[11 + l].B1 = T_(w.cact, l - 1); J.j[11 + l].A2 = nullptr; J.j[11 + l].B2 = nullptr;
-        C_(11 + l, ABSMAX_CZBAR + l, ABSMAX_CACT + l - 1, -1, -1);
+        C_(11 + l, 0, ABSMAX_CZBAR + l, TMAX_CZBAR + l, ABSMAX_CACT + l - 1, -1);
     }
 }
 
@@ -775,7 +804,7 @@ int launch_weight_grads_gemm(const Workspace& w, float* slabs, int G, int arith,
     const DwGroups Gp = build_dw_groups(J, G);
     if (arith == ARITH_FP32) hipLaunchKernelGGL(dw_lds_kernel, dim3(G), dim3(512), 0, st, J, Gp, w.ntiles, slabs, gstride);
     else if (arith == ARITH_F16) hipLaunchKernelGGL(dw_f16x2_kernel, dim3(G), dim3(512), 0, st, J, Gp, w.ntiles, slabs, gstride,
-                                                    reinterpret_cast<const unsigned*>(w.absmax));
+                                                    reinterpret_cast<const unsigned*>(w.absmax), reinterpret_cast<const unsigned*>(w.tmax));
     else hipLaunchKernelGGL(dw_bf16x3_kernel, dim3(G), dim3(512), 0, st, J, Gp, w.ntiles, slabs, gstride);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }

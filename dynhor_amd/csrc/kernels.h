@@ -35,13 +35,13 @@ int launch_color_fwd_h(const float* packed, const float* pts, const float* dirs,
                        int grid, hipStream_t stream);
 int launch_color_bwd_h(const float* packed, const float* colors, const float* d_colors, const float* dirs, int n_per_ray,
                        int64_t npts, const float* cact, float* czbar, float* featbar, float* d_normals, float* tpart,
-                       float* d_pts, float* d_dirs_pts, unsigned* absmax, int grid, hipStream_t st);
+                       float* d_pts, float* d_dirs_pts, unsigned* absmax, unsigned* tmax, int grid, hipStream_t st);
 int launch_sdf_tangent_h(const float* packed, const float* pts, const float* d_normals, int64_t npts, const float* act,
-                         const float* asave, float* t0aux, float* tsave, float* rsave, float* tpart, unsigned* absmax, int grid,
-                         hipStream_t st);
+                         const float* asave, float* t0aux, float* tsave, float* rsave, float* tpart, unsigned* absmax, unsigned* tmax,
+                         int grid, hipStream_t st);
 int launch_sdf_bwd_h(const float* packed, const float* d_sdf, const float* pts, const float* d_normals, int64_t npts,
                      const float* act, const float* rsave, const float* featbar, const float* gesave, float* zbar, float* tpart,
-                     float* d_pts, unsigned* absmax, int grid, hipStream_t st);
+                     float* d_pts, unsigned* absmax, unsigned* tmax, int grid, hipStream_t st);
 
 // per-ray kernels (kernels_ray.hip)
 int launch_gen_rays(const uint8_t* rgb, const int8_t* label, const uint8_t* normal, const float* R, const float* T,

@@ -682,7 +682,7 @@ static inline int grid_for(int64_t npts, int grid) {
 int launch_color_bwd(const float* packed, const float* colors, const float* d_colors, int64_t npts, const float* cact,
                      float* czbar, float* featbar, float* d_normals, float* tpart, float* absmax, int grid, int arith, hipStream_t st) {
     if (arith == ARITH_F16) return launch_color_bwd_h(packed, colors, d_colors, nullptr, 1, npts, cact, czbar, featbar, d_normals, tpart, nullptr,
-                                                     nullptr, reinterpret_cast<unsigned*>(absmax), grid, st);
+                                                     nullptr, reinterpret_cast<unsigned*>(absmax), reinterpret_cast<unsigned*>(absmax) + ABSMAX_FLOATS, grid, st);
     if (arith == ARITH_FP32) hipLaunchKernelGGL(color_bwd_kernel<false>, dim3(grid_for(npts, grid)), dim3(256), 0, st, make_col_ptrs(packed), colors,
                                                 d_colors, npts, cact, czbar, featbar, d_normals, tpart, nullptr, 1, nullptr, nullptr);
     else hipLaunchKernelGGL(color_bwd_s_kernel<false>, dim3(grid_for(npts, grid)), dim3(256), 0, st, make_col16_ptrs(packed), colors,
@@ -693,7 +693,7 @@ int launch_color_bwd_rays(const float* packed, const float* colors, const float*
                           int64_t npts, const float* cact, float* czbar, float* featbar, float* d_normals, float* tpart,
                           float* d_pts, float* d_dirs_pts, float* absmax, int grid, int arith, hipStream_t st) {
     if (arith == ARITH_F16) return launch_color_bwd_h(packed, colors, d_colors, dirs, n_per_ray, npts, cact, czbar, featbar, d_normals, tpart, d_pts,
-                                                     d_dirs_pts, reinterpret_cast<unsigned*>(absmax), grid, st);
+                                                     d_dirs_pts, reinterpret_cast<unsigned*>(absmax), reinterpret_cast<unsigned*>(absmax) + ABSMAX_FLOATS, grid, st);
     if (arith == ARITH_FP32) hipLaunchKernelGGL(color_bwd_kernel<true>, dim3(grid_for(npts, grid)), dim3(256), 0, st, make_col_ptrs(packed), colors,
                                                 d_colors, npts, cact, czbar, featbar, d_normals, tpart, dirs, n_per_ray, d_pts, d_dirs_pts);
     else hipLaunchKernelGGL(color_bwd_s_kernel<true>, dim3(grid_for(npts, grid)), dim3(256), 0, st, make_col16_ptrs(packed), colors,
@@ -704,7 +704,7 @@ int launch_sdf_tangent(const float* packed, const float* pts, const float* d_nor
                        const float* asave, float* t0aux, float* tsave, float* rsave, float* tpart, float* absmax, int grid, int arith,
                        hipStream_t st) {
     if (arith == ARITH_F16) return launch_sdf_tangent_h(packed, pts, d_normals, npts, act, asave, t0aux, tsave, rsave, tpart,
-                                                       reinterpret_cast<unsigned*>(absmax), grid, st);
+                                                       reinterpret_cast<unsigned*>(absmax), reinterpret_cast<unsigned*>(absmax) + ABSMAX_FLOATS, grid, st);
     if (arith == ARITH_FP32) hipLaunchKernelGGL(sdf_tangent_kernel, dim3(grid_for(npts, grid)), dim3(256), 0, st, make_sdf_ptrs(packed), pts,
                                                 d_normals, npts, act, asave, t0aux, tsave, rsave, tpart);
     else hipLaunchKernelGGL(sdf_tangent_s_kernel, dim3(grid_for(npts, grid)), dim3(256), 0, st, make_sdf16_ptrs(packed), pts, d_normals,
@@ -714,7 +714,7 @@ int launch_sdf_tangent(const float* packed, const float* pts, const float* d_nor
 int launch_sdf_bwd(const float* packed, const float* d_sdf, int64_t npts, const float* act, const float* rsave,
                    const float* featbar, float* zbar, float* tpart, float* absmax, int grid, int arith, hipStream_t st) {
     if (arith == ARITH_F16) return launch_sdf_bwd_h(packed, d_sdf, nullptr, nullptr, npts, act, rsave, featbar, nullptr, zbar, tpart, nullptr,
-                                                   reinterpret_cast<unsigned*>(absmax), grid, st);
+                                                   reinterpret_cast<unsigned*>(absmax), reinterpret_cast<unsigned*>(absmax) + ABSMAX_FLOATS, grid, st);
     if (arith == ARITH_FP32) hipLaunchKernelGGL(sdf_bwd_kernel<false>, dim3(grid_for(npts, grid)), dim3(256), 0, st, make_sdf_ptrs(packed), d_sdf, npts,
                                                 act, rsave, featbar, zbar, tpart, nullptr, nullptr, nullptr, nullptr);
     else hipLaunchKernelGGL(sdf_bwd_s_kernel<false>, dim3(grid_for(npts, grid)), dim3(256), 0, st, make_sdf16_ptrs(packed), d_sdf, npts,
@@ -725,7 +725,7 @@ int launch_sdf_bwd_rays(const float* packed, const float* d_sdf, const float* pt
                         const float* act, const float* rsave, const float* featbar, const float* gesave, float* zbar,
                         float* tpart, float* d_pts, float* absmax, int grid, int arith, hipStream_t st) {
     if (arith == ARITH_F16) return launch_sdf_bwd_h(packed, d_sdf, pts, d_normals, npts, act, rsave, featbar, gesave, zbar, tpart, d_pts,
-                                                   reinterpret_cast<unsigned*>(absmax), grid, st);
+                                                   reinterpret_cast<unsigned*>(absmax), reinterpret_cast<unsigned*>(absmax) + ABSMAX_FLOATS, grid, st);
     if (arith == ARITH_FP32) hipLaunchKernelGGL(sdf_bwd_kernel<true>, dim3(grid_for(npts, grid)), dim3(256), 0, st, make_sdf_ptrs(packed), d_sdf, npts,
                                                 act, rsave, featbar, zbar, tpart, pts, d_normals, gesave, d_pts);
     else hipLaunchKernelGGL(sdf_bwd_s_kernel<true>, dim3(grid_for(npts, grid)), dim3(256), 0, st, make_sdf16_ptrs(packed), d_sdf, npts, act,

@@ -77,12 +77,17 @@ __device__ __forceinline__ void hs_init(HScratch& h, int tid) { if (tid < 12) h.
 // the image hand-off of every layer: publish this wave's maximum, wait until every wave has left the previous image, derive the
 // tile's scale, write the scaled image.  Returns the scale (S, 1 / S).
 // extra_max / extra_lds: a second operand that will share the accumulator (and hence the scale) of the GEMM that reads this image
+// tslot: where this tile's maximum goes for the weight-gradient kernel (workspace.h tmax), or nullptr
 __device__ __forceinline__ TileScale lds_handoff(const f32x16 (&acc)[MT][2], float* smain, HScratch& hs, float* lmax, int tid,
-                                                 int wave, int lane, float extra_max = 0.f, const float* extra_lds = nullptr) {
+                                                 int wave, int lane, float extra_max = 0.f, const float* extra_lds = nullptr,
+                                                 unsigned* tslot = nullptr) {
     tile_max_publish(hs.sred, wave, lane, acc_absmax(acc));
     __syncthreads();
     const float m = tile_max_read(hs.sred);
-    if (lmax && tid == 0) *lmax = fmaxf(*lmax, m);
+    if (tid == 0) {
+        if (lmax) *lmax = fmaxf(*lmax, m);
+        if (tslot) *tslot = __builtin_bit_cast(unsigned, m);
+    }
     if (extra_lds) extra_max = fmaxf(extra_max, *extra_lds);
     const TileScale ts = scale_for_max(fmaxf(m, extra_max));
     acc_to_lds_scaled(acc, smain, wave, lane, ts.S);
@@ -254,7 +259,8 @@ __global__ __launch_bounds__(256, 2) void color_bwd_h_kernel(ColHPtrs C, const f
                                                             float* __restrict__ featbar, float* __restrict__ d_normals,
                                                             float* __restrict__ tpart, const float* __restrict__ dirs,
                                                             int n_per_ray, float* __restrict__ d_pts,
-                                                            float* __restrict__ d_dirs_pts, unsigned* __restrict__ absmax) {
+                                                            float* __restrict__ d_dirs_pts, unsigned* __restrict__ absmax,
+                                                            unsigned* __restrict__ tmax) {
     __shared__ __attribute__((aligned(16))) float smain[TM * LDX];
     __shared__ __attribute__((aligned(16))) float saux[TM * LDA];     // scratch: craw [128][4]
     __shared__ HScratch hs;
@@ -305,7 +311,7 @@ __global__ __launch_bounds__(256, 2) void color_bwd_h_kernel(ColHPtrs C, const f
         }
         acc_store_native(acc, czbar + ((int64_t)3 * ntiles + tile) * TILE_F, wave, lane);
         tile_colsum(acc, tp + (TP_COL_B0 + 3) * 256, wave, lane);
-        TileScale ts = lds_handoff(acc, smain, hs, &hs.lmax[3], tid, wave, lane);
+        TileScale ts = lds_handoff(acc, smain, hs, &hs.lmax[3], tid, wave, lane, 0.f, nullptr, tmax + (TMAX_CZBAR + 3) * ntiles + tile);
         for (int l = 3; l >= 1; --l) {
             acc_zero(acc);
             gemm_rows_h(acc, smain, LDX, 16, C.rev[l], wave, lane);                        // hbar_l = zbar_l W_l
@@ -322,7 +328,7 @@ __global__ __launch_bounds__(256, 2) void color_bwd_h_kernel(ColHPtrs C, const f
             }
             acc_store_native(acc, czbar + ((int64_t)(l - 1) * ntiles + tile) * TILE_F, wave, lane);
             tile_colsum(acc, tp + (TP_COL_B0 + l - 1) * 256, wave, lane);
-            ts = lds_handoff(acc, smain, hs, &hs.lmax[l - 1], tid, wave, lane);
+            ts = lds_handoff(acc, smain, hs, &hs.lmax[l - 1], tid, wave, lane, 0.f, nullptr, tmax + (TMAX_CZBAR + l - 1) * ntiles + tile);
         }
         // lin0: featbar = zbar_0 W0[:,33:] ; extras adjoint = zbar_0 W0[:,:33] (only the normal columns 30..32 matter)
         const float inv0 = ts.inv * winv_from_bits(C.wabs[0]);
@@ -330,10 +336,7 @@ __global__ __launch_bounds__(256, 2) void color_bwd_h_kernel(ColHPtrs C, const f
         gemm_rows_h(acc, smain, LDX, 16, C.rev[0], wave, lane);
         acc_map(acc, [&](int, int, int, float v) { return v * inv0; });
         acc_store_native(acc, featbar + tile * TILE_F, wave, lane);
-        {
-            const float m = acc_absmax(acc);
-            if (lane == 0) atomicMax(reinterpret_cast<unsigned*>(&hs.lmax[4]), __builtin_bit_cast(unsigned, m));     // LDS atomic: four waves
-        }
+        tile_max_publish(hs.sred2, wave, lane, acc_absmax(acc));       // featbar's maxima: read behind the barrier that ends the tile
         f32x16 a2[AUX_NTW];
         aux_zero(a2);
         gemm_auxout_h(a2, smain, 16, C.revaux, wave, lane);
@@ -377,6 +380,11 @@ __global__ __launch_bounds__(256, 2) void color_bwd_h_kernel(ColHPtrs C, const f
             }
         }
         __syncthreads();
+        if (tid == 0) {                                  // (sred2: the next write to it is a whole tile away)
+            const float m = tile_max_read(hs.sred2);
+            hs.lmax[4] = fmaxf(hs.lmax[4], m);
+            tmax[TMAX_FEATBAR * ntiles + tile] = __builtin_bit_cast(unsigned, m);
+        }
     }
     if (absmax) {
         if (tid < 4) post_class_max(absmax, ABSMAX_CZBAR + tid, hs.lmax[tid]);
@@ -390,7 +398,7 @@ __global__ __launch_bounds__(256, 2) void sdf_tangent_h_kernel(SdfHPtrs P, const
                                                               const float* __restrict__ act, const float* __restrict__ asave,
                                                               float* __restrict__ t0aux, float* __restrict__ tsave,
                                                               float* __restrict__ rsave, float* __restrict__ tpart,
-                                                              unsigned* __restrict__ absmax) {
+                                                              unsigned* __restrict__ absmax, unsigned* __restrict__ tmax) {
     __shared__ __attribute__((aligned(16))) float smain[TM * LDX];
     __shared__ __attribute__((aligned(16))) float saux[TM * LDA];
     __shared__ HScratch hs;
@@ -425,7 +433,7 @@ __global__ __launch_bounds__(256, 2) void sdf_tangent_h_kernel(SdfHPtrs P, const
         }
         __syncthreads();
         const float m_aux = tile_max_read(hs.sred2);                 // max |t_0| of the tile
-        if (tid == 0) hs.lmax[7] = fmaxf(hs.lmax[7], m_aux);
+        if (tid == 0) { hs.lmax[7] = fmaxf(hs.lmax[7], m_aux); tmax[TMAX_T0AUX * ntiles + tile] = __builtin_bit_cast(unsigned, m_aux); }
         const TileScale ts_aux = scale_for_max(m_aux);
         aux_lds_to_native(saux, t0aux + tile * AUXT_F, wave, lane);
         f32x16 acc[MT][2];
@@ -458,7 +466,7 @@ __global__ __launch_bounds__(256, 2) void sdf_tangent_h_kernel(SdfHPtrs P, const
             }
             if (l < 7) {
                 acc_store_native(acc, tsave + ((int64_t)l * ntiles + tile) * TILE_F, wave, lane);    // t_{l+1}
-                ts = lds_handoff(acc, smain, hs, &hs.lmax[l], tid, wave, lane, l == 3 ? m_aux : 0.f);
+                ts = lds_handoff(acc, smain, hs, &hs.lmax[l], tid, wave, lane, l == 3 ? m_aux : 0.f, nullptr, tmax + (TMAX_TSAVE + l) * ntiles + tile);
             } else {
                 tile_colsum(acc, tp + TP_W8ROW0_T * 256, wave, lane);                                 // colsum t_8
             }
@@ -478,7 +486,8 @@ __global__ __launch_bounds__(256, 2) void sdf_bwd_h_kernel(SdfHPtrs P, const flo
                                                           const float* __restrict__ featbar, float* __restrict__ zbar,
                                                           float* __restrict__ tpart, const float* __restrict__ pts,
                                                           const float* __restrict__ d_normals, const float* __restrict__ gesave,
-                                                          float* __restrict__ d_pts, unsigned* __restrict__ absmax) {
+                                                          float* __restrict__ d_pts, unsigned* __restrict__ absmax,
+                                                          unsigned* __restrict__ tmax) {
     __shared__ __attribute__((aligned(16))) float smain[TM * LDX];
     __shared__ __attribute__((aligned(16))) float saux[TM * LDA];     // scratch: sdfbar [128]
     __shared__ HScratch hs;
@@ -547,7 +556,7 @@ __global__ __launch_bounds__(256, 2) void sdf_bwd_h_kernel(SdfHPtrs P, const flo
             acc_store_native(acc, zbar + ((int64_t)l * ntiles + tile) * TILE_F, wave, lane);
             tile_colsum(acc, tp + (TP_SDF_B0 + l) * 256, wave, lane);
             if (l > 0) {
-                ts = lds_handoff(acc, smain, hs, &hs.lmax[l], tid, wave, lane);
+                ts = lds_handoff(acc, smain, hs, &hs.lmax[l], tid, wave, lane, 0.f, nullptr, tmax + (TMAX_ZBAR + l) * ntiles + tile);
                 const float inv = ts.inv * winv_from_bits(P.wabs[l]);
                 if (RAYS && l == 4) {                                                // skip path -> ebar (true units)
                     gemm_auxout_h(eb, smain, 16, P.revaux[4], wave, lane);
@@ -557,7 +566,7 @@ __global__ __launch_bounds__(256, 2) void sdf_bwd_h_kernel(SdfHPtrs P, const flo
                 gemm_rows_h(acc, smain, LDX, 16, P.rev[l], wave, lane);             // hbar_l = zbar_l W_l
                 acc_map(acc, [&](int, int, int, float v) { return v * inv; });
             } else if (RAYS) {
-                ts = lds_handoff(acc, smain, hs, &hs.lmax[0], tid, wave, lane);      // zbar_0
+                ts = lds_handoff(acc, smain, hs, &hs.lmax[0], tid, wave, lane, 0.f, nullptr, tmax + TMAX_ZBAR * ntiles + tile);      // zbar_0
                 {
                     f32x16 e0[AUX_NTW];
                     aux_zero(e0);
@@ -591,12 +600,16 @@ __global__ __launch_bounds__(256, 2) void sdf_bwd_h_kernel(SdfHPtrs P, const flo
                     }
                 }
             } else {
-                // zbar_0 feeds only the weight-gradient kernel: its class maximum, one LDS atomic per wave
-                const float m = acc_absmax(acc);
-                if (lane == 0) atomicMax(reinterpret_cast<unsigned*>(&hs.lmax[0]), __builtin_bit_cast(unsigned, m));
+                // zbar_0 feeds only the weight-gradient kernel: its maxima, read behind the barrier that ends the tile
+                tile_max_publish(hs.sred2, wave, lane, acc_absmax(acc));
             }
         }
         __syncthreads();
+        if (!RAYS && tid == 0) {                         // (sred2: the next write to it is a whole tile away)
+            const float m = tile_max_read(hs.sred2);
+            hs.lmax[0] = fmaxf(hs.lmax[0], m);
+            tmax[TMAX_ZBAR * ntiles + tile] = __builtin_bit_cast(unsigned, m);
+        }
     }
     if (absmax && tid < 8) post_class_max(absmax, ABSMAX_ZBAR + tid, hs.lmax[tid]);
 }
@@ -622,27 +635,27 @@ int launch_color_fwd_h(const float* packed, const float* pts, const float* dirs,
 }
 int launch_color_bwd_h(const float* packed, const float* colors, const float* d_colors, const float* dirs, int n_per_ray,
                        int64_t npts, const float* cact, float* czbar, float* featbar, float* d_normals, float* tpart,
-                       float* d_pts, float* d_dirs_pts, unsigned* absmax, int grid, hipStream_t st) {
+                       float* d_pts, float* d_dirs_pts, unsigned* absmax, unsigned* tmax, int grid, hipStream_t st) {
     if (d_pts) hipLaunchKernelGGL(color_bwd_h_kernel<true>, dim3(grid_for(npts, grid)), dim3(256), 0, st, make_colh_ptrs(packed), colors,
-                                  d_colors, npts, cact, czbar, featbar, d_normals, tpart, dirs, n_per_ray, d_pts, d_dirs_pts, absmax);
+                                  d_colors, npts, cact, czbar, featbar, d_normals, tpart, dirs, n_per_ray, d_pts, d_dirs_pts, absmax, tmax);
     else hipLaunchKernelGGL(color_bwd_h_kernel<false>, dim3(grid_for(npts, grid)), dim3(256), 0, st, make_colh_ptrs(packed), colors,
-                            d_colors, npts, cact, czbar, featbar, d_normals, tpart, nullptr, 1, nullptr, nullptr, absmax);
+                            d_colors, npts, cact, czbar, featbar, d_normals, tpart, nullptr, 1, nullptr, nullptr, absmax, tmax);
     return ok();
 }
 int launch_sdf_tangent_h(const float* packed, const float* pts, const float* d_normals, int64_t npts, const float* act,
-                         const float* asave, float* t0aux, float* tsave, float* rsave, float* tpart, unsigned* absmax, int grid,
-                         hipStream_t st) {
+                         const float* asave, float* t0aux, float* tsave, float* rsave, float* tpart, unsigned* absmax, unsigned* tmax,
+                         int grid, hipStream_t st) {
     hipLaunchKernelGGL(sdf_tangent_h_kernel, dim3(grid_for(npts, grid)), dim3(256), 0, st, make_sdfh_ptrs(packed), pts, d_normals,
-                       npts, act, asave, t0aux, tsave, rsave, tpart, absmax);
+                       npts, act, asave, t0aux, tsave, rsave, tpart, absmax, tmax);
     return ok();
 }
 int launch_sdf_bwd_h(const float* packed, const float* d_sdf, const float* pts, const float* d_normals, int64_t npts,
                      const float* act, const float* rsave, const float* featbar, const float* gesave, float* zbar, float* tpart,
-                     float* d_pts, unsigned* absmax, int grid, hipStream_t st) {
+                     float* d_pts, unsigned* absmax, unsigned* tmax, int grid, hipStream_t st) {
     if (d_pts) hipLaunchKernelGGL(sdf_bwd_h_kernel<true>, dim3(grid_for(npts, grid)), dim3(256), 0, st, make_sdfh_ptrs(packed), d_sdf, npts,
-                                  act, rsave, featbar, zbar, tpart, pts, d_normals, gesave, d_pts, absmax);
+                                  act, rsave, featbar, zbar, tpart, pts, d_normals, gesave, d_pts, absmax, tmax);
     else hipLaunchKernelGGL(sdf_bwd_h_kernel<false>, dim3(grid_for(npts, grid)), dim3(256), 0, st, make_sdfh_ptrs(packed), d_sdf, npts,
-                            act, rsave, featbar, zbar, tpart, nullptr, nullptr, nullptr, nullptr, absmax);
+                            act, rsave, featbar, zbar, tpart, nullptr, nullptr, nullptr, nullptr, absmax, tmax);
     return ok();
 }
 

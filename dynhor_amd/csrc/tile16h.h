@@ -4,10 +4,10 @@
 //   X = S x with S a power of two;  X = Xh + Xl,  Xh = fp16(X),  Xl = fp16(X - Xh)  (the UNSCALED residual)
 //   x w  <-  (Xh Wl + Xl Wh + Xh Wh) / (S_x S_w)        fp32 accumulation, smallest terms first
 //
-// Xh carries 11 significant bits, the residual (exact in fp32: v_fma_mix_f32 straight from the f16 half) is <= 2^-12 |X| and is
-// rounded to 11 bits again, so X is represented to 2^-24 |X| -- as long as Xl is a normal fp16 number, i.e. |X| >= 2^-2.  Below
-// that Xl is an fp16 SUBNORMAL (the matrix cores do not flush them: scripts/micro/tchain2_micro.hip gemm_check) and the
-// representation error is 2^-25 ABSOLUTE in units of X.  The scheme is therefore fp32-accurate once S puts the operand's
+// Xh carries 11 significant bits, the residual (exact in fp32: v_fma_mix_f32 straight from the f16 half) is <= 2^-11 |X| and is
+// rounded to 11 bits again, so X is represented to 2^-22 |X| in the worst case and 2^-24.6 |X| rms (fp32 itself: 2^-24 / 2^-25.8)
+// -- as long as Xl is a normal fp16 number.  Where it is an fp16 SUBNORMAL (the matrix cores do not flush them:
+// scripts/micro/tchain2_micro.hip gemm_check) the representation error is 2^-25 ABSOLUTE in units of X.  The scheme is therefore fp32-accurate once S puts the operand's
 // dominant magnitudes at >= O(1): measured on the hardware 1.9e-7 relative L2 vs fp64 against 2.3e-7 for the exact fp32 MFMA and
 // 2.5e-7 for bf16x3 (profiles/r04_ab_f16x2_chain_micro.json; tests/test_cpu_f16_split.py restates it on the CPU), and wrong by
 // orders of magnitude for UNSCALED 1e-6 operands.  Hence the scales:

@@ -17,11 +17,18 @@ int64_t dw_slab_floats(int G);   // per-tile partial-sum slots of 256 floats (bi
 enum : int { ABSMAX_ASAVE = 0, ABSMAX_ZBAR = 8, ABSMAX_TSAVE = 16, ABSMAX_T0AUX = 23, ABSMAX_FEATBAR = 24, ABSMAX_CZBAR = 25,
              ABSMAX_CACT = 29, ABSMAX_FEAT = 33, ABSMAX_N = 34 };
 constexpr int ABSMAX_FLOATS = 64 * 64;
+// tmax: PER-TILE maxima of the heavy-tailed classes (adjoints and tangents: a few sample points near the surface carry almost
+// everything): [TMAX_N][ntiles] u32.  The two-piece fp16 weight-gradient kernel scales such an operand tile by tile (a launch-wide
+// scale set by one outlier would push the typical tile into fp16's subnormals: measured 1.7e-4 on the gradient) and divides the
+// tile's other operand by the same power of two, so that every product still carries one launch-wide scale.  Written (plain
+// stores, every tile once) by the kernels that write the tiles.
+enum : int { TMAX_ZBAR = 0, TMAX_FEATBAR = 8, TMAX_CZBAR = 9, TMAX_TSAVE = 13, TMAX_T0AUX = 20, TMAX_N = 21 };
 
 struct Workspace {
     int64_t ntiles;
     float* base;
     float* absmax;  // [64][64] u32, see above
+    float* tmax;    // [TMAX_N][nt] u32, see above
     // forward (saved for backward)
     float* act;     // [8][nt][TILE_F]   inputs of SDF layers 1..8 (post-softplus)
     float* eaux;    // [nt][AUXT_F]      positional embedding (aux native)
@@ -51,6 +58,7 @@ inline Workspace carve_workspace(float* base, int64_t npts) {
     int64_t o = 0;
     auto take = [&](int64_t n) { float* p = base ? base + o : nullptr; o += n; return p; };
     w.absmax = take(ABSMAX_FLOATS);
+    w.tmax = take((TMAX_N * nt + 3) / 4 * 4);
     w.act = take(8 * nt * TILE_F);
     w.eaux = take(nt * AUXT_F);
     w.feat = take(nt * TILE_F);

@@ -35,8 +35,9 @@ DEFAULT_CONF = {
               # per-frame pose refinement: 6-D rotation + translation per frame, rotation at 10x lr
               "refine_poses": False, "pose_lr": 1e-4, "pose_rot_lr_mult": 10.0, "pose_start_iter": 0},
     # family "neus": the 8x256 / 4x256 fp32 MLPs (BASELINE.json configs[1]); "hash": hash-grid + shallow MLPs (configs[3])
-    # arithmetic: null (leave the library's word alone), "split_bf16" (shipping) or "fp32_mfma" (the native fp32-MFMA twins) for THIS
-    # Runner's renderer -- two Runners of one process may differ
+    # arithmetic: null (the library's default: split_f16), "split_f16" (two fp16 pieces / three products, shipping), "split_bf16"
+    # (three bf16 pieces / six products) or "fp32_mfma" (the native fp32-MFMA twins) for THIS Runner's renderer -- passed with every
+    # launch, so Runners of one process (also on different host threads) may differ
     "model": {"family": "neus", "arithmetic": None, "sdf_network": {}, "variance_network": {"init_val": 0.3}, "rendering_network": {},
               "hash_sdf_network": {}, "sh_rendering_network": {},
               # hash family only: sampler "hierarchical" (NeuS 64+64) or "occgrid" (instant-nsr-pl occupancy-grid marching)

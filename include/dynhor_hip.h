@@ -59,6 +59,12 @@ int64_t dh_num_params(void);
 int64_t dh_packed_floats(void);
 int dh_param_layout(int net, int layer, int64_t* bias_off, int64_t* g_off, int64_t* v_off, int* out_dim, int* in_dim);
 
+/* Where a section of the packed buffer lies (float offset, float count) -- for tests and tools that decode it: 0 = the
+ * register-resident chains' bf16x3 weight stream (132 stages of 24 KB), 1 = their 10 bias rows, 2 = the two-piece fp16 stream
+ * (132 stages of 16 KB), 3 = its 11-row table (16 x bias of lin0..7, lin8 row 0, lin8 bias rows 1..256, 1 / S_w of lin0..8),
+ * 4 = max |W| per linear (16 u32: sdf lin0..8, colour lin0..4), from which the fp16 weight scales are derived. */
+int dh_packed_section(int section, int64_t* offset_floats, int64_t* n_floats);
+
 /* weight-norm (W = g v/||v||, upstream nn.utils.weight_norm) + MFMA-operand packing; once per optimiser step. */
 int dh_pack_weights(const float* params, float* packed, void* stream);
 

@@ -10,7 +10,8 @@ handful of low-resolution frames cannot resolve 0.1 dB.  This script therefore
     difference mean +- s.e.;
   * offers arms that isolate WHAT differs between the two trajectories:
       hip_vs_oracle       shipping HIP kernels vs the oracle in GPU-eager PyTorch (the north-star comparison)
-      hip_vs_hip_f32      shipping split-bf16 kernels vs the native fp32-MFMA kernel set (second, independent arithmetic)
+      hip_vs_hip_f32      shipping two-piece fp16 kernels vs the native fp32-MFMA kernel set (second, independent arithmetic)
+      hip_vs_hip_bf16     shipping two-piece fp16 kernels vs the three-piece bf16 kernels of rounds 1-3
       hip_noise_floor     the HIP path vs itself with initial weights perturbed by 1e-7 relative (chaos only: no kernel differs)
       oracle_noise_floor  the oracle vs itself, same perturbation
       hip_scatter         (hash family) shipping table scatter vs the unmerged per-evaluation scatter
@@ -54,7 +55,7 @@ class HipArm:
 
     def _modes(self):
         if self.arith is not None:
-            _lib.set_arithmetic(self.arith)
+            self.r.renderer.arithmetic = self.arith        # passed with every launch
         if self.scatter is not None:
             _lib.check(_lib.lib().dh_hash_set_scatter_mode(self.scatter))
 
@@ -162,7 +163,7 @@ def oracle_render_psnr(arm, ds, it, frames, level):
 
 
 ARM_NAMES = {"hip_vs_oracle": ("hip", "oracle_gpu_eager"), "oracle_noise_floor": ("oracle_perturbed_1e-7", "oracle"),
-             "hip_vs_hip_f32": ("hip_split_bf16", "hip_fp32_mfma"), "hip_noise_floor": ("hip_perturbed_1e-7", "hip"),
+             "hip_vs_hip_f32": ("hip_split_f16", "hip_fp32_mfma"), "hip_vs_hip_bf16": ("hip_split_f16", "hip_split_bf16"), "hip_noise_floor": ("hip_perturbed_1e-7", "hip"),
              "hip_scatter": ("hip_scatter_merged", "hip_scatter_per_evaluation"),
              "hip_occgrid_vs_hierarchical": ("hip_occgrid_sampler", "hip_hierarchical_sampler")}
 
@@ -188,7 +189,9 @@ def run_seed(args, seed, dev):
         r_b = make_runner(args.family, wseed, args.batch, 2, 64, dev, tag + "_b")
         r_b.dataset = ds
         if mode == "hip_vs_hip_f32":
-            A, B = HipArm(r_a, arithmetic=_lib.ARITH_SPLIT_BF16), HipArm(r_b, arithmetic=_lib.ARITH_FP32_MFMA)
+            A, B = HipArm(r_a, arithmetic=_lib.ARITH_SPLIT_F16), HipArm(r_b, arithmetic=_lib.ARITH_FP32_MFMA)
+        elif mode == "hip_vs_hip_bf16":
+            A, B = HipArm(r_a, arithmetic=_lib.ARITH_SPLIT_F16), HipArm(r_b, arithmetic=_lib.ARITH_SPLIT_BF16)
         elif mode == "hip_noise_floor":
             A, B = HipArm(r_a), HipArm(r_b); A.perturb(1e-7, 5)
         elif mode == "hip_scatter":
@@ -258,7 +261,6 @@ def run_seed(args, seed, dev):
             print(json.dumps({"seed": seed, **e}), flush=True, file=LOG)
     if seg is not None:
         close_segment()
-    _lib.set_arithmetic(_lib.ARITH_SPLIT_BF16)
     _lib.check(_lib.lib().dh_hash_set_scatter_mode(0))
     wa = [e.get("psnr_a_window_level", e["psnr_a"]) for e in rec["eval"]]
     wb = [e.get("psnr_b_window_level", e["psnr_b"]) for e in rec["eval"]]

@@ -50,7 +50,16 @@ def test_host_only_entry_points(hiplib):
         _lib.param_layout(0, 9)
     inf, fwd, tot = _lib.workspace_floats(128 * 2048)
     assert 0 < inf < fwd < tot
-    assert _lib.workspace_floats(0)[:2] == (0, 0)
+    # an empty launch still owns the fixed-size table of per-class maxima (workspace.h absmax: 64 x 64 words)
+    assert _lib.workspace_floats(0)[:2] == (4096, 4096)
+    # the packed buffer's sections (dh_packed_section) lie inside it, in order, without overlap
+    secs = [_lib.packed_section(i) for i in range(5)]
+    assert all(o >= 0 and n > 0 and o + n <= hiplib.dh_packed_floats() for o, n in secs)
+    by_off = sorted(secs)
+    assert all(a[0] + a[1] <= b[0] for a, b in zip(by_off, by_off[1:]))
+    assert secs[0][1] == 132 * 8 * 3 * 64 * 4 and secs[2][1] == 132 * 8 * 2 * 64 * 4
+    with pytest.raises(_lib.DynhorHipError):
+        _lib.packed_section(5)
 
 
 def test_argument_validation_without_gpu(hiplib):

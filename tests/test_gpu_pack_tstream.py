@@ -1,4 +1,5 @@
-"""The register-resident chains' weight stream (csrc/layout.h PACKT): every bf16x8 of it, decoded on the host, must hold the
+"""The register-resident chains' weight streams (csrc/layout.h PACKT: three bf16 pieces; PACKH: two fp16 pieces of S_w W): every
+16-byte fragment of them, decoded on the host, must hold the
 effective weights W = g v / |v| at the position the header documents -- stage order lin0 (3 k-steps), lin1-3 (16 each), lin4 (14
 of lin3's output + 3 of the embedding, both scaled 1/sqrt 2), lin5-7, lin8 rows 1..256; bf16x8 index ((stage*8 + M)*3 + piece)*64 +
 lane = W[32 M + (lane & 31)][k], slot i <-> input feature 16 s + 8 (i/4) + 4 (lane >> 5) + (i % 4); then the ten bias rows."""
@@ -12,7 +13,8 @@ from tests.util import flat_from_oracle, randomized_models
 pytestmark = pytest.mark.gpu
 
 
-def test_tstream_holds_the_effective_weights_where_layout_h_says(hiplib):
+@pytest.mark.parametrize("arith", ["bf16x3", "f16x2"])
+def test_tstream_holds_the_effective_weights_where_layout_h_says(hiplib, arith):
     from dynhor_amd import _lib
     dev = torch.device("cuda:0")
     sdf, col, var = randomized_models(seed=5, device=dev, jitter=0.05)
@@ -20,16 +22,31 @@ def test_tstream_holds_the_effective_weights_where_layout_h_says(hiplib):
     packed = torch.empty(hiplib.dh_packed_floats(), device=dev)
     _lib.check(hiplib.dh_pack_weights(_lib.ptr(flat), _lib.ptr(packed), _lib.stream()))
     torch.cuda.synchronize()
-    n_stage, stage_floats = 132, 8 * 3 * 64 * 4
-    bias0 = packed.numel() - 10 * 256
-    stream0 = bias0 - n_stage * stage_floats
-    pieces = packed[stream0:bias0].view(torch.bfloat16).view(n_stage, 8, 3, 64, 8).float()      # stage, M, piece, lane, slot
-    w = (pieces[:, :, 0] + pieces[:, :, 1] + pieces[:, :, 2]).cpu()                              # [stage, M, lane, slot]
     sd = {k: v.detach().double().cpu() for k, v in sdf.state_dict().items()}
     W = {}
     for l in range(9):
         v, g = sd["lin%d.weight_v" % l], sd["lin%d.weight_g" % l].reshape(-1)
         W[l] = g[:, None] * v / v.norm(dim=1, keepdim=True)
+    n_stage = 132
+    if arith == "bf16x3":
+        stream0, n = _lib.packed_section(0)
+        bias0, _ = _lib.packed_section(1)
+        pieces = packed[stream0:stream0 + n].view(torch.bfloat16).view(n_stage, 8, 3, 64, 8).float()      # stage, M, piece, lane, slot
+        w = (pieces[:, :, 0] + pieces[:, :, 1] + pieces[:, :, 2]).cpu()                              # [stage, M, lane, slot]
+        wscale = {l: 1.0 for l in range(9)}
+    else:
+        stream0, n = _lib.packed_section(2)
+        bias0, _ = _lib.packed_section(3)
+        pieces = packed[stream0:stream0 + n].view(torch.float16).view(n_stage, 8, 2, 64, 8).double()
+        w = (pieces[:, :, 0] + pieces[:, :, 1]).cpu()                                                 # = S_w W
+        wabs0, _ = _lib.packed_section(4)
+        wabs = packed[wabs0:wabs0 + 16].view(torch.int32).cpu()
+        wscale = {}
+        for l in range(9):
+            m = torch.tensor([int(wabs[l])], dtype=torch.int32).view(torch.float32).item()
+            assert abs(m - W[l].abs().max().item()) <= 1e-6 * m, (l, m, W[l].abs().max().item())     # max |W| of the linear
+            wscale[l] = 2.0 ** (3 - math.floor(math.log2(m)))                                          # scaled maximum in [8, 16)
+            assert 8.0 <= wscale[l] * m < 16.0
     # (layer, k-steps, first row, first input column, valid input columns, scale) in stream order
     jobs = [(0, 3, 0, 0, 39, 1.0), (1, 16, 0, 0, 256, 1.0), (2, 16, 0, 0, 256, 1.0), (3, 16, 0, 0, 256, 1.0),
             (4, 14, 0, 0, 217, 1 / math.sqrt(2)), (4, 3, 0, 217, 39, 1 / math.sqrt(2)),
@@ -49,17 +66,23 @@ def test_tstream_holds_the_effective_weights_where_layout_h_says(hiplib):
                 oo = (o[:, None] + row0).expand(64, 8)[ok]
                 kk = (k + col0)[ok]
                 ref[ok] = scale * W[l][oo, kk]
-                err = (w[stage, M].double() - ref).abs().max().item()
+                err = (w[stage, M].double() / wscale[l] - ref).abs().max().item()
                 worst = max(worst, err)
                 assert err < 2e-6, (l, s, M, err)
             stage += 1
     assert stage == n_stage
     print("max |stream - W| = %.2e" % worst)
-    # bias rows 0..7, lin8's effective row 0, lin8's bias rows 1..256
-    b = packed[bias0:].view(10, 256).double().cpu()
+    # bias rows 0..7 (the fp16 chain carries activations scaled by 16: its rows are 16 x bias), lin8's effective row 0, lin8's bias
+    # rows 1..256; the fp16 table's row 10: 1 / S_w of lin0..8
+    nrow = 10 if arith == "bf16x3" else 11
+    b = packed[bias0:bias0 + nrow * 256].view(nrow, 256).double().cpu()
+    xs = 1.0 if arith == "bf16x3" else 16.0
     for l in range(8):
         ref = torch.zeros(256, dtype=torch.float64)
         ref[:sd["lin%d.bias" % l].numel()] = sd["lin%d.bias" % l]
-        assert (b[l] - ref).abs().max() < 1e-7
+        assert (b[l] - xs * ref).abs().max() < 2e-6
+    if arith == "f16x2":
+        for l in range(9):
+            assert b[10, l].item() == 1.0 / wscale[l]
     assert (b[8] - W[8][0]).abs().max() < 2e-6
     assert (b[9] - sd["lin8.bias"][1:]).abs().max() < 1e-7

@@ -106,10 +106,10 @@ def test_pose_parameter_gradients_match_oracle_end_to_end(tiny_dataset):
     assert ref.rot6d.grad[others].abs().max().item() == 0 and ref.trans.grad[others].abs().max().item() == 0
 
 
-def test_both_arithmetics_give_the_same_ray_adjoints(tiny_dataset):
+def test_all_arithmetics_give_the_same_ray_adjoints(tiny_dataset):
     """the native fp32-MFMA twin set covers the pose-refinement kernels too (dh_color_backward_rays /
-    dh_sdf_backward_rays no longer return DH_ERR_UNSUPPORTED under DH_ARITH_FP32_MFMA): the second, independent arithmetic
-    cross-checks d loss / d rays of the shipping split-bf16 kernels on the same step."""
+    dh_sdf_backward_rays): the independent, exact-fp32 arithmetic cross-checks d loss / d rays of the shipping two-piece fp16
+    kernels and of the three-piece bf16 ones on the same step."""
     from dynhor_amd import _lib
     ds = tiny_dataset
     _, p_r = make_pair(seed=53, jitter=0.05, n_samples=32, n_importance=32)
@@ -118,23 +118,27 @@ def test_both_arithmetics_give_the_same_ray_adjoints(tiny_dataset):
     near, far = ds._last_near_far
     t_rand = torch.rand(192, 1, device="cuda:0", generator=g)
     res = {}
+    z = None
     try:
-        for mode in (_lib.ARITH_SPLIT_BF16, _lib.ARITH_FP32_MFMA):
-            _lib.set_arithmetic(mode)
-            z = p_r.sample_z(rays[:, :3].contiguous(), rays[:, 3:6].contiguous(), near, far, t_rand=t_rand) if mode == _lib.ARITH_SPLIT_BF16 else z
-            p_r.sample_z = lambda *a, **k: z
+        for mode in (_lib.ARITH_FP32_MFMA, _lib.ARITH_SPLIT_F16, _lib.ARITH_SPLIT_BF16):
+            p_r.arithmetic = mode                     # passed with every launch (the `_ex` entry points)
+            if z is None:
+                z = p_r.sample_z(rays[:, :3].contiguous(), rays[:, 3:6].contiguous(), near, far, t_rand=t_rand)
+                p_r.sample_z = lambda *a, **k: z
             stats = p_r.train_step_core(rays, near, far, ds.R[0], 0.3, 0.1, 0.1, 0.05, ray_grads=True)
             torch.cuda.synchronize()
             d_o, d_d, d_R = p_r.last_ray_grads
             res[mode] = (stats.clone(), p_r.store.grad_flat.clone(), d_o.clone(), d_d.clone(), d_R.clone())
     finally:
-        _lib.set_arithmetic(_lib.ARITH_SPLIT_BF16)
-    a, b = res[_lib.ARITH_SPLIT_BF16], res[_lib.ARITH_FP32_MFMA]
+        p_r.arithmetic = None
+    b = res[_lib.ARITH_FP32_MFMA]
     rel = lambda x, y: ((x.double() - y.double()).norm() / y.double().norm()).item()
-    print(f"split-bf16 vs fp32-MFMA, pose refinement step: loss diff {(a[0][0] - b[0][0]).abs().item():.2e}; weight grad {rel(a[1], b[1]):.2e}; "
-          f"d_rays_o {rel(a[2], b[2]):.2e}; d_rays_d {rel(a[3], b[3]):.2e}; d_R {rel(a[4], b[4]):.2e}")
-    assert (a[0][:6] - b[0][:6]).abs().max().item() < 5e-6
-    assert rel(a[1], b[1]) < 2e-5 and rel(a[2], b[2]) < 5e-5 and rel(a[3], b[3]) < 5e-5 and rel(a[4], b[4]) < 5e-5
+    for name, mode in (("split-f16", _lib.ARITH_SPLIT_F16), ("split-bf16", _lib.ARITH_SPLIT_BF16)):
+        a = res[mode]
+        print(f"{name} vs fp32-MFMA, pose refinement step: loss diff {(a[0][0] - b[0][0]).abs().item():.2e}; weight grad {rel(a[1], b[1]):.2e}; "
+              f"d_rays_o {rel(a[2], b[2]):.2e}; d_rays_d {rel(a[3], b[3]):.2e}; d_R {rel(a[4], b[4]):.2e}")
+        assert (a[0][:6] - b[0][:6]).abs().max().item() < 5e-6
+        assert rel(a[1], b[1]) < 2e-5 and rel(a[2], b[2]) < 5e-5 and rel(a[3], b[3]) < 5e-5 and rel(a[4], b[4]) < 5e-5
 
 
 def test_runner_refines_poses_and_checkpoints_them(tmp_path):
