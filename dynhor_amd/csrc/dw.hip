@@ -465,13 +465,16 @@ __device__ __forceinline__ void dw_body_pieces_h(const DwJob& J, const DwScales&
         return f;
     };
     if (NP > 0) {
-        Raw r0, r1;
+        // THREE raw register sets: with the matrix work halved this kernel is bound by the HBM stream (32 KB per k-pair and CU
+        // against 768 MFMA cycles), so three k-pairs of loads stay in flight (96 KB per CU)
+        Raw r0, r1, r2;
         load(r0);
         load(r1);
+        load(r2);
         __builtin_amdgcn_sched_barrier(0);
         publish_a(r0, 0);
         publish_b(r0, 0);
-        load(r0);                                          // pair 2 in flight
+        load(r0);                                          // pair 3 in flight
         __syncthreads();
         constexpr int H = NBW / 2;
         auto step = [&](int par, Raw& nxt) {
@@ -518,15 +521,27 @@ __device__ __forceinline__ void dw_body_pieces_h(const DwJob& J, const DwScales&
             __syncthreads();
         };
         const float ratio = npairs == 2 ? sc.prod1 / sc.prod0 : 1.f;       // powers of two: exact
-        int p = 0;
-        for (; p + 1 < NP; p += 2) {
-            if (npairs == 2 && p == NP1) {               // NP1 is even: the change-over falls on a step(0) boundary
+        // step p computes piece buffer p & 1 and publishes raw set (p + 1) % 3 (k-pair p + 1), which it refills with k-pair p + 4:
+        // the buffers alternate with period 2, the register sets with period 3 -- both STATICALLY over six steps
+        auto rescale = [&](int p) {
+            if (npairs == 2 && p == NP1) {
                 DH_UNROLL for (int i = 0; i < NA; ++i) DH_UNROLL for (int j = 0; j < NBW; ++j) DH_UNROLL for (int r = 0; r < 16; ++r) acc[i][j][r] *= ratio;
             }
-            step(0, r1);
-            step(1, r0);
+        };
+        int p = 0;
+        for (; p + 5 < NP; p += 6) {
+            rescale(p); step(0, r1);
+            rescale(p + 1); step(1, r2);
+            rescale(p + 2); step(0, r0);
+            rescale(p + 3); step(1, r1);
+            rescale(p + 4); step(0, r2);
+            rescale(p + 5); step(1, r0);
         }
-        if (p < NP) step(0, r1);
+        if (p < NP) { rescale(p); step(0, r1); ++p; }
+        if (p < NP) { rescale(p); step(1, r2); ++p; }
+        if (p < NP) { rescale(p); step(0, r0); ++p; }
+        if (p < NP) { rescale(p); step(1, r1); ++p; }
+        if (p < NP) { rescale(p); step(0, r2); ++p; }
     }
     const float inv = 1.f / (npairs == 2 ? sc.prod1 : sc.prod0);
     DH_UNROLL for (int i = 0; i < NA; ++i)

@@ -255,8 +255,13 @@ def run_seed(args, seed, dev):
                 e["psnr_b_window_level"] = eval_psnr(B.eval_runner(scratch), it + 1, args.eval_level)
             if args.cross_check and (it + 1) == evals[-1] and mode == "hip_vs_oracle":
                 fr = [0, ds.n_images // 4, ds.n_images // 2, (3 * ds.n_images) // 4]
+                # independent evaluation: the same four frames with the HIP arm rendered by the HIP renderer and the
+                # oracle arm by the ORACLE's own renderer -- a forward bias common to both arms cannot cancel in this difference
+                e["hip_weights_by_hip_renderer_4f"] = eval_psnr(A.eval_runner(scratch), it + 1, 4, frames=fr)
                 e["oracle_weights_by_hip_renderer_4f"] = eval_psnr(B.eval_runner(scratch), it + 1, 4, frames=fr)
                 e["oracle_weights_by_oracle_renderer_4f"] = oracle_render_psnr(B, ds, it + 1, fr, 4)
+                rec["delta_4f_shared_renderer_db"] = e["hip_weights_by_hip_renderer_4f"] - e["oracle_weights_by_hip_renderer_4f"]
+                rec["delta_4f_independent_renderers_db"] = e["hip_weights_by_hip_renderer_4f"] - e["oracle_weights_by_oracle_renderer_4f"]
             rec["eval"].append(e)
             print(json.dumps({"seed": seed, **e}), flush=True, file=LOG)
     if seg is not None:
@@ -326,6 +331,10 @@ def run_parity(argv=None):
            "protocol": "paired seeds (ray stream + initial weights per seed, shared by both arms); PSNR = masked MSE aggregated over "
                        "ALL frames, rendered by the HIP forward-only path for both arms; window = mean over the eval checkpoints",
            "window_delta": summarize(recs, "window_delta_db"), "final_delta": summarize(recs, "final_delta_db"),
+           **({"delta_4f_shared_renderer": summarize(recs, "delta_4f_shared_renderer_db"),
+               "delta_4f_independent_renderers": summarize(recs, "delta_4f_independent_renderers_db"),
+               "evaluator_difference_4f": summarize([{"d": r["delta_4f_independent_renderers_db"] - r["delta_4f_shared_renderer_db"]} for r in recs], "d")}
+              if all("delta_4f_independent_renderers_db" in r for r in recs) else {}),
            "window_mean_a": sum(r["window_mean_a"] for r in recs) / len(recs), "window_mean_b": sum(r["window_mean_b"] for r in recs) / len(recs),
            "sec_per_iter_a": sum(r["sec_per_iter_a"] for r in recs) / len(recs), "sec_per_iter_b": sum(r["sec_per_iter_b"] for r in recs) / len(recs),
            "note": "oracle = this repo's PyTorch restatement of NeuS (parity unpinned at the reference)", "seeds": recs}
