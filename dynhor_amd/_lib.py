@@ -144,6 +144,29 @@ def get_arithmetic() -> int:
     return int(lib().dh_get_arithmetic())
 
 
+_ROCTX = False
+
+
+def roctx():
+    """ctypes handle of the ROCm marker library (roctxRangePushA / roctxRangePop), or None when it is not installed.  rocprofv3
+    --marker-trace records the ranges; outside a profiler they cost two empty calls.  librocprofiler-sdk-roctx is the library
+    rocprofv3 intercepts; libroctx64 is the older name of the same interface."""
+    global _ROCTX
+    if _ROCTX is False:
+        _ROCTX = None
+        for name in ("librocprofiler-sdk-roctx.so", "libroctx64.so"):
+            try:
+                L = ctypes.CDLL(name)
+                L.roctxRangePushA.argtypes = [ctypes.c_char_p]
+                L.roctxRangePushA.restype = ctypes.c_int
+                L.roctxRangePop.restype = ctypes.c_int
+                _ROCTX = L
+                break
+            except (OSError, AttributeError):
+                continue
+    return _ROCTX
+
+
 def check(status: int):
     if status != 0:
         raise DynhorHipError(f"dynhor_hip status {status}: {lib().dh_strerror(status).decode()}")

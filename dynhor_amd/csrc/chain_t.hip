@@ -715,10 +715,34 @@ extern "C" void dh_dev_nograd_t_debug(float* dbg, int layer) { g_dbg = dbg; g_db
 #else
 #define T_DBG_ARGS
 #endif
-// h2: the two-piece fp16 arithmetic
+// One workgroup per CU with up to 156 KB of static LDS and LDS-DMA: what the current device offers is asked once per device
+// (the launchers hard-coded 256 workgroups and failed with a bare launch error where the LDS does not exist).
+struct TDev { int cus; int lds; };
+static TDev t_device() {
+    static TDev cache[16] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return TDev{0, 0};
+    TDev d = cache[dev];                                   // (a benign race: every thread writes the same two values)
+    if (d.cus == 0) {
+        int cus = 0, lds = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 0;
+        if (hipDeviceGetAttribute(&lds, hipDeviceAttributeMaxSharedMemoryPerMultiprocessor, dev) != hipSuccess) lds = 0;
+        d = TDev{cus, lds};
+        cache[dev] = d;
+    }
+    return d;
+}
+template <class C>
+static int t_grid(int64_t ntiles) {                        // 0: the device cannot run this kernel
+    const TDev d = t_device();
+    if (d.cus <= 0 || d.lds < t_lds_bytes<C>()) return 0;
+    return (int)(ntiles < d.cus ? ntiles : d.cus);
+}
+// h2: the two-piece fp16 arithmetic.  Returns DH_ERR_UNSUPPORTED (-2) where the device lacks the LDS these kernels are built on.
 int launch_sdf_nograd_t(const float* packed, const float* pts, int64_t npts, float* sdf, bool h2, hipStream_t stream) {
     const int64_t ntiles = (npts + T_PTS - 1) / T_PTS;
-    const int g = (int)(ntiles < 256 ? ntiles : 256);
+    const int g = h2 ? t_grid<TCfgNoGrad<TArH2>>(ntiles) : t_grid<TCfgNoGrad<TArB3>>(ntiles);
+    if (g <= 0) return -2;
     if (h2) hipLaunchKernelGGL(sdf_nograd_h_kernel, dim3(g), dim3(256), 0, stream, static_cast<const void*>(packed + PACKH.stream),
                                packed + PACKH.bias11, packed + PACK.sdf_b8_0, pts, npts, sdf T_DBG_ARGS);
     else hipLaunchKernelGGL(sdf_nograd_t_kernel, dim3(g), dim3(256), 0, stream, static_cast<const void*>(packed + PACKT.stream),
@@ -728,7 +752,8 @@ int launch_sdf_nograd_t(const float* packed, const float* pts, int64_t npts, flo
 int launch_sdf_fwd_train_t(const float* packed, const float* pts, int64_t npts, float* sdf, float* feat, float* act, float* eaux,
                            bool h2, hipStream_t stream) {
     const int64_t ntiles = (npts + T_PTS - 1) / T_PTS;
-    const int g = (int)(ntiles < 256 ? ntiles : 256);
+    const int g = h2 ? t_grid<TCfgTrain<TArH2>>(ntiles) : t_grid<TCfgTrain<TArB3>>(ntiles);
+    if (g <= 0) return -2;
     if (h2) hipLaunchKernelGGL(sdf_fwd_train_h_kernel, dim3(g), dim3(256), 0, stream, static_cast<const void*>(packed + PACKH.stream),
                                packed + PACKH.bias11, packed + PACK.sdf_b8_0, pts, npts, sdf, feat, act, eaux T_DBG_ARGS);
     else hipLaunchKernelGGL(sdf_fwd_train_t_kernel, dim3(g), dim3(256), 0, stream, static_cast<const void*>(packed + PACKT.stream),

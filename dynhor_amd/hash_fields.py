@@ -218,21 +218,40 @@ class HashNeuSRenderer(NeuSRenderer):
         self.grid.update(lambda p: self.sdf(p), self.store.inv_s(), self.march_step, generator=generator, jitter=jitter)
 
     def _buffers(self, B: int):
-        """Sample buffers of a batch of B rays at the fixed capacity B * max_samples (rounded to 8 rows), allocated once."""
-        buf = self._packed_buf.get(B)
+        """Sample buffers of a batch of B rays at the fixed capacity B * max_samples (rounded to 8 rows).  The TRAINING batch size
+        (the first one seen by a training step; last_state and Runner.report() keep pointing into its buffers) owns an entry that
+        is never evicted; every other size (validation / vote chunks, ragged last chunks) shares ONE inference buffer set that is
+        allocated at the largest size seen and sliced (per-B entries with eviction re-allocated the training buffers)."""
+        if getattr(self, "_train_B", None) is None and getattr(self, "_in_train_step", False):
+            self._train_B = B
+        role = "train" if B == getattr(self, "_train_B", None) else "infer"
+        buf = self._packed_buf.get(role)
+        if buf is not None and (buf.B < B if role == "infer" else buf.B != B):
+            buf = None
+        if buf is not None and buf.B != B:
+            buf = self._slice_buffers(buf, B)
         if buf is None:
             from types import SimpleNamespace
             dev = self.store.device
             cap = (B * self.max_samples + 7) // 8 * 8
             z = lambda *shape, dt=torch.float32: torch.zeros(*shape, dtype=dt, device=dev)
-            buf = SimpleNamespace(cap=cap, cnt_raw=z(B, dt=torch.int32), t_start=z(cap), pts=z(cap, 3), dirs=z(cap, 3),
+            buf = SimpleNamespace(B=B, cap=cap, cnt_raw=z(B, dt=torch.int32), t_start=z(cap), pts=z(cap, 3), dirs=z(cap, 3),
                                   ray_idx=z(cap, dt=torch.int32), sdf=z(cap), normals=z(cap, 3), colors=z(cap, 3), feat=z(cap, 13),
                                   weights=z(cap), cdf=z(cap), inside=z(cap), d_sdf=z(cap), d_normals=z(cap, 3), d_colors=z(cap, 3),
                                   d_feat=z(cap, 13), caps=torch.tensor(self._cap_ladder, dtype=torch.int32, device=dev))
-            if len(self._packed_buf) >= 3:       # training batch, validation chunk, one more: the oldest goes
-                self._packed_buf.pop(next(iter(self._packed_buf)))
-            self._packed_buf[B] = buf
+            self._packed_buf[role] = buf
         return buf
+
+    def _slice_buffers(self, big, B: int):
+        """A view of the inference buffer set for a smaller chunk of B rays (same storage, capacity B * max_samples)."""
+        from types import SimpleNamespace
+        cap = (B * self.max_samples + 7) // 8 * 8
+        out = {}
+        for k, v in vars(big).items():
+            if k in ("B", "cap", "caps"):
+                continue
+            out[k] = v[:B] if k == "cnt_raw" else v[:cap]
+        return SimpleNamespace(B=B, cap=cap, caps=big.caps, **out)
 
     @torch.no_grad()
     def march(self, rays_o, rays_d, near, far, u):
@@ -336,7 +355,11 @@ class HashNeuSRenderer(NeuSRenderer):
         rays_o = rays[:, 0:3].contiguous(); rays_d = rays[:, 3:6].contiguous()
         if t_rand is None and self.perturb > 0:
             t_rand = torch.rand(B, 1, device=dev)
-        m = self.march(rays_o, rays_d, near, far, t_rand if self.perturb > 0 else None)
+        self._in_train_step = True           # _buffers: this batch size owns the never-evicted training entry
+        try:
+            m = self.march(rays_o, rays_d, near, far, t_rand if self.perturb > 0 else None)
+        finally:
+            self._in_train_step = False
         bg = None if background_rgb is None else background_rgb.reshape(-1).contiguous().float()
         s = self._forward_packed(rays_o, rays_d, m, cos_anneal_ratio, bg, want_nmap=normal_weight > 0.0)
         stats = torch.empty(8, device=dev)

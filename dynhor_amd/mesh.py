@@ -15,7 +15,10 @@ _TETS = torch.tensor([[0, 1, 3, 7], [0, 3, 2, 7], [0, 2, 6, 7], [0, 6, 4, 7], [0
 
 def marching_tetrahedra(u: torch.Tensor, threshold: float, bound_min, bound_max):
     """u [N,N,N] scalar field (upstream convention: u = -sdf, inside > threshold).  Returns (vertices [V,3] float32 in
-    world units, triangles [T,3] int64)."""
+    world units, triangles [T,3] int64).  A surface vertex lies on a grid EDGE and is identified by that edge (the pair of corner
+    indices): every tetrahedron sharing the edge computes the same position from the same end, and vertices are welded by that
+    key -- the mesh is watertight by construction (round 4: welding by quantised positions left a few cracks where the two ends'
+    roundings differed; tests/test_cpu_mesh.py)."""
     dev = u.device
     N = u.shape[0]
     bmin = torch.as_tensor(bound_min, dtype=torch.float32, device=dev)
@@ -34,62 +37,69 @@ def marching_tetrahedra(u: torch.Tensor, threshold: float, bound_min, bound_max)
     base = ((vmax > 0) & (vmin <= 0)).nonzero().reshape(-1, 1, 3)              # [C,1,3] active cells only
     corners = base + _CORNERS.to(dev).reshape(1, 8, 3)                          # [C,8,3]
     vals = f[corners[..., 0], corners[..., 1], corners[..., 2]]               # [C,8]
+    lin = (corners[..., 0] * N + corners[..., 1]) * N + corners[..., 2]        # [C,8] linear index of every corner
     tets = _TETS.to(dev)
-    tv = vals[:, tets]                                                         # [C,6,4]
-    tp = corners[:, tets].float()                                              # [C,6,4,3]
-    tv = tv.reshape(-1, 4); tp = tp.reshape(-1, 4, 3)
+    tv = vals[:, tets].reshape(-1, 4)                                          # [C*6,4]
+    tp = corners[:, tets].float().reshape(-1, 4, 3)                            # [C*6,4,3]
+    ti = lin[:, tets].reshape(-1, 4)                                           # [C*6,4]
     inside = tv > 0
     n_in = inside.sum(dim=1)
-    tris = []
+    tris, keys = [], []
+    NN = N * N * N
 
-    def interp(pa, pb, va, vb):
-        t = (va / (va - vb)).clamp(0, 1).unsqueeze(-1)
-        return pa + t * (pb - pa)
+    def edge_vertex(p, v, idx, ar, a, b):
+        """Crossing of edge (a, b) (per-row corner slots): position computed from the lower corner index, and the edge's key."""
+        pa, pb, va, vb, ia, ib = p[ar, a], p[ar, b], v[ar, a], v[ar, b], idx[ar, a], idx[ar, b]
+        sw = ia > ib
+        p0, p1 = torch.where(sw[:, None], pb, pa), torch.where(sw[:, None], pa, pb)
+        v0, v1 = torch.where(sw, vb, va), torch.where(sw, va, vb)
+        t = (v0 / (v0 - v1)).clamp(0, 1).unsqueeze(-1)
+        return p0 + t * (p1 - p0), torch.minimum(ia, ib) * NN + torch.maximum(ia, ib)
+
+    def emit(pts, ks, ref, ref_inside):
+        """One triangle per row from three (position, key) pairs, oriented so that its normal points away from `ref` if
+        ref_inside (ref lies on the inside), towards it otherwise."""
+        tri = torch.stack(pts, dim=1)
+        key = torch.stack(ks, dim=1)
+        n = torch.linalg.cross(tri[:, 1] - tri[:, 0], tri[:, 2] - tri[:, 0])
+        s = (n * (ref - tri.mean(dim=1))).sum(-1)
+        wrong = (s > 0) if ref_inside else (s < 0)
+        tri[wrong] = tri[wrong][:, [0, 2, 1]]
+        key[wrong] = key[wrong][:, [0, 2, 1]]
+        tris.append(tri); keys.append(key)
 
     # one corner inside (or one outside): a single triangle on the three edges leaving that corner
-    for count, flip in ((1, False), (3, True)):
+    for count in (1, 3):
         sel = n_in == count
         if sel.any():
-            v, p, ins = tv[sel], tp[sel], inside[sel]
-            lone = (ins if count == 1 else ~ins).float().argmax(dim=1)          # index of the lone corner
-            others = torch.stack([(lone + k) % 4 for k in (1, 2, 3)], dim=1)
+            v, p, ins, idx = tv[sel], tp[sel], inside[sel], ti[sel]
+            lone = (ins if count == 1 else ~ins).float().argmax(dim=1)          # slot of the lone corner
             ar = torch.arange(v.shape[0], device=dev)
-            pa, va = p[ar, lone], v[ar, lone]
-            pts = [interp(pa, p[ar, others[:, k]], va, v[ar, others[:, k]]) for k in range(3)]
-            tri = torch.stack(pts, dim=1)
-            # orientation: make the normal point from inside (u > thr) to outside
-            n = torch.linalg.cross(tri[:, 1] - tri[:, 0], tri[:, 2] - tri[:, 0])
-            to_lone = pa - tri.mean(dim=1)
-            wrong = ((n * to_lone).sum(-1) > 0) if count == 1 else ((n * to_lone).sum(-1) < 0)
-            tri[wrong] = tri[wrong][:, [0, 2, 1]]
-            tris.append(tri)
+            ev = [edge_vertex(p, v, idx, ar, lone, (lone + k) % 4) for k in (1, 2, 3)]
+            emit([e[0] for e in ev], [e[1] for e in ev], p[ar, lone], ref_inside=(count == 1))
     # two inside / two outside: a quad (two triangles) across the four mixed edges
     sel = n_in == 2
     if sel.any():
-        v, p, ins = tv[sel], tp[sel], inside[sel]
+        v, p, ins, idx = tv[sel], tp[sel], inside[sel], ti[sel]
         order = torch.argsort(ins.int(), dim=1, descending=True, stable=True)   # [in0, in1, out0, out1]
         ar = torch.arange(v.shape[0], device=dev)
-        g = lambda k: (p[ar, order[:, k]], v[ar, order[:, k]])
-        (pi0, vi0), (pi1, vi1), (po0, vo0), (po1, vo1) = g(0), g(1), g(2), g(3)
-        q00, q01 = interp(pi0, po0, vi0, vo0), interp(pi0, po1, vi0, vo1)
-        q10, q11 = interp(pi1, po0, vi1, vo0), interp(pi1, po1, vi1, vo1)
-        for tri in (torch.stack([q00, q01, q11], 1), torch.stack([q00, q11, q10], 1)):
-            n = torch.linalg.cross(tri[:, 1] - tri[:, 0], tri[:, 2] - tri[:, 0])
-            to_in = 0.5 * (pi0 + pi1) - tri.mean(dim=1)
-            wrong = (n * to_in).sum(-1) > 0
-            tri[wrong] = tri[wrong][:, [0, 2, 1]]
-            tris.append(tri)
+        i0, i1, o0, o1 = order[:, 0], order[:, 1], order[:, 2], order[:, 3]
+        q00, q01 = edge_vertex(p, v, idx, ar, i0, o0), edge_vertex(p, v, idx, ar, i0, o1)
+        q10, q11 = edge_vertex(p, v, idx, ar, i1, o0), edge_vertex(p, v, idx, ar, i1, o1)
+        ref = 0.5 * (p[ar, i0] + p[ar, i1])
+        emit([q00[0], q01[0], q11[0]], [q00[1], q01[1], q11[1]], ref, ref_inside=True)
+        emit([q00[0], q11[0], q10[0]], [q00[1], q11[1], q10[1]], ref, ref_inside=True)
     if not tris:
         return torch.zeros(0, 3, device=dev), torch.zeros(0, 3, dtype=torch.int64, device=dev)
-    tri = torch.cat(tris, dim=0)                                               # [T,3,3] in grid units
-    area2 = torch.linalg.cross(tri[:, 1] - tri[:, 0], tri[:, 2] - tri[:, 0]).norm(dim=-1)
-    tri = tri[area2 > 1e-12]
-    # weld vertices shared between tetrahedra (quantised to 1e-5 grid units)
-    flat = tri.reshape(-1, 3)
-    key = torch.round(flat * 1e5).to(torch.int64)
-    uniq, inv = torch.unique(key, dim=0, return_inverse=True)
+    flat = torch.cat(tris, dim=0).reshape(-1, 3)                                # positions in grid units
+    key = torch.cat(keys, dim=0).reshape(-1)
+    uniq, inv = torch.unique(key, return_inverse=True)
     verts = torch.zeros(uniq.shape[0], 3, device=dev).index_copy_(0, inv, flat)
     faces = inv.reshape(-1, 3)
+    # a crossing that falls exactly on a grid corner makes a triangle collapse onto one vertex KEYED by different edges: such
+    # zero-area triangles are dropped only when two of their indices coincide after welding (never by area: that opened holes)
+    ok = (faces[:, 0] != faces[:, 1]) & (faces[:, 1] != faces[:, 2]) & (faces[:, 0] != faces[:, 2])
+    faces = faces[ok]
     verts = verts / (N - 1) * (bmax - bmin) + bmin
     return verts, faces
 

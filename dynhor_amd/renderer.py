@@ -31,13 +31,32 @@ def _p(t):
 
 class StageTimer:
     """Calls a C-ABI stage; when enabled, brackets it with HIP events on the launch stream (torch's current stream) so
-    bench.py can report per-kernel durations measured inside the timed region."""
+    bench.py can report per-kernel durations measured inside the timed region.  markers (Runner conf train.roctx, a flag, not an
+    environment variable): every stage call sits in a roctx range named after the stage, so that a `rocprofv3 --marker-trace
+    --kernel-trace` timeline reads as the stages of DESIGN.md section 1 (tracing)."""
 
     def __init__(self):
         self.enabled = False
         self.records = {}
+        self.markers = False
+        self._roctx = None
+
+    def set_markers(self, on: bool):
+        self._roctx = _lib.roctx() if on else None
+        self.markers = bool(on) and self._roctx is not None
+        return self.markers
 
     def __call__(self, name, fn, *args):
+        if self.markers:
+            self._roctx.roctxRangePushA(name.encode())
+            try:
+                self._call(name, fn, *args)
+            finally:
+                self._roctx.roctxRangePop()
+        else:
+            self._call(name, fn, *args)
+
+    def _call(self, name, fn, *args):
         if self.enabled:
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record()

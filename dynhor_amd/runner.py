@@ -30,6 +30,8 @@ DEFAULT_CONF = {
               "warm_up_end": 5000, "anneal_end": 50000, "igr_weight": 0.1, "mask_weight": 0.1, "normal_weight": 0.0,
               "save_freq": 10000, "val_freq": 2500, "report_freq": 100, "use_white_bkgd": False, "keep_only": False,
               "seed": 1234, "ray_seed": 4321,
+              # roctx: put every C-ABI stage call into a ROCm marker range (rocprofv3 --marker-trace); off by default
+              "roctx": False,
               # full loss stack (BASELINE.json configs[4]): dense-correspondence reprojection term, DESIGN.md section 9
               "corr_weight": 0.0, "corr_fraction": 0.25, "corr_delta_px": 4.0, "corr_vote_freq": 0, "corr_vote_tau_px": 8.0,
               # per-frame pose refinement: 6-D rotation + translation per frame, rotation at 10x lr
@@ -118,6 +120,8 @@ class Runner:
             extra["arithmetic"] = _lib.ARITH_NAMES[ar]
         self.renderer = renderer_cls(self.nerf_outside, self.sdf_network, self.deviation_network, self.color_network,
                                      store=self.store, device=self.device, **self.conf["model"]["neus_renderer"], **extra)
+        if tr.get("roctx"):
+            self.renderer.timer.set_markers(True)
         self.pose_refiner = None
         if tr["refine_poses"]:
             from .pose import PoseRefiner
@@ -208,7 +212,15 @@ class Runner:
                 self.save_checkpoint()
             if self.rank == 0 and self.val_freq and self.iter_step % self.val_freq == 0:
                 self.validate_image()
+        self.close()
         return self
+
+    def close(self):
+        """Flush and close the scalar writer (train() calls it; safe to call twice)."""
+        if self._board is not None:
+            self._board.flush()
+            self._board.close()
+            self._board = None
 
     def report(self, stats):
         v = dh_dist.mean_stats(stats).tolist()
@@ -222,7 +234,14 @@ class Runner:
             # upstream Statistics/cdf and Statistics/weight_max (App. A.8), masked by obj*keep like the colour loss
             m = (self._last_rays[:, 9:10] * self._last_rays[:, 10:11])
             msum = float(m.sum()) + 1e-5
-            rec["Statistics/cdf"] = float((st.cdf[:, :1] * m).sum()) / msum
+            if st.cdf.dim() == 2:
+                cdf0 = st.cdf[:, :1]
+            else:
+                # packed rays (hash family, occupancy-grid sampler): cdf is the flat capacity buffer; a ray's first sample sits at
+                # its segment offset, rays without samples contribute nothing (st.cdf[:, :1] raised IndexError here)
+                off, cnt = st.m.off, st.m.cnt
+                cdf0 = (st.cdf[off.clamp(max=st.cdf.shape[0] - 1)] * (cnt > 0)).view(-1, 1)
+            rec["Statistics/cdf"] = float((cdf0 * m).sum()) / msum
             rec["Statistics/weight_max"] = float((st.wmax * m).sum()) / msum
         if self.rank == 0:
             self.scalars.append(rec)

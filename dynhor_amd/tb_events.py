@@ -87,11 +87,13 @@ class EventFileWriter:
 
 
 def make_writer(logdir: str):
+    """torch's SummaryWriter when the tensorboard package is importable, else the EventFileWriter above.  Only a MISSING package
+    selects the fallback: a bad logdir or a permission error surfaces from whichever writer is used."""
     try:
         from torch.utils.tensorboard import SummaryWriter       # needs the tensorboard package
-        return SummaryWriter(logdir)
-    except Exception:
+    except (ImportError, ModuleNotFoundError):
         return EventFileWriter(logdir)
+    return SummaryWriter(logdir)
 
 
 def _read_varint(buf: bytes, i: int):

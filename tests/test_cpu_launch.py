@@ -55,11 +55,17 @@ def test_spawn_ranks_relays_a_failing_rank(tmp_path):
     assert p.returncode != 0
 
 
-def test_bench_parent_refuses_more_ranks_than_gpus_without_touching_one():
+def test_bench_parent_starts_ranks_without_touching_a_gpu_and_relays_their_failure():
+    """The parent makes no device query at all (ADVICE r3: torch.cuda.device_count() can initialise the HIP runtime when amdsmi
+    discovery fails): it only starts the ranks.  Here there is no GPU, so every rank dies in torch.cuda.set_device -- and the
+    parent leaves with their non-zero exit code instead of a JSON line (VERDICT r3 next #6)."""
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "0"],
-                       capture_output=True, text=True, timeout=300, env=env)
-    assert p.returncode == 2 and "GPU(s) are visible" in p.stderr and "AssertionError" not in p.stderr
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode != 0 and not [l for l in p.stdout.splitlines() if l.startswith("{")]
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    parent = src[src.index("if args.gpus > 1 and not launch.launched_by_torchrun():"):src.index("world = int(os.environ.get(\"WORLD_SIZE\"")]
+    assert "torch.cuda" not in parent.replace("torch.cuda.set_device", "")
 
 
 def test_bench_rejects_mismatched_world_size():

@@ -39,3 +39,39 @@ def test_threshold_and_bounds_are_respected(tmp_path):
     write_ply(path, v, f)
     head = open(path, "rb").read(200).decode("latin1")
     assert head.startswith("ply") and f"element vertex {v.shape[0]}" in head and f"element face {f.shape[0]}" in head
+
+
+def test_hausdorff_distance_to_the_analytic_scene_surface_at_resolution_64():
+    """VERDICT r3 next #4c: upstream extract_geometry triangulates with marching cubes, this repo with marching tetrahedra -- two
+    triangulations of the same level set.  The number behind "the mesh is the surface": on the bench's analytic scene (sphere +
+    rounded box, dynhor_amd/scene.py) at resolution 64 over [-1, 1]^3 (cell 0.0317) the two-sided Hausdorff distance between the
+    mesh and the analytic zero set is bounded by a small fraction of a cell."""
+    from dynhor_amd.scene import scene_sdf
+    N = 64
+    g = _grid(N)
+    u = -scene_sdf(g.reshape(-1, 3)).reshape(N, N, N)
+    v, f = marching_tetrahedra(u, 0.0, [-1, -1, -1], [1, 1, 1])
+    cell = 2.0 / (N - 1)
+    # mesh -> surface: every vertex and every triangle centroid (a unit-gradient SDF: |sdf| IS the distance)
+    d_v = scene_sdf(v).abs().max().item()
+    cen = (v[f[:, 0]] + v[f[:, 1]] + v[f[:, 2]]) / 3.0
+    d_c = scene_sdf(cen).abs().max().item()
+    # surface -> mesh: points projected onto the analytic surface by Newton steps along the gradient, then the nearest mesh vertex
+    gen = torch.Generator().manual_seed(0)
+    p = torch.nn.functional.normalize(torch.randn(4000, 3, generator=gen), dim=1) * 0.45
+    for _ in range(12):
+        p = p.detach().requires_grad_(True)
+        s = scene_sdf(p)
+        (gr,) = torch.autograd.grad(s.sum(), p)
+        p = p - s.detach()[:, None] * gr / (gr.norm(dim=1, keepdim=True) ** 2 + 1e-12)
+    p = p.detach()
+    assert scene_sdf(p).abs().max().item() < 1e-5
+    d_s = torch.cdist(p, v).min(dim=1).values.max().item()
+    print(f"resolution 64: vertices {v.shape[0]}, triangles {f.shape[0]}; mesh -> surface {max(d_v, d_c):.2e} (vertices {d_v:.2e}, "
+          f"centroids {d_c:.2e}); surface -> nearest vertex {d_s:.2e}; cell {cell:.4f}")
+    assert d_v < 0.25 * cell            # linear interpolation along cell edges; the maximum sits at the crease where sphere and box meet
+    assert d_c < 0.5 * cell             # flat triangles against a curved surface and across that crease
+    assert d_s < 1.0 * cell             # no hole: some vertex within one cell of every surface point
+    e = torch.cat([f[:, [0, 1]], f[:, [1, 2]], f[:, [2, 0]]]).sort(dim=1).values
+    _, cnt = torch.unique(e, dim=0, return_counts=True)
+    assert (cnt == 2).all(), "closed 2-manifold"

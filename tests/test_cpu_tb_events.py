@@ -35,3 +35,28 @@ def test_make_writer_falls_back_without_tensorboard(tmp_path):
     w.add_scalar("x", 1.0, 1)
     w.flush(); w.close()
     assert glob.glob(str(tmp_path / "b" / "events.out.tfevents.*"))
+
+
+def test_roctx_marker_library_loads_and_ranges_nest():
+    """the stage calls can be wrapped in roctx ranges (Runner conf train.roctx).  Here: the marker
+    library loads, push / pop nest, and the StageTimer brackets a stage call with exactly one range also when the call raises."""
+    from dynhor_amd import _lib
+    from dynhor_amd.renderer import StageTimer
+    R = _lib.roctx()
+    if R is None:
+        import pytest
+        pytest.skip("no roctx library in this image")
+    d0 = R.roctxRangePushA(b"outer")
+    d1 = R.roctxRangePushA(b"inner")
+    assert d1 == d0 + 1
+    assert R.roctxRangePop() == d1 and R.roctxRangePop() == d0
+    t = StageTimer()
+    assert t.set_markers(True) is True
+    calls = []
+    t("stage_ok", lambda a, b: calls.append((a, b)) or 0, 1, 2)
+    assert calls == [(1, 2)]
+    try:
+        t("stage_bad", lambda: -3)                    # a non-zero status raises DynhorHipError; the range must still be popped
+    except _lib.DynhorHipError:
+        pass
+    assert R.roctxRangePushA(b"probe") == d0 and R.roctxRangePop() == d0

@@ -252,6 +252,31 @@ def test_runner_trains_and_validates_with_occupancy_grid_sampler(tmp_path):
         r.renderer.train_step_core(r._last_rays, *r.dataset._last_near_far, r.dataset.R[0], 0.1, ray_grads=True)
 
 
+def test_runner_reports_and_validates_in_chunks_without_touching_the_training_buffers(tmp_path):
+    """Runner.report() indexed the packed state's flat cdf as [B, n] (IndexError after report_freq iterations: the
+    occupancy-grid path could not be trained through the CLI), and a validation pass with a few chunk sizes evicted -- and
+    re-allocated -- the training batch's sample buffers that last_state still points into."""
+    r = _occ_runner(tmp_path)
+    r.report_freq = 2
+    r.train(n_iters=4)                                      # reports twice; must not raise
+    recs = [x for x in r.scalars if "Statistics/cdf" in x]
+    assert len(recs) >= 2 and all(0.0 <= x["Statistics/cdf"] <= 1.0 and 0.0 <= x["Statistics/weight_max"] <= 1.0 for x in recs)
+    assert r._board is None, "train() closes the scalar writer"
+    r.train_iteration()
+    st = r.renderer.last_state
+    ptr, w0 = st.weights.data_ptr(), st.weights.clone()
+    ds = r.dataset
+    rays, _, _ = ds.gen_rays_at(0, 2)
+    near, far = ds._last_near_far
+    for n in (700, 300, 1000, 55):                          # ragged validation chunks of several sizes
+        o, d = rays[:n, :3].contiguous(), rays[:n, 3:6].contiguous()
+        c, _ = r.renderer.render_rays(o, d, near[:n], far[:n], 0.5, None, want_nmap=False)
+        assert c.shape == (n, 3) and torch.isfinite(c).all()
+    assert torch.equal(st.weights, w0), "inference chunks must not overwrite the training step's state"
+    r.train_iteration()
+    assert r.renderer.last_state.weights.data_ptr() == ptr, "the training buffers are allocated once"
+
+
 def test_device_side_count_matches_exact_size_launch():
     """the packed stages take the sample count from the DEVICE (n_active) on buffers laid out for a fixed
     capacity.  Same samples through (a) exact-size launches (n = N, n_active = null) and (b) capacity launches (n = cap >
