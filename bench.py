@@ -33,6 +33,11 @@ MACS = {
     "sdf_tangent": 458752, "sdf_backward": 514560, "weight_grads_gemm": 1254656,
     "sdf_nograd_coarse": 459008, "sdf_nograd_fine": 459008,
 }
+# algorithmic HBM bytes per launch of each MLP stage = the saved tiles ("native" [64 x 256] fp32 tiles) it must
+# read or write ONCE, as (main tiles, aux [64 x 64] tiles) per 64 sample points: forward writes act[8] + feat and the embedding;
+# the reverse chain reads act[8], writes a[8]; ...; the weight-gradient GEMMs read 40 distinct main + 3 aux tiles (dw.hip job table)
+STAGE_TILES = {"sdf_forward": (9, 1), "sdf_gradient": (16, 0), "color_forward": (5, 1), "color_backward": (9, 0),
+               "sdf_tangent": (31, 1), "sdf_backward": (25, 0), "weight_grads_gemm": (40, 3)}
 FP32_MFMA_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md, Chip-level parameters
 BF16_MFMA_PEAK_TFLOPS = 2500.0     # same table: bf16 dense
 HBM_PEAK_GBPS = 8000.0             # same table: HBM3E spec
@@ -408,21 +413,45 @@ def main():
                 nprod = {_lib.ARITH_SPLIT_F16: 3.0, _lib.ARITH_SPLIT_BF16: 6.0}.get(arith, 1.0)
                 peak = BF16_MFMA_PEAK_TFLOPS / nprod if split else FP32_MFMA_PEAK_TFLOPS
                 traffic, tsrc = offline_traffic(dom, names[dom])
-                roof = {"bound": "mfma", "kernel": names[dom], "stage": dom, "achieved": per_kernel[dom]["tflops"],
-                        "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(per_kernel[dom]["tflops"] / peak, 4),
-                        "peak_basis": (f"fp16 / bf16 dense MFMA 2500 TFLOP/s / {int(nprod)} split products per fp32 product" if split
-                                       else "fp32 MFMA v_mfma_f32_32x32x2_f32"),
-                        "frac_of_six_product_peak": round(per_kernel[dom]["tflops"] / (BF16_MFMA_PEAK_TFLOPS / 6.0), 4),
-                        "frac_of_fp32_mfma_peak": round(per_kernel[dom]["tflops"] / FP32_MFMA_PEAK_TFLOPS, 4),
-                        "traffic": traffic, "traffic_source": tsrc, "avg_launch_ms": per_kernel[dom]["ms"],
-                        "whole_step_tflops": round(value / world * FLOP_PER_RAY_TRAIN / 1e12, 2),
-                        "whole_step_frac_of_peak": round(value / world * FLOP_PER_RAY_TRAIN / 1e12 / peak, 4),
-                        "whole_step_frac_of_six_product_peak": round(value / world * FLOP_PER_RAY_TRAIN / 1e12 / (BF16_MFMA_PEAK_TFLOPS / 6.0), 4),
-                        "whole_step_frac_of_fp32_mfma_peak": round(value / world * FLOP_PER_RAY_TRAIN / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4)}
+                ntile = (P + 63) // 64
                 for k, v in per_kernel.items():
                     if "tflops" in v:
                         v["kernel"] = names.get(k)
                         v["frac_of_peak"] = round(v["tflops"] / peak, 4)
+                    if k in STAGE_TILES:
+                        nbytes = ntile * (STAGE_TILES[k][0] * 65536 + STAGE_TILES[k][1] * 16384)
+                        v["algorithmic_hbm_bytes"] = nbytes
+                        v["hbm_gbps"] = round(nbytes / (v["ms"] * 1e-3) / 1e9, 1)
+                        v["frac_of_hbm_peak"] = round(nbytes / (v["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)
+                # which roofline bounds the dominant kernel: the one that allows it the LONGER time.  With three products per fp32
+                # product the saved-tile kernels (tangent, backward, weight gradients) have more HBM time than matrix time.
+                d = per_kernel[dom]
+                t_mfma = 2.0 * MACS[dom] * pts.get(dom, P) / (peak * 1e12)
+                t_hbm = d.get("algorithmic_hbm_bytes", 0) / (HBM_PEAK_GBPS * 1e9)
+                mfma_view = {"achieved_tflops": d["tflops"], "peak_tflops": round(peak, 1), "frac": round(d["tflops"] / peak, 4),
+                             "peak_basis": (f"fp16 / bf16 dense MFMA 2500 TFLOP/s / {int(nprod)} split products per fp32 product" if split
+                                            else "fp32 MFMA v_mfma_f32_32x32x2_f32"),
+                             "frac_of_six_product_peak": round(d["tflops"] / (BF16_MFMA_PEAK_TFLOPS / 6.0), 4),
+                             "frac_of_fp32_mfma_peak": round(d["tflops"] / FP32_MFMA_PEAK_TFLOPS, 4)}
+                if t_hbm > t_mfma:
+                    roof = {"bound": "hbm", "kernel": names[dom], "stage": dom, "achieved": d["hbm_gbps"], "peak": HBM_PEAK_GBPS,
+                            "unit": "GB/s", "frac": d["frac_of_hbm_peak"],
+                            "frac_of_achievable_6290": round(d["hbm_gbps"] / HBM_ACHIEVABLE_GBPS, 4),
+                            "algorithmic_bytes": d["algorithmic_hbm_bytes"],
+                            "why": f"at peak rates this launch needs {t_hbm * 1e3:.2f} ms of HBM time against {t_mfma * 1e3:.2f} ms of matrix time",
+                            "mfma_view": mfma_view}
+                else:
+                    roof = {"bound": "mfma", "kernel": names[dom], "stage": dom, "achieved": d["tflops"], "peak": round(peak, 1),
+                            "unit": "TFLOP/s", "frac": round(d["tflops"] / peak, 4), **{k: v for k, v in mfma_view.items() if k.startswith("peak_basis") or k.startswith("frac_of")},
+                            "hbm_view": {"achieved_gbps": d.get("hbm_gbps"), "frac": d.get("frac_of_hbm_peak")}}
+                step_tf = value / world * FLOP_PER_RAY_TRAIN / 1e12
+                step_bytes = sum(v.get("algorithmic_hbm_bytes", 0) for v in per_kernel.values())
+                roof.update({"traffic": traffic, "traffic_source": tsrc, "avg_launch_ms": d["ms"],
+                             "whole_step_tflops": round(step_tf, 2), "whole_step_frac_of_peak": round(step_tf / peak, 4),
+                             "whole_step_frac_of_six_product_peak": round(step_tf / (BF16_MFMA_PEAK_TFLOPS / 6.0), 4),
+                             "whole_step_frac_of_fp32_mfma_peak": round(step_tf / FP32_MFMA_PEAK_TFLOPS, 4),
+                             "whole_step_algorithmic_hbm_gbps": round(step_bytes / (ms * 1e-3) / 1e9, 1),
+                             "whole_step_frac_of_hbm_peak": round(step_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)})
                 workload = (f"custom_shoes-shaped synthetic seq, 512x512, {B} rays x (64+64) samples per rank, "
                             "NeuS SDF(8x256, skip 4, softplus100) + colour(4x256) MLP, full training iteration")
                 arithmetic = {"fp32_mfma": "fp32 everywhere, every GEMM on v_mfma_f32_32x32x2_f32 (--arithmetic fp32_mfma)",

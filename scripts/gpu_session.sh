@@ -1,23 +1,23 @@
 #!/bin/bash
-# The round-3 profile + bench-line call (one gpurun call, ~12 GPU-minutes): rocprofv3 stats + PMC passes of both families, the
-# traffic tables bench.py reads, then the verbatim bench lines that go to profiles/r03_bench_n1*.json.
+# The round-4 profile + bench-line call (one gpurun call, ~12 GPU-minutes): rocprofv3 stats + PMC passes of both families, the
+# traffic tables bench.py reads, then the verbatim bench lines that go to profiles/r04_bench_n1*.json.
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 export TMPDIR=/tmp
+R=r04
 bash scripts/prof.sh > gpurun_out/prof_neus.log 2>&1
-cp gpurun_out/prof_summary.json gpurun_out/r03_pmc_summary.json
-cp $(ls -t gpurun_out/keep/*_kernel_stats.csv | head -1) gpurun_out/r03_kernel_stats.csv
-python scripts/make_traffic_json.py gpurun_out/r03_pmc_summary.json gpurun_out/pmc_traffic.json > /dev/null
+cp gpurun_out/prof_summary.json gpurun_out/${R}_pmc_summary.json
+cp $(ls -t gpurun_out/keep/*_kernel_stats.csv | head -1) gpurun_out/${R}_kernel_stats.csv
+python scripts/make_traffic_json.py gpurun_out/${R}_pmc_summary.json gpurun_out/pmc_traffic.json > /dev/null
 bash scripts/prof.sh --family hash > gpurun_out/prof_hash.log 2>&1
-cp gpurun_out/prof_summary.json gpurun_out/r03_hash_pmc_summary.json
-cp $(ls -t gpurun_out/keep/*_kernel_stats.csv | head -1) gpurun_out/r03_hash_kernel_stats.csv
-python scripts/make_traffic_json.py gpurun_out/r03_hash_pmc_summary.json gpurun_out/pmc_traffic_hash.json hash > /dev/null
+cp gpurun_out/prof_summary.json gpurun_out/${R}_hash_pmc_summary.json
+cp $(ls -t gpurun_out/keep/*_kernel_stats.csv | head -1) gpurun_out/${R}_hash_kernel_stats.csv
+python scripts/make_traffic_json.py gpurun_out/${R}_hash_pmc_summary.json gpurun_out/pmc_traffic_hash.json hash > /dev/null
 cp gpurun_out/pmc_traffic.json gpurun_out/pmc_traffic_hash.json profiles/       # so that the bench lines below carry roofline.traffic
-python bench.py --steps 100 --warmup 20 > gpurun_out/r03_bench_n1.json 2> gpurun_out/bench_n1.err
-python bench.py --arithmetic fp32_mfma --steps 100 --warmup 20 --no-cpu-baseline > gpurun_out/r03_bench_n1_fp32_mfma.json 2> gpurun_out/bench_n1_fp32.err
-python bench.py --loss full --steps 100 --warmup 20 --no-cpu-baseline > gpurun_out/r03_bench_n1_full_loss.json 2> gpurun_out/bench_n1_full.err
-python bench.py --family hash --steps 100 --warmup 20 > gpurun_out/r03_bench_n1_hash.json 2> gpurun_out/bench_hash.err
-python bench.py --family hash --hash-sampler occgrid --steps 100 --warmup 20 --no-cpu-baseline > gpurun_out/r03_bench_n1_hash_occgrid.json 2> gpurun_out/bench_hash_occ.err
-python bench.py --gpus 1 --force-dist --backend nccl --steps 20 --warmup 5 --no-cpu-baseline > gpurun_out/r03_bench_n1_rccl_1rank.json 2> gpurun_out/bench_rccl.err
+python bench.py > gpurun_out/${R}_bench_n1.json 2> gpurun_out/bench_n1.err
+python bench.py --arithmetic split_bf16 --no-cpu-baseline --no-secondary > gpurun_out/${R}_bench_n1_split_bf16.json 2> gpurun_out/bench_n1_bf16.err
+python bench.py --arithmetic fp32_mfma --no-cpu-baseline --no-secondary > gpurun_out/${R}_bench_n1_fp32_mfma.json 2> gpurun_out/bench_n1_fp32.err
+python bench.py --family hash > gpurun_out/${R}_bench_n1_hash.json 2> gpurun_out/bench_hash.err
+python bench.py --gpus 1 --force-dist --backend nccl --steps 20 --warmup 5 --no-cpu-baseline --no-secondary > gpurun_out/${R}_bench_n1_rccl_1rank.json 2> gpurun_out/bench_rccl.err
 python scripts/host_overhead.py > gpurun_out/host_overhead_neus.log 2>&1
-for f in r03_bench_n1 r03_bench_n1_fp32_mfma r03_bench_n1_full_loss r03_bench_n1_hash r03_bench_n1_hash_occgrid r03_bench_n1_rccl_1rank; do echo "== $f"; head -c 330 gpurun_out/$f.json; echo; done
+for f in ${R}_bench_n1 ${R}_bench_n1_split_bf16 ${R}_bench_n1_fp32_mfma ${R}_bench_n1_hash ${R}_bench_n1_rccl_1rank; do echo "== $f"; head -c 330 gpurun_out/$f.json; echo; done

@@ -10,7 +10,7 @@ import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from dynhor_amd import _lib
 src, dst = sys.argv[1], sys.argv[2]
-mode = _lib.ARITH_FP32_MFMA if (len(sys.argv) > 3 and sys.argv[3] == "fp32_mfma") else _lib.ARITH_SPLIT_BF16
+mode = _lib.ARITH_NAMES.get(sys.argv[3], _lib.ARITH_DEFAULT) if len(sys.argv) > 3 else _lib.ARITH_DEFAULT
 p = json.load(open(src))
 out = {}
 missing = []

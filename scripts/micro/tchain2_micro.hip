@@ -134,6 +134,13 @@ __device__ __forceinline__ void ring_advance_read(Ring& R) {
 }
 // the MFMAs of a group, each followed by its share of the dealt epilogue (EPS micro-steps per MFMA) and, after MFMA DAI / DBI,
 // the LDS-DMA piece DA / DB (-1: none)
+// timing-only switches (wrong results, same instruction shape otherwise): what the LDS-DMA issue and the barrier cost
+#ifndef TC_NODMA
+#define TC_NODMA 0
+#endif
+#ifndef TC_NOBAR
+#define TC_NOBAR 0
+#endif
 template <class AR, int NB, int G, int EM, int EBASE, int DA, int DB, int I>
 __device__ __forceinline__ void group_steps(Acc& A, const AFrag<AR> (&a)[2], const Pieces<AR>& b, const f32x16& xE, Pieces<AR> (&bn)[2], EpiSt& st, Ring& R) {
     constexpr int NMF = 2 * AR::NPROD, EPS = 12 / NMF;
@@ -141,8 +148,8 @@ __device__ __forceinline__ void group_steps(Acc& A, const AFrag<AR> (&a)[2], con
     if constexpr (I < NMF) {
         mfma_step<AR, NB, G, I>(A, a, b);
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (I == DAI && DA >= 0) { ring_issue_one<AR, DA>(R); __builtin_amdgcn_sched_barrier(0); }
-        if constexpr (I == DBI && DB >= 0) { ring_issue_one<AR, DB>(R); __builtin_amdgcn_sched_barrier(0); }
+        if constexpr (!TC_NODMA && I == DAI && DA >= 0) { ring_issue_one<AR, DA>(R); __builtin_amdgcn_sched_barrier(0); }
+        if constexpr (!TC_NODMA && I == DBI && DB >= 0) { ring_issue_one<AR, DB>(R); __builtin_amdgcn_sched_barrier(0); }
         if constexpr (EM >= 0 && EM < NM) {
             epi_step<AR, EM, EBASE + EPS * I>(xE, bn, st);
             if constexpr (EPS == 2) epi_step<AR, EM, EBASE + EPS * I + 1>(xE, bn, st);
@@ -175,8 +182,8 @@ __device__ __forceinline__ void kstep(Acc& A, const Pieces<AR>& b, const f32x16&
     group_steps<AR, NB, 1, EM, EH * 48 + 12, B3 ? 5 : 3, -1, 0>(A, a1, b, xE, bn, st, R);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(dma_per_wave<AR>() * (DEPTH - 1)) : "memory");
-    asm volatile("s_barrier" ::: "memory");
+    if constexpr (!TC_NODMA) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(dma_per_wave<AR>() * (DEPTH - 1)) : "memory");
+    if constexpr (!TC_NOBAR) asm volatile("s_barrier" ::: "memory");
     read_group<AR, 3>(a1, R.rd_addr);
     __builtin_amdgcn_sched_barrier(0);
     group_steps<AR, NB, 2, EM, EH * 48 + 24, 0, B3 ? 1 : -1, 0>(A, a0, b, xE, bn, st, R);
@@ -211,6 +218,9 @@ __device__ __forceinline__ void layer(Acc& A, Pieces<AR> (&bA)[2], Pieces<AR> (&
     epi_only<AR, 0, 0, 96>((NB ? A.s0 : A.s1)[0], bA, st);
     if constexpr (!EPI) { bB[0] = bA[0]; bB[1] = bA[1]; }
     mpair<AR, NB, 0, EPI>(A, bA, bB, st, a0, a1, R);
+    if constexpr (!EPI) {          // rule 17: without the dealt epilogue nothing reads m-tiles 1..7 -- keep their MFMAs from being deleted
+        DH_UNROLL for (int m = 0; m < NM; ++m) asm volatile("" ::"v"((NB ? A.s1 : A.s0)[m]));
+    }
 }
 
 // EPI = 0: timing-only arm -- no dealt epilogue (the pieces of m-tile 0 feed every k-step): MFMA + weight ring alone
@@ -368,7 +378,8 @@ void* make_weights() {
     return d;
 }
 
-int main() {
+int main(int argc, char**) {
+    if (argc > 1) goto timing;           // any argument: skip the accuracy part
     accuracy("activations O(1), S_x = 1", 1.f, 0.f, 1.f, 16.f);
     accuracy("activations O(1), S_x = 16", 1.f, 0.f, 16.f, 16.f);
     accuracy("activations O(1), weights unscaled too", 1.f, 0.f, 1.f, 1.f);
@@ -376,6 +387,7 @@ int main() {
     accuracy("adjoints 1e-6, scaled to 2^9", 1e-6f, 0.f, 536870912.f, 16.f);
     accuracy("adjoints 1e-6 x e^(+-4), scaled to 2^9", 1e-6f, 4.f, 8388608.f, 16.f);
     accuracy("values 1e3, scaled to 2^9", 1e3f, 0.f, 0.5f, 16.f);
+timing:
     void* w3 = make_weights<ArB3>();
     void* w2 = make_weights<ArH2>();
     float* out; hipMalloc(&out, (size_t)512 * 256 * 4);
@@ -385,8 +397,8 @@ int main() {
     for (int round = 0; round < 3; ++round) {
         run_t<ArB3, 1>("bf16x3 chain (shipping core)", w3, out, clk, a, b, reps);
         run_t<ArH2, 1>("f16x2 chain", w2, out, clk, a, b, reps);
-        run_t<ArB3, 0>("bf16x3 bare MFMA + ring", w3, out, clk, a, b, reps);
-        run_t<ArH2, 0>("f16x2 bare MFMA + ring", w2, out, clk, a, b, reps);
+        run_t<ArB3, 0>("bf16x3 bare MFMA + ring (accumulators kept alive)", w3, out, clk, a, b, reps);
+        run_t<ArH2, 0>("f16x2 bare MFMA + ring (accumulators kept alive)", w2, out, clk, a, b, reps);
     }
     hipError_t e = hipDeviceSynchronize();
     printf("status: %s\n", hipGetErrorString(e));
