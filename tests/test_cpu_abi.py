@@ -110,7 +110,7 @@ def test_stage_kernel_table_names_kernels_that_exist_in_the_library():
     names = {k for table in _lib.STAGE_KERNELS.values() for k in table.values()} | set(_lib.HASH_STAGE_KERNELS.values())
     for k in sorted(names):
         assert k.encode() in blob, f"{k} is not a kernel of libdynhor_hip.so (stale STAGE_KERNELS entry)"
-    assert set(_lib.STAGE_KERNELS[0]) == set(_lib.STAGE_KERNELS[1]), "both arithmetic modes list the same stages"
+    assert set(_lib.STAGE_KERNELS[0]) == set(_lib.STAGE_KERNELS[1]) == set(_lib.STAGE_KERNELS[2]), "all arithmetic modes list the same stages"
 
 
 def test_traffic_tool_rejects_a_profile_that_lacks_a_shipping_kernel(tmp_path):
@@ -119,20 +119,21 @@ def test_traffic_tool_rejects_a_profile_that_lacks_a_shipping_kernel(tmp_path):
     import sys
     from dynhor_amd import _lib
     entry = {"FETCH_SIZE": {"mean_per_dispatch": 1000.0, "dispatches": 3}, "WRITE_SIZE": {"mean_per_dispatch": 500.0, "dispatches": 3}}
-    full = {"prof_pmc2": {k: entry for k in _lib.STAGE_KERNELS[0].values()}, "prof_pmc3": {k: entry for k in _lib.STAGE_KERNELS[0].values()}}
+    ship = _lib.STAGE_KERNELS[_lib.ARITH_DEFAULT]
+    full = {"prof_pmc2": {k: entry for k in ship.values()}, "prof_pmc3": {k: entry for k in ship.values()}}
     src, dst = tmp_path / "pmc.json", tmp_path / "traffic.json"
     json.dump(full, open(src, "w"))
     tool = os.path.join(ROOT, "scripts", "make_traffic_json.py")
     p = subprocess.run([sys.executable, tool, str(src), str(dst)], capture_output=True, text=True)
     assert p.returncode == 0, p.stderr
     out = json.load(open(dst))
-    assert out["weight_grads_gemm"]["kernel"] == "dw_bf16x3_kernel"
+    assert out["weight_grads_gemm"]["kernel"] == ship["weight_grads_gemm"] == "dw_f16x2_kernel"
     assert out["weight_grads_gemm"]["hbm_bytes_per_launch"] == 1000.0 * 1024 * 2 + 500.0 * 1024      # FETCH_SIZE x2 on gfx950
     stale = {"prof_pmc2": dict(full["prof_pmc2"]), "prof_pmc3": dict(full["prof_pmc3"])}
-    del stale["prof_pmc2"]["sdf_tangent_s_kernel"]                                                  # e.g. a renamed kernel
+    del stale["prof_pmc2"]["sdf_tangent_h_kernel"]                                                  # e.g. a renamed kernel
     json.dump(stale, open(src, "w"))
     p = subprocess.run([sys.executable, tool, str(src), str(dst)], capture_output=True, text=True)
-    assert p.returncode != 0 and "sdf_tangent_s_kernel" in (p.stderr + p.stdout)
+    assert p.returncode != 0 and "sdf_tangent_h_kernel" in (p.stderr + p.stdout)
 
 
 def test_committed_profiles_name_the_shipping_kernels():
@@ -142,16 +143,16 @@ def test_committed_profiles_name_the_shipping_kernels():
     import json
     import re
     from dynhor_amd import _lib
-    ship = _lib.STAGE_KERNELS[_lib.ARITH_SPLIT_BF16]
+    ship = _lib.STAGE_KERNELS[_lib.ARITH_DEFAULT]
     traffic = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
     for stage, e in traffic.items():
         assert ship.get(stage) == e["kernel"], (stage, e["kernel"], ship.get(stage))
     names = set()
-    for r in csv.DictReader(open(os.path.join(ROOT, "profiles", "r03_kernel_stats.csv"))):
+    for r in csv.DictReader(open(os.path.join(ROOT, "profiles", "r04_kernel_stats.csv"))):
         names.add(re.sub(r"[<(].*", "", re.sub(r"^dh::", "", re.sub(r"^void ", "", r["Name"]))))
     missing = sorted(set(ship.values()) - names)
-    assert not missing, f"profiles/r03_kernel_stats.csv lacks shipping kernels {missing}"
-    line = json.loads(open(os.path.join(ROOT, "profiles", "r03_bench_n1.json")).read().strip().split("\n")[-1])
+    assert not missing, f"profiles/r04_kernel_stats.csv lacks shipping kernels {missing}"
+    line = json.loads(open(os.path.join(ROOT, "profiles", "r04_bench_n1.json")).read().strip().split("\n")[-1])
     assert line["roofline"]["kernel"] == ship[line["roofline"]["stage"]]
     for stage, v in line["kernels"].items():
         if "kernel" in v:
@@ -160,4 +161,4 @@ def test_committed_profiles_name_the_shipping_kernels():
     import subprocess
     import sys
     p = subprocess.run([sys.executable, table], capture_output=True, text=True)
-    assert p.returncode == 0 and "dw_bf16x3_kernel" in p.stdout, p.stderr
+    assert p.returncode == 0 and "dw_f16x2_kernel" in p.stdout, p.stderr
