@@ -18,6 +18,10 @@
 
 namespace dh {
 
+#ifndef H2_LEAN2
+#define H2_LEAN2 true            // development macro: the GEMM form of the two kernels with two saved-tile input streams (tile16h.h)
+#endif
+
 // tile partial-sum slots (workspace.h: tpart [nt][N_TILE_PART][256]) -- as kernels_mlp_bwd.hip
 enum : int { TP_SDF_B0 = 0, TP_SDF_B8 = 8, TP_W8ROW0_T = 9, TP_W8ROW0_S = 10, TP_SCAL = 11, TP_COL_B0 = 12,
              TP_COL_W4 = 16, TP_COL_B4 = 19 };
@@ -78,7 +82,7 @@ __device__ __forceinline__ void hs_init(HScratch& h, int tid) { if (tid < 12) h.
 // tile's scale, write the scaled image.  Returns the scale (S, 1 / S).
 // extra_max / extra_lds: a second operand that will share the accumulator (and hence the scale) of the GEMM that reads this image
 // tslot: where this tile's maximum goes for the weight-gradient kernel (workspace.h tmax), or nullptr
-__device__ __forceinline__ TileScale lds_handoff(const f32x16 (&acc)[MT][2], float* smain, HScratch& hs, float* lmax, int tid,
+__device__ __forceinline__ TileScale lds_handoff(const f32x16 (&acc)[MT][2], _Float16* smain, HScratch& hs, float* lmax, int tid,
                                                  int wave, int lane, float extra_max = 0.f, const float* extra_lds = nullptr,
                                                  unsigned* tslot = nullptr) {
     tile_max_publish(hs.sred, wave, lane, acc_absmax(acc));
@@ -90,7 +94,7 @@ __device__ __forceinline__ TileScale lds_handoff(const f32x16 (&acc)[MT][2], flo
     }
     if (extra_lds) extra_max = fmaxf(extra_max, *extra_lds);
     const TileScale ts = scale_for_max(fmaxf(m, extra_max));
-    acc_to_lds_scaled(acc, smain, wave, lane, ts.S);
+    acc_to_lds_split(acc, smain, wave, lane, ts.S);
     __syncthreads();
     return ts;
 }
@@ -101,10 +105,11 @@ __global__ __launch_bounds__(256, 2) void color_fwd_h_kernel(ColHPtrs C, const f
                                                             const float* __restrict__ feat, int64_t npts,
                                                             float* __restrict__ color, float* __restrict__ cact,
                                                             float* __restrict__ caux, int save, unsigned* __restrict__ absmax) {
-    __shared__ __attribute__((aligned(16))) float smain[TM * LDX];
+    __shared__ __attribute__((aligned(16))) _Float16 smain[IMG_H];
     __shared__ __attribute__((aligned(16))) float saux[TM * LDA];
     __shared__ HScratch hs;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int loff = tile_loff(wave, lane);
     const int64_t ntiles = (npts + TM - 1) / TM;
     hs_init(hs, tid);
     float winv[4];
@@ -136,24 +141,24 @@ __global__ __launch_bounds__(256, 2) void color_fwd_h_kernel(ColHPtrs C, const f
             if (lane == 0) hs.sred2[0] = mx;
         }
         f32x16 acc[MT][2];
-        acc_load_native(acc, feat + tile * TILE_F, wave, lane);
+        acc_load_native_b(acc, tile_rsrc(feat + tile * TILE_F), loff);
         // (the barrier inside also publishes saux; the previous tile ended with one, so the images are free).  The extras [p,
         // embed(view), n] share layer 0's accumulator with feat: one scale for both, from the larger of the two maxima
         TileScale ts = lds_handoff(acc, smain, hs, save ? &hs.lmax[4] : nullptr, tid, wave, lane, 0.f, &hs.sred2[0]);
         if (save) aux_lds_to_native(saux, caux + tile * AUXT_F, wave, lane);
         for (int l = 0; l < 4; ++l) {
             acc_zero(acc);
-            gemm_rows_h(acc, smain, LDX, 16, C.main[l], wave, lane);
+            gemm_rows_hp(acc, smain, 16, C.main[l], wave, lane);
             const float inv = ts.inv * winv[l];
-            if (l == 0) gemm_rows_h<true>(acc, saux, LDA, AUX_KC, C.aux, wave, lane, ts.S);
+            if (l == 0) gemm_rows_aux_h(acc, saux, C.aux, wave, lane, ts.S);
             const float b0 = C.bias[l][acc_col(wave, 0, lane)], b1 = C.bias[l][acc_col(wave, 1, lane)];
             acc_map(acc, [&](int, int t, int, float v) { return fmaxf(fmaf(v, inv, t ? b1 : b0), 0.f); });
-            if (save) acc_store_native(acc, cact + ((int64_t)l * ntiles + tile) * TILE_F, wave, lane);
+            if (save) acc_store_native_b(acc, tile_rsrc(cact + ((int64_t)l * ntiles + tile) * TILE_F), loff);
             ts = lds_handoff(acc, smain, hs, save ? &hs.lmax[l] : nullptr, tid, wave, lane);
         }
         const int64_t gp = tile * TM + tid / TPP;
         DH_UNROLL for (int j = 0; j < 3; ++j) {
-            const float raw = fmaf(row_dot256(smain, C.w4 + j * 256, tid), ts.inv, C.b4[j]);
+            const float raw = fmaf(row_dot256_hp(smain, C.w4 + j * 256, tid), ts.inv, C.b4[j]);
             if (tid % TPP == 0 && gp < npts) color[gp * 3 + j] = 1.f / (1.f + __expf(-raw));
         }
         __syncthreads();
@@ -169,10 +174,11 @@ __global__ __launch_bounds__(256, 2) void sdf_grad_h_kernel(SdfHPtrs P, const fl
                                                            const float* __restrict__ act, float* __restrict__ asave,
                                                            float* __restrict__ normals, int save, float* __restrict__ gesave,
                                                            unsigned* __restrict__ absmax) {
-    __shared__ __attribute__((aligned(16))) float smain[TM * LDX];
+    __shared__ __attribute__((aligned(16))) _Float16 smain[IMG_H];
     __shared__ __attribute__((aligned(16))) float saux[TM * LDA];
     __shared__ HScratch hs;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int loff = tile_loff(wave, lane);
     const int64_t ntiles = (npts + TM - 1) / TM;
     hs_init(hs, tid);
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -183,39 +189,43 @@ __global__ __launch_bounds__(256, 2) void sdf_grad_h_kernel(SdfHPtrs P, const fl
         // a_7 = W8[0,:] * sigma'(z_7)
         {
             const float w0 = P.w8row0[acc_col(wave, 0, lane)], w1 = P.w8row0[acc_col(wave, 1, lane)];
-            acc_load_native(acc, act + ((int64_t)7 * ntiles + tile) * TILE_F, wave, lane);
+            acc_load_native_b(acc, tile_rsrc(act + ((int64_t)7 * ntiles + tile) * TILE_F), loff);
             acc_map(acc, [&](int, int t, int, float h) { float s, em; softplus_deriv_from_h(h, s, em); return (t ? w1 : w0) * s; });
-            if (save) acc_store_native(acc, asave + ((int64_t)7 * ntiles + tile) * TILE_F, wave, lane);
+            if (save) acc_store_native_b(acc, tile_rsrc(asave + ((int64_t)7 * ntiles + tile) * TILE_F), loff);
             ts = lds_handoff(acc, smain, hs, &hs.lmax[7], tid, wave, lane);
         }
         for (int l = 7; l >= 1; --l) {
             acc_zero(acc);
-            gemm_rows_h(acc, smain, LDX, 16, P.rev[l], wave, lane);                 // u_l = a_l W_l
+            // sigma' comes from act[l-1] == the input of layer l: its first m-slab is requested inside the GEMM's last chunks
+            const rsrc_t hr = tile_rsrc(act + ((int64_t)(l - 1) * ntiles + tile) * TILE_F);
+            Slab h0, h1;
+            gemm_rows_hp<false>(acc, smain, 16, P.rev[l], wave, lane, [&] { slab_ld(h0, hr, loff, 0); });      // u_l = a_l W_l
+            slab_ld(h1, hr, loff, 1);
             const float inv = ts.inv * winv_from_bits(P.wabs[l]);
             if (l == 4) {                                                         // skip path -> ge (true units)
-                gemm_auxout_h(ge, smain, 16, P.revaux[4], wave, lane);
+                gemm_auxout_hp(ge, smain, 16, P.revaux[4], wave, lane);
                 DH_UNROLL for (int tt = 0; tt < AUX_NTW; ++tt) DH_UNROLL for (int r = 0; r < 16; ++r) ge[tt][r] *= inv;
             }
-            // a_{l-1} = u_l * sigma'(z_{l-1})   (sigma' from act[l-1] == input of layer l)
-            const f32x4* hp = reinterpret_cast<const f32x4*>(act + ((int64_t)(l - 1) * ntiles + tile) * TILE_F) + (size_t)wave * MT * 8 * 64 + lane;
+            // a_{l-1} = u_l * sigma'(z_{l-1})
             DH_UNROLL for (int m = 0; m < MT; ++m) {
+                const Slab& hs_ = m ? h1 : h0;
                 DH_UNROLL for (int t = 0; t < 2; ++t)
                     DH_UNROLL for (int r4 = 0; r4 < 4; ++r4) {
-                        const f32x4 h = DH_TILE_LD(hp + ((m * 2 + t) * 4 + r4) * 64);
+                        const f32x4 h = hs_.v[t * 4 + r4];
                         DH_UNROLL for (int rr = 0; rr < 4; ++rr) {
                             float s, em; softplus_deriv_from_h(h[rr], s, em);
                             acc[m][t][4 * r4 + rr] *= s * inv;
                         }
                     }
-                __builtin_amdgcn_sched_barrier(0);     // bound live registers: one m-slab (8 float4) in flight
+                __builtin_amdgcn_sched_barrier(0);
             }
-            if (save) acc_store_native(acc, asave + ((int64_t)(l - 1) * ntiles + tile) * TILE_F, wave, lane);
+            if (save) acc_store_native_b(acc, tile_rsrc(asave + ((int64_t)(l - 1) * ntiles + tile) * TILE_F), loff);
             ts = lds_handoff(acc, smain, hs, &hs.lmax[l - 1], tid, wave, lane);
         }
         {                                                                         // ge += a_0 W_0
             f32x16 g0[AUX_NTW];
             aux_zero(g0);
-            gemm_auxout_h(g0, smain, 16, P.revaux[0], wave, lane);
+            gemm_auxout_hp(g0, smain, 16, P.revaux[0], wave, lane);
             const float inv = ts.inv * winv_from_bits(P.wabs[0]);
             DH_UNROLL for (int tt = 0; tt < AUX_NTW; ++tt) DH_UNROLL for (int r = 0; r < 16; ++r) ge[tt][r] = fmaf(g0[tt][r], inv, ge[tt][r]);
         }
@@ -261,10 +271,11 @@ __global__ __launch_bounds__(256, 2) void color_bwd_h_kernel(ColHPtrs C, const f
                                                             int n_per_ray, float* __restrict__ d_pts,
                                                             float* __restrict__ d_dirs_pts, unsigned* __restrict__ absmax,
                                                             unsigned* __restrict__ tmax) {
-    __shared__ __attribute__((aligned(16))) float smain[TM * LDX];
+    __shared__ __attribute__((aligned(16))) _Float16 smain[IMG_H];
     __shared__ __attribute__((aligned(16))) float saux[TM * LDA];     // scratch: craw [128][4]
     __shared__ HScratch hs;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int loff = tile_loff(wave, lane);
     const int64_t ntiles = (npts + TM - 1) / TM;
     hs_init(hs, tid);
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -286,7 +297,7 @@ __global__ __launch_bounds__(256, 2) void color_bwd_h_kernel(ColHPtrs C, const f
         }
         f32x16 acc[MT][2];
         // lin4: dW4 partials, zbar_3 = (craw W4) * [h4 > 0]
-        acc_load_native(acc, cact + ((int64_t)3 * ntiles + tile) * TILE_F, wave, lane);
+        acc_load_native_b(acc, tile_rsrc(cact + ((int64_t)3 * ntiles + tile) * TILE_F), loff);
         {
             const int col0 = acc_col(wave, 0, lane), col1 = acc_col(wave, 1, lane);
             float w4[3][2];
@@ -309,37 +320,40 @@ __global__ __launch_bounds__(256, 2) void color_bwd_h_kernel(ColHPtrs C, const f
                     if (lane < 32) tp[(TP_COL_W4 + j) * 256 + 64 * wave + 32 * t + lane] = s;
                 }
         }
-        acc_store_native(acc, czbar + ((int64_t)3 * ntiles + tile) * TILE_F, wave, lane);
+        acc_store_native_b(acc, tile_rsrc(czbar + ((int64_t)3 * ntiles + tile) * TILE_F), loff);
         tile_colsum(acc, tp + (TP_COL_B0 + 3) * 256, wave, lane);
         TileScale ts = lds_handoff(acc, smain, hs, &hs.lmax[3], tid, wave, lane, 0.f, nullptr, tmax + (TMAX_CZBAR + 3) * ntiles + tile);
         for (int l = 3; l >= 1; --l) {
             acc_zero(acc);
-            gemm_rows_h(acc, smain, LDX, 16, C.rev[l], wave, lane);                        // hbar_l = zbar_l W_l
+            const rsrc_t hr = tile_rsrc(cact + ((int64_t)(l - 1) * ntiles + tile) * TILE_F);
+            Slab h0, h1;
+            gemm_rows_hp<false>(acc, smain, 16, C.rev[l], wave, lane, [&] { slab_ld(h0, hr, loff, 0); });      // hbar_l = zbar_l W_l
+            slab_ld(h1, hr, loff, 1);
             const float inv = ts.inv * winv_from_bits(C.wabs[l]);
-            const f32x4* hp = reinterpret_cast<const f32x4*>(cact + ((int64_t)(l - 1) * ntiles + tile) * TILE_F) + (size_t)wave * MT * 8 * 64 + lane;
             DH_UNROLL for (int m = 0; m < MT; ++m) {
+                const Slab& hs_ = m ? h1 : h0;
                 DH_UNROLL for (int t = 0; t < 2; ++t)
                     DH_UNROLL for (int r4 = 0; r4 < 4; ++r4) {
-                        const f32x4 h = DH_TILE_LD(hp + ((m * 2 + t) * 4 + r4) * 64);
+                        const f32x4 h = hs_.v[t * 4 + r4];
                         DH_UNROLL for (int rr = 0; rr < 4; ++rr)
                             acc[m][t][4 * r4 + rr] = h[rr] > 0.f ? acc[m][t][4 * r4 + rr] * inv : 0.f;
                     }
                 __builtin_amdgcn_sched_barrier(0);
             }
-            acc_store_native(acc, czbar + ((int64_t)(l - 1) * ntiles + tile) * TILE_F, wave, lane);
+            acc_store_native_b(acc, tile_rsrc(czbar + ((int64_t)(l - 1) * ntiles + tile) * TILE_F), loff);
             tile_colsum(acc, tp + (TP_COL_B0 + l - 1) * 256, wave, lane);
             ts = lds_handoff(acc, smain, hs, &hs.lmax[l - 1], tid, wave, lane, 0.f, nullptr, tmax + (TMAX_CZBAR + l - 1) * ntiles + tile);
         }
         // lin0: featbar = zbar_0 W0[:,33:] ; extras adjoint = zbar_0 W0[:,:33] (only the normal columns 30..32 matter)
         const float inv0 = ts.inv * winv_from_bits(C.wabs[0]);
         acc_zero(acc);
-        gemm_rows_h(acc, smain, LDX, 16, C.rev[0], wave, lane);
+        gemm_rows_hp(acc, smain, 16, C.rev[0], wave, lane);
         acc_map(acc, [&](int, int, int, float v) { return v * inv0; });
-        acc_store_native(acc, featbar + tile * TILE_F, wave, lane);
+        acc_store_native_b(acc, tile_rsrc(featbar + tile * TILE_F), loff);
         tile_max_publish(hs.sred2, wave, lane, acc_absmax(acc));       // featbar's maxima: read behind the barrier that ends the tile
         f32x16 a2[AUX_NTW];
         aux_zero(a2);
-        gemm_auxout_h(a2, smain, 16, C.revaux, wave, lane);
+        gemm_auxout_hp(a2, smain, 16, C.revaux, wave, lane);
         DH_UNROLL for (int tt = 0; tt < AUX_NTW; ++tt) DH_UNROLL for (int r = 0; r < 16; ++r) a2[tt][r] *= inv0;
         DH_UNROLL for (int tt = 0; tt < AUX_NTW; ++tt) {
             const int col = aux_col(wave, tt, lane);
@@ -399,10 +413,11 @@ __global__ __launch_bounds__(256, 2) void sdf_tangent_h_kernel(SdfHPtrs P, const
                                                               float* __restrict__ t0aux, float* __restrict__ tsave,
                                                               float* __restrict__ rsave, float* __restrict__ tpart,
                                                               unsigned* __restrict__ absmax, unsigned* __restrict__ tmax) {
-    __shared__ __attribute__((aligned(16))) float smain[TM * LDX];
+    __shared__ __attribute__((aligned(16))) _Float16 smain[IMG_H];
     __shared__ __attribute__((aligned(16))) float saux[TM * LDA];
     __shared__ HScratch hs;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int loff = tile_loff(wave, lane);
     const int64_t ntiles = (npts + TM - 1) / TM;
     hs_init(hs, tid);
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -440,19 +455,20 @@ __global__ __launch_bounds__(256, 2) void sdf_tangent_h_kernel(SdfHPtrs P, const
         TileScale ts = ts_aux;
         for (int l = 0; l < 8; ++l) {
             acc_zero(acc);
+            const rsrc_t hr = tile_rsrc(act + ((int64_t)l * ntiles + tile) * TILE_F);
+            const rsrc_t ar = tile_rsrc(asave + ((int64_t)l * ntiles + tile) * TILE_F);
+            const rsrc_t rr_ = tile_rsrc(rsave + ((int64_t)l * ntiles + tile) * TILE_F);
             // l == 4: the main image (t_4) was written at the scale of max(|t_4|, |t_0|) so that both GEMMs share one accumulator
-            if (l > 0) gemm_rows_h(acc, smain, LDX, l == 4 ? 14 : 16, P.main[l], wave, lane);
-            if (l == 0 || l == 4) gemm_rows_h<true>(acc, saux, LDA, AUX_KC, P.aux[l], wave, lane, ts.S);     // abar_l
+            if (l > 0) gemm_rows_hp<H2_LEAN2>(acc, smain, l == 4 ? 14 : 16, P.main[l], wave, lane);
+            if (l == 0 || l == 4) gemm_rows_aux_h(acc, saux, P.aux[l], wave, lane, ts.S);     // abar_l
             const float inv = ts.inv * winv_from_bits(P.wabs[l]);
-            const size_t woff = (size_t)wave * MT * 8 * 64 + lane;
-            const f32x4* hp = reinterpret_cast<const f32x4*>(act + ((int64_t)l * ntiles + tile) * TILE_F) + woff;
-            const f32x4* ap = reinterpret_cast<const f32x4*>(asave + ((int64_t)l * ntiles + tile) * TILE_F) + woff;
-            f32x4* rp = reinterpret_cast<f32x4*>(rsave + ((int64_t)l * ntiles + tile) * TILE_F) + woff;
             DH_UNROLL for (int m = 0; m < MT; ++m) {
+                // (two input streams: one m-slab of each in flight is what the register file holds beside the accumulators)
+                Slab hs_, as_;
+                slab_ld(hs_, hr, loff, m); slab_ld(as_, ar, loff, m);
                 DH_UNROLL for (int t = 0; t < 2; ++t)
                     DH_UNROLL for (int r4 = 0; r4 < 4; ++r4) {
-                        const int idx = ((m * 2 + t) * 4 + r4) * 64;
-                        const f32x4 h = DH_TILE_LD(hp + idx), a = DH_TILE_LD(ap + idx);
+                        const f32x4 h = hs_.v[t * 4 + r4], a = as_.v[t * 4 + r4];
                         f32x4 rv;
                         DH_UNROLL for (int rr = 0; rr < 4; ++rr) {
                             float s, em; softplus_deriv_from_h(h[rr], s, em);
@@ -460,12 +476,12 @@ __global__ __launch_bounds__(256, 2) void sdf_tangent_h_kernel(SdfHPtrs P, const
                             rv[rr] = ab * a[rr] * (SOFTPLUS_BETA * em);
                             acc[m][t][4 * r4 + rr] = s * ab;
                         }
-                        DH_TILE_ST(rp + idx, rv);
+                        tile_st(rr_, loff, (m * 2 + t) * 4 + r4, rv);
                     }
                 __builtin_amdgcn_sched_barrier(0);
             }
             if (l < 7) {
-                acc_store_native(acc, tsave + ((int64_t)l * ntiles + tile) * TILE_F, wave, lane);    // t_{l+1}
+                acc_store_native_b(acc, tile_rsrc(tsave + ((int64_t)l * ntiles + tile) * TILE_F), loff);    // t_{l+1}
                 ts = lds_handoff(acc, smain, hs, &hs.lmax[l], tid, wave, lane, l == 3 ? m_aux : 0.f, nullptr, tmax + (TMAX_TSAVE + l) * ntiles + tile);
             } else {
                 tile_colsum(acc, tp + TP_W8ROW0_T * 256, wave, lane);                                 // colsum t_8
@@ -488,10 +504,11 @@ __global__ __launch_bounds__(256, 2) void sdf_bwd_h_kernel(SdfHPtrs P, const flo
                                                           const float* __restrict__ d_normals, const float* __restrict__ gesave,
                                                           float* __restrict__ d_pts, unsigned* __restrict__ absmax,
                                                           unsigned* __restrict__ tmax) {
-    __shared__ __attribute__((aligned(16))) float smain[TM * LDX];
+    __shared__ __attribute__((aligned(16))) _Float16 smain[IMG_H];
     __shared__ __attribute__((aligned(16))) float saux[TM * LDA];     // scratch: sdfbar [128]
     __shared__ HScratch hs;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int loff = tile_loff(wave, lane);
     const int64_t ntiles = (npts + TM - 1) / TM;
     hs_init(hs, tid);
     const float w0c0 = P.w8row0[acc_col(wave, 0, lane)], w0c1 = P.w8row0[acc_col(wave, 1, lane)];
@@ -504,7 +521,7 @@ __global__ __launch_bounds__(256, 2) void sdf_bwd_h_kernel(SdfHPtrs P, const flo
         f32x16 acc[MT][2];
         f32x16 eb[AUX_NTW];
         if (RAYS) aux_zero(eb);
-        acc_load_native(acc, featbar + tile * TILE_F, wave, lane);
+        acc_load_native_b(acc, tile_rsrc(featbar + tile * TILE_F), loff);
         tile_colsum(acc, tp + TP_SDF_B8 * 256, wave, lane);
         TileScale ts = lds_handoff(acc, smain, hs, nullptr, tid, wave, lane);      // (featbar's class maximum: the colour backward)
         if (wave == 0) {                                       // sum of sdfbar -> bbar_8[0]
@@ -515,7 +532,7 @@ __global__ __launch_bounds__(256, 2) void sdf_bwd_h_kernel(SdfHPtrs P, const flo
         }
         // hbar_8 = featbar W8[1:,:] + sdfbar (x) W8[0,:]
         acc_zero(acc);
-        gemm_rows_h(acc, smain, LDX, 16, P.rev[8], wave, lane);
+        gemm_rows_hp<H2_LEAN2>(acc, smain, 16, P.rev[8], wave, lane);
         {
             const float inv = ts.inv * winv_from_bits(P.wabs[8]);
             DH_UNROLL for (int m = 0; m < MT; ++m)
@@ -526,15 +543,14 @@ __global__ __launch_bounds__(256, 2) void sdf_bwd_h_kernel(SdfHPtrs P, const flo
                 }
         }
         for (int l = 7; l >= 0; --l) {
-            const size_t woff = (size_t)wave * MT * 8 * 64 + lane;
-            const f32x4* hp = reinterpret_cast<const f32x4*>(act + ((int64_t)l * ntiles + tile) * TILE_F) + woff;
-            const f32x4* rp = reinterpret_cast<const f32x4*>(rsave + ((int64_t)l * ntiles + tile) * TILE_F) + woff;
             float ws0 = 0.f, ws1 = 0.f;                         // sum_rows sdfbar * h_8 (l == 7 only)
             DH_UNROLL for (int m = 0; m < MT; ++m) {
+                Slab hs_, rs_;
+                slab_ld(hs_, tile_rsrc(act + ((int64_t)l * ntiles + tile) * TILE_F), loff, m);
+                slab_ld(rs_, tile_rsrc(rsave + ((int64_t)l * ntiles + tile) * TILE_F), loff, m);
                 DH_UNROLL for (int t = 0; t < 2; ++t)
                     DH_UNROLL for (int r4 = 0; r4 < 4; ++r4) {
-                        const int idx = ((m * 2 + t) * 4 + r4) * 64;
-                        const f32x4 h = DH_TILE_LD(hp + idx), rv = DH_TILE_LD(rp + idx);
+                        const f32x4 h = hs_.v[t * 4 + r4], rv = rs_.v[t * 4 + r4];
                         DH_UNROLL for (int rr = 0; rr < 4; ++rr) {
                             float s, em; softplus_deriv_from_h(h[rr], s, em);
                             if (l == 7) {
@@ -553,24 +569,24 @@ __global__ __launch_bounds__(256, 2) void sdf_bwd_h_kernel(SdfHPtrs P, const flo
                     tp[TP_W8ROW0_S * 256 + 64 * wave + 32 + lane] = ws1;
                 }
             }
-            acc_store_native(acc, zbar + ((int64_t)l * ntiles + tile) * TILE_F, wave, lane);
+            acc_store_native_b(acc, tile_rsrc(zbar + ((int64_t)l * ntiles + tile) * TILE_F), loff);
             tile_colsum(acc, tp + (TP_SDF_B0 + l) * 256, wave, lane);
             if (l > 0) {
                 ts = lds_handoff(acc, smain, hs, &hs.lmax[l], tid, wave, lane, 0.f, nullptr, tmax + (TMAX_ZBAR + l) * ntiles + tile);
                 const float inv = ts.inv * winv_from_bits(P.wabs[l]);
                 if (RAYS && l == 4) {                                                // skip path -> ebar (true units)
-                    gemm_auxout_h(eb, smain, 16, P.revaux[4], wave, lane);
+                    gemm_auxout_hp(eb, smain, 16, P.revaux[4], wave, lane);
                     DH_UNROLL for (int tt = 0; tt < AUX_NTW; ++tt) DH_UNROLL for (int r = 0; r < 16; ++r) eb[tt][r] *= inv;
                 }
                 acc_zero(acc);
-                gemm_rows_h(acc, smain, LDX, 16, P.rev[l], wave, lane);             // hbar_l = zbar_l W_l
+                gemm_rows_hp<H2_LEAN2>(acc, smain, 16, P.rev[l], wave, lane);             // hbar_l = zbar_l W_l
                 acc_map(acc, [&](int, int, int, float v) { return v * inv; });
             } else if (RAYS) {
                 ts = lds_handoff(acc, smain, hs, &hs.lmax[0], tid, wave, lane, 0.f, nullptr, tmax + TMAX_ZBAR * ntiles + tile);      // zbar_0
                 {
                     f32x16 e0[AUX_NTW];
                     aux_zero(e0);
-                    gemm_auxout_h(e0, smain, 16, P.revaux[0], wave, lane);           // ebar += zbar_0 W_0
+                    gemm_auxout_hp(e0, smain, 16, P.revaux[0], wave, lane);           // ebar += zbar_0 W_0
                     const float inv = ts.inv * winv_from_bits(P.wabs[0]);
                     DH_UNROLL for (int tt = 0; tt < AUX_NTW; ++tt) DH_UNROLL for (int r = 0; r < 16; ++r) eb[tt][r] = fmaf(e0[tt][r], inv, eb[tt][r]);
                 }

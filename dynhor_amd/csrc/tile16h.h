@@ -15,8 +15,13 @@
 //   * O(1) operands (softplus / ReLU activations, embeddings, features): the constant H2_XS = 16 (overflow beyond 4094);
 //   * everything else (adjoints, tangents, reverse-chain values): per 64-point tile and layer, from the tile's own maximum
 //     (tile_scale below): scaled maximum in [256, 512), 128 x headroom to fp16's 65504.
-// The LDS activation image of the tile-resident chains holds the SCALED fp32 values; each wave splits its A fragments as it
-// fetches them (2 vector ops per value instead of 4.5): v_cvt_pk_f16_f32, 2 x v_fma_mix_f32, v_cvt_pk_f16_f32 per pair.
+// The split costs 2 vector ops per value (v_cvt_pk_f16_f32, 2 x v_fma_mix_f32, v_cvt_pk_f16_f32 per pair; bf16x3: 4.5).
+// The LDS activation image of the tile-resident chains holds the PIECES: two fp16 planes [TM x 256] (row stride LDH halves), 2 x
+// 2 bytes per value = the 4 bytes of the fp32 image they replace, so two workgroups per CU still fit -- which three bf16 planes did
+// not (tile16.h).  The wave that PRODUCES a value splits it once in its epilogue (acc_to_lds_split: the tile's scale is known there,
+// lds_handoff), and the GEMM loop is ds_read_b128 of ready MFMA operands + weight loads + MFMAs: none of the split-on-fetch form's
+// 32 vector ops per k-chunk, redone by each of the four waves.  Only the 48-wide aux images stay fp32 and are split as they are
+// fetched (gemm_rows_aux_h: three k-chunks).
 // Packed weights (pack.hip packh_kernel): f16x8 index ((kc*NT + nt)*2 + piece)*64 + lane holds
 //   S_w M[k = 16 kc + 8 (lane>>5) + s][n = 32 nt + (lane&31)], s = 0..7  (piece 0 = hi, 1 = lo).
 #pragma once
@@ -26,8 +31,7 @@ namespace dh {
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2v __attribute__((ext_vector_type(2)));
-struct H2 { u32x4 p[2]; };                     // hi, lo pieces of 8 values (one MFMA operand each)
-
+struct H2 { u32x4 p[2]; };
 __device__ __forceinline__ unsigned pack_f16x2(f32x2 v) { return __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2v)); }
 // v - float(h.lo), v - float(h.hi): one v_fma_mix_f32 each, the f16 half read in place (exact: |v - h| <= ulp_f16 / 2)
 __device__ __forceinline__ f32x2 resid_f16x2(f32x2 v, unsigned h) {
@@ -111,19 +115,31 @@ constexpr int ABSMAX_STRIDE = 64;
 __device__ __forceinline__ void post_class_max(unsigned* absmax, int cls, float m) {
     atomicMax(absmax + cls * ABSMAX_STRIDE, __builtin_bit_cast(unsigned, m));
 }
-// accumulators -> LDS main tile, scaled
-__device__ __forceinline__ void acc_to_lds_scaled(const f32x16 (&acc)[MT][2], float* xs, int wave, int lane, float S) {
+// ---------------------------------------------------------------- the piece-plane LDS image
+constexpr int LDH = 264;                 // row stride of a plane in halves: 528 B = 132 dwords, 132 % 64 == 4 like LDX -> conflict-free b128 reads
+constexpr int PLANE_H = TM * LDH;        // halves per plane; the image is hi plane, then lo plane
+constexpr int IMG_H = 2 * PLANE_H;
+// accumulators -> scaled, split, into the two planes.  A lane holds 16 rows of ONE column per accumulator: a converted pair is two
+// rows of that column, written as two 16-bit stores per plane (ds_write_b16 / ds_write_b16_d16_hi).
+__device__ __forceinline__ void acc_to_lds_split(const f32x16 (&acc)[MT][2], _Float16* img, int wave, int lane, float S) {
     DH_UNROLL for (int m = 0; m < MT; ++m)
         DH_UNROLL for (int t = 0; t < 2; ++t) {
-            float* base = xs + (m * 32 + 4 * (lane >> 5)) * LDX + acc_col(wave, t, lane);
-            DH_UNROLL for (int r = 0; r < 16; ++r) base[((r & 3) + 8 * (r >> 2)) * LDX] = acc[m][t][r] * S;
+            _Float16* base = img + (m * 32 + 4 * (lane >> 5)) * LDH + acc_col(wave, t, lane);
+            DH_UNROLL for (int r = 0; r < 16; r += 2) {
+                f32x2 x;
+                x[0] = acc[m][t][r] * S;
+                x[1] = acc[m][t][r + 1] * S;
+                const unsigned h = pack_f16x2(x);
+                const unsigned l = pack_f16x2(resid_f16x2(x, h));
+                const f16x2v hv = __builtin_bit_cast(f16x2v, h), lv = __builtin_bit_cast(f16x2v, l);
+                _Float16* q = base + ((r & 3) + 8 * (r >> 2)) * LDH;
+                q[0] = hv[0]; q[LDH] = hv[1];
+                q[PLANE_H] = lv[0]; q[PLANE_H + LDH] = lv[1];
+            }
         }
 }
-
-// ---------------------------------------------------------------- split-on-fetch GEMM (the chains' core), tile16.h's scheme
-// Program order pinned as in gemm_rows_s: raw fp32 A fragments two k-chunks ahead, weight pieces one; the 12 MFMAs of a k-chunk
-// product-major at raised priority, and after MFMA i two of the 24 split micro-steps of the NEXT k-chunk (pair j = 8 m + q:
-// convert | two residuals | convert).
+// ---------------------------------------------------------------- split micro-steps (the weight-gradient kernel deals them between its MFMAs)
+// pair j = 8 m + q of the 8 values of an operand fragment: convert | two residuals | convert.
 // SC: the image is UNSCALED and the scale st.sc is applied as the values are fetched (the small aux images)
 struct SplitStateH { f32x2 r[4 * MT]; float sc; };
 template <int STEP, bool SC>
@@ -142,6 +158,9 @@ __device__ __forceinline__ void split_step_h(H2 (&a)[MT], const RawA& raw, Split
         a[m].p[1][q] = pack_f16x2(st.r[j]);
     }
 }
+
+// ---------------------------------------------------------------- MFMA issue order of one k-chunk
+// the 12 MFMAs of a k-chunk (two m-tiles x two n-tiles x three products) product-major, each at raised wave priority
 template <int I>
 __device__ __forceinline__ void mfma_step_h(f32x16 (&acc)[MT][2], const H2 (&a)[MT], const H2 (&b)[2]) {
     constexpr int pa[3] = {0, 1, 0}, pb[3] = {1, 0, 0};                      // mfma3's product order
@@ -150,78 +169,186 @@ __device__ __forceinline__ void mfma_step_h(f32x16 (&acc)[MT][2], const H2 (&a)[
     acc[m][t] = mfma_h(a[m].p[pa[p]], b[t].p[pb[p]], acc[m][t]);
     __builtin_amdgcn_s_setprio(0);
 }
-template <int I, int N, bool SC>
-__device__ __forceinline__ void phase_steps_h(f32x16 (&acc)[MT][2], const H2 (&ac)[MT], const H2 (&bc)[2], H2 (&an)[MT],
-                                              const RawA& rn, SplitStateH& st) {
-    if constexpr (I < N) {
-        mfma_step_h<I>(acc, ac, bc);
-        __builtin_amdgcn_sched_barrier(0);
-        split_step_h<2 * I, SC>(an, rn, st);
-        split_step_h<2 * I + 1, SC>(an, rn, st);
-        __builtin_amdgcn_sched_barrier(0);
-        phase_steps_h<I + 1, N, SC>(acc, ac, bc, an, rn, st);
-    }
-}
 template <int I, int N>
 __device__ __forceinline__ void mfma_only_h(f32x16 (&acc)[MT][2], const H2 (&ac)[MT], const H2 (&bc)[2]) {
     if constexpr (I < N) { mfma_step_h<I>(acc, ac, bc); mfma_only_h<I + 1, N>(acc, ac, bc); }
 }
-template <int I, int N, bool SC>
-__device__ __forceinline__ void split_only_h(H2 (&an)[MT], const RawA& rn, SplitStateH& st) {
-    if constexpr (I < N) { split_step_h<I, SC>(an, rn, st); split_only_h<I + 1, N, SC>(an, rn, st); }
+
+// ---------------------------------------------------------------- saved tiles and weights through buffer descriptors
+// A chain touches up to four saved-tile streams per layer plus the weight stream; as flat pointers each costs 64-bit vector address
+// pairs (one per 4 KB of reach), and the backward kernels spilled.  Through a buffer descriptor the base is scalar (four SGPRs built
+// per tile and layer with scalar arithmetic) and ONE 32-bit lane offset serves every stream.
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+__device__ __forceinline__ rsrc_t tile_rsrc(const float* tile) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(tile), 0, TILE_F * 4, 0x00020000);
 }
-// acc[m][t] += X[TM x 16 nkc] * M.  xs: the SCALED fp32 LDS image (row stride ldx floats; SC: unscaled, `sc` applied on fetch), wp:
-// packed fp16 weight pieces (NT = 8).  The result carries the product of the two scales.
-template <bool SC = false>
-__device__ __forceinline__ void gemm_rows_h(f32x16 (&acc)[MT][2], const float* xs, const int ldx, const int nkc,
-                                            const u32x4* __restrict__ wp, const int wave, const int lane, const float sc = 1.f) {
-    static_assert(MT == 2, "12 MFMAs per k-chunk = 8 pairs x 3 split steps / 2");
-    const float* xrow = xs + (lane & 31) * ldx + 8 * (lane >> 5);
-    const u32x4* wl = wp + (2 * wave) * 2 * 64 + lane;
-    const int last = nkc - 1;
-    H2 a0[MT], a1[MT];
-    H2 b0[2], b1[2];
-    RawA r0, r1;
-    SplitStateH st;
-    st.sc = sc;
-    auto loadb = [&](H2 (&b)[2], int kc) {                  // past the end: clamped (a harmless re-read), no branch
-        kc = kc < last ? kc : last;
+__device__ __forceinline__ int tile_loff(int wave, int lane) { return (wave * MT * 8 * 64 + lane) * 16; }
+// float4 idx = (m*2 + t)*4 + r4 of this lane's share of a native tile (tile.h); non-temporal like DH_TILE_LD / DH_TILE_ST
+__device__ __forceinline__ f32x4 tile_ld(rsrc_t r, int loff, int idx) {
+    const int off = idx * 1024;
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, loff + (off & 4095), off & ~4095, 2));
+}
+// STORES carry their whole offset in the vector offset + immediate, never in a scalar soffset: with a REGISTER soffset hipcc (ROCm
+// 7.2) schedules a vector write to the store's data registers directly behind a buffer_store_dwordx4 -- it only guards the
+// immediate-soffset form -- and on gfx950 the store then sends the new values (measured: a tile class wrong by O(1), differently on
+// every run; scripts/_cmp_libs.py history in profiles/HISTORY.md).
+__device__ __forceinline__ void tile_st(rsrc_t r, int loff, int idx, const f32x4& v) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, loff + idx * 1024, 0, 2);
+}
+__device__ __forceinline__ void acc_store_native_b(const f32x16 (&acc)[MT][2], rsrc_t r, int loff) {
+    DH_UNROLL for (int m = 0; m < MT; ++m)
         DH_UNROLL for (int t = 0; t < 2; ++t)
-            DH_UNROLL for (int p = 0; p < 2; ++p) b[t].p[p] = wl[((kc * 8 + t) * 2 + p) * 64];
-    };
-    auto loada = [&](RawA& r, int kc) {
-        kc = kc < last ? kc : last;
-        DH_UNROLL for (int m = 0; m < MT; ++m) {
-            r.lo[m] = *reinterpret_cast<const f32x4*>(xrow + m * 32 * ldx + kc * 16);
-            r.hi[m] = *reinterpret_cast<const f32x4*>(xrow + m * 32 * ldx + kc * 16 + 4);
-        }
-    };
-    loadb(b0, 0); loada(r0, 0); loada(r1, 1);
-    split_only_h<0, 24, SC>(a0, r0, st);
-    _Pragma("unroll 1") for (int kc = 0; kc + 1 < nkc; kc += 2) {
-        loadb(b1, kc + 1); loada(r0, kc + 2);
-        __builtin_amdgcn_sched_barrier(0);
-        phase_steps_h<0, 12, SC>(acc, a0, b0, a1, r1, st);
-        loadb(b0, kc + 2); loada(r1, kc + 3);
-        __builtin_amdgcn_sched_barrier(0);
-        phase_steps_h<0, 12, SC>(acc, a1, b1, a0, r0, st);
-    }
-    if (nkc & 1) mfma_only_h<0, 12>(acc, a0, b0);
+            DH_UNROLL for (int r4 = 0; r4 < 4; ++r4) {
+                f32x4 v;
+                v[0] = acc[m][t][4 * r4 + 0]; v[1] = acc[m][t][4 * r4 + 1]; v[2] = acc[m][t][4 * r4 + 2]; v[3] = acc[m][t][4 * r4 + 3];
+                tile_st(r, loff, (m * 2 + t) * 4 + r4, v);
+            }
+}
+__device__ __forceinline__ void acc_load_native_b(f32x16 (&acc)[MT][2], rsrc_t r, int loff) {
+    DH_UNROLL for (int m = 0; m < MT; ++m)
+        DH_UNROLL for (int t = 0; t < 2; ++t)
+            DH_UNROLL for (int r4 = 0; r4 < 4; ++r4) {
+                const f32x4 v = tile_ld(r, loff, (m * 2 + t) * 4 + r4);
+                acc[m][t][4 * r4 + 0] = v[0]; acc[m][t][4 * r4 + 1] = v[1]; acc[m][t][4 * r4 + 2] = v[2]; acc[m][t][4 * r4 + 3] = v[3];
+            }
+}
+// one m-slab (8 float4: t, r4) of a saved tile: what an epilogue holds in flight per stream
+struct Slab { f32x4 v[8]; };
+__device__ __forceinline__ void slab_ld(Slab& s, rsrc_t r, int loff, int m) {
+    DH_UNROLL for (int i = 0; i < 8; ++i) s.v[i] = tile_ld(r, loff, m * 8 + i);
+}
+__device__ __forceinline__ rsrc_t weight_rsrc(const u32x4* wp) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<u32x4*>(wp), 0, 0x40000000, 0x00020000);
 }
 
-// 64-wide "aux" output from the scaled main image (tile16.h gemm_auxout_s)
-__device__ __forceinline__ void gemm_auxout_h(f32x16 (&acc2)[AUX_NTW], const float* xs, const int nkc,
-                                              const u32x4* __restrict__ wp, const int wave, const int lane) {
-    const float* xrow = xs + (32 * aux_mtile(wave) + (lane & 31)) * LDX + 8 * (lane >> 5);
-    const u32x4* wl = wp + aux_ntile(wave, 0) * 2 * 64 + lane;
+// ---------------------------------------------------------------- piece-plane GEMM (the chains' core)
+// acc[m][t] += X[TM x 16 nkc] * M from the piece planes: per k-chunk a wave issues 4 ds_read_b128 (its two m-tiles, hi and lo) and 4
+// weight loads (two n-tiles, hi and lo; L2), then the 12 MFMAs of the chunk product-major at raised priority.  A fragments one chunk
+// ahead, weight pieces two chunks ahead in four rotating buffers.  nkc even, >= 6.  The result carries the product of the two scales.
+// `pre`: called once, at the top of the THIRD-LAST chunk, right after the last weight load of the GEMM has been issued -- the place
+// for the epilogue's first saved-tile loads: vector-memory loads return in order, so a tile load issued any earlier would stand
+// between the remaining weight loads and their consumers, and one issued in the epilogue is exposed in full.  Three chunks = 36
+// MFMAs cover it (a fourth would need all four weight buffers live at once: the two-stream kernels spilled).
+struct NoPre { __device__ __forceinline__ void operator()() const {} };
+// LEAN: two weight buffers one chunk ahead instead of four two ahead (32 registers less; the kernels with two saved-tile input
+// streams per epilogue, whose register file is full), `pre` at the top of the last chunk.
+template <bool LEAN = false, class Pre = NoPre>
+__device__ __forceinline__ void gemm_rows_hp(f32x16 (&acc)[MT][2], const _Float16* img, const int nkc,
+                                             const u32x4* __restrict__ wp, const int wave, const int lane, Pre&& pre = Pre()) {
+    static_assert(MT == 2, "");
+    const _Float16* xrow = img + (lane & 31) * LDH + 8 * (lane >> 5);
+    const rsrc_t wr = weight_rsrc(wp);
+    const int woff = ((2 * wave) * 2 * 64 + lane) * 16;
+    auto loadb = [&](H2 (&b)[2], int kc) {
+        DH_UNROLL for (int t = 0; t < 2; ++t)
+            DH_UNROLL for (int p = 0; p < 2; ++p)
+                b[t].p[p] = __builtin_amdgcn_raw_buffer_load_b128(wr, woff + (t * 2 + p) * 1024, kc * (8 * 2 * 64 * 16), 0);
+    };
+    auto loada = [&](H2 (&a)[MT], int kc) {
+        DH_UNROLL for (int m = 0; m < MT; ++m)
+            DH_UNROLL for (int p = 0; p < 2; ++p)
+                a[m].p[p] = *reinterpret_cast<const u32x4*>(xrow + p * PLANE_H + m * 32 * LDH + kc * 16);
+    };
+    H2 a0[MT], a1[MT];
+    if constexpr (LEAN) {
+        H2 b0[2], b1[2];
+        loadb(b0, 0); loada(a0, 0);
+        _Pragma("unroll 1") for (int kc = 0; kc < nkc; kc += 2) {
+            loadb(b1, kc + 1); loada(a1, kc + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_only_h<0, 12>(acc, a0, b0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (kc + 2 < nkc) { loadb(b0, kc + 2); loada(a0, kc + 2); }
+            else pre();
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_only_h<0, 12>(acc, a1, b1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        return;
+    }
+    H2 bA[2], bB[2], bC[2], bD[2];
+    // chunks c, c+1 from (b0, b1); (b2, b3) <- c+2, c+3
+    auto step2 = [&](int c, H2 (&b0)[2], H2 (&b1)[2], H2 (&b2)[2], H2 (&b3)[2]) {
+        loadb(b2, c + 2); loada(a1, c + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_only_h<0, 12>(acc, a0, b0);
+        __builtin_amdgcn_sched_barrier(0);
+        loadb(b3, c + 3); loada(a0, c + 2);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_only_h<0, 12>(acc, a1, b1);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    // the last four chunks: the remaining weights, then the caller's prefetch
+    auto tail4 = [&](int c, H2 (&b0)[2], H2 (&b1)[2], H2 (&b2)[2], H2 (&b3)[2]) {
+        loadb(b2, c + 2); loada(a1, c + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_only_h<0, 12>(acc, a0, b0);
+        __builtin_amdgcn_sched_barrier(0);
+        loadb(b3, c + 3);
+        pre();
+        loada(a0, c + 2);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_only_h<0, 12>(acc, a1, b1);
+        __builtin_amdgcn_sched_barrier(0);
+        loada(a1, c + 3);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_only_h<0, 12>(acc, a0, b2);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_only_h<0, 12>(acc, a1, b3);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    loadb(bA, 0); loadb(bB, 1); loada(a0, 0);
+    int kc = 0;
+    _Pragma("unroll 1") for (; kc + 8 <= nkc; kc += 4) {
+        step2(kc, bA, bB, bC, bD);
+        step2(kc + 2, bC, bD, bA, bB);
+    }
+    if (nkc - kc == 6) {
+        step2(kc, bA, bB, bC, bD);
+        tail4(kc + 2, bC, bD, bA, bB);
+    } else {
+        tail4(kc, bA, bB, bC, bD);
+    }
+}
+
+// acc[m][t] += sc * X[TM x 48] * M from the small fp32 aux image (row stride LDA; embedding / colour extras, unscaled in LDS): three
+// k-chunks, split as they are fetched.  All three chunks' weight pieces are requested up front.
+__device__ __forceinline__ void gemm_rows_aux_h(f32x16 (&acc)[MT][2], const float* xs, const u32x4* __restrict__ wp,
+                                                const int wave, const int lane, const float sc) {
+    static_assert(AUX_KC == 3, "");
+    const float* xrow = xs + (lane & 31) * LDA + 8 * (lane >> 5);
+    const rsrc_t wr = weight_rsrc(wp);
+    const int woff = ((2 * wave) * 2 * 64 + lane) * 16;
+    H2 b[AUX_KC][2];
+    asm volatile("" ::: "memory");           // (keeps these loads from being hoisted above a main GEMM that precedes this one)
+    DH_UNROLL for (int kc = 0; kc < AUX_KC; ++kc)
+        DH_UNROLL for (int t = 0; t < 2; ++t)
+            DH_UNROLL for (int p = 0; p < 2; ++p)
+                b[kc][t].p[p] = __builtin_amdgcn_raw_buffer_load_b128(wr, woff + (t * 2 + p) * 1024, kc * (8 * 2 * 64 * 16), 0);
+    DH_UNROLL for (int kc = 0; kc < AUX_KC; ++kc) {
+        H2 a[MT];
+        DH_UNROLL for (int m = 0; m < MT; ++m) {
+            const f32x4 lo = *reinterpret_cast<const f32x4*>(xrow + m * 32 * LDA + kc * 16);
+            const f32x4 hi = *reinterpret_cast<const f32x4*>(xrow + m * 32 * LDA + kc * 16 + 4);
+            a[m] = split2(lo * sc, hi * sc);
+        }
+        mfma_only_h<0, 12>(acc, a, b[kc]);
+    }
+}
+
+// 64-wide "aux" output from the piece planes (one m-tile per wave)
+__device__ __forceinline__ void gemm_auxout_hp(f32x16 (&acc2)[AUX_NTW], const _Float16* img, const int nkc,
+                                               const u32x4* __restrict__ wp, const int wave, const int lane) {
+    const _Float16* xrow = img + (32 * aux_mtile(wave) + (lane & 31)) * LDH + 8 * (lane >> 5);
+    const rsrc_t wr = weight_rsrc(wp);
+    const int woff = (aux_ntile(wave, 0) * 2 * 64 + lane) * 16;
     const int last = nkc - 1;
     auto fetch = [&](H2& a, H2 (&b)[AUX_NTW], int kc) {
         kc = kc < last ? kc : last;
         DH_UNROLL for (int t = 0; t < AUX_NTW; ++t)
-            DH_UNROLL for (int p = 0; p < 2; ++p) b[t].p[p] = wl[((kc * 2 + t) * 2 + p) * 64];
-        const f32x4 lo = *reinterpret_cast<const f32x4*>(xrow + kc * 16);
-        const f32x4 hi = *reinterpret_cast<const f32x4*>(xrow + kc * 16 + 4);
-        a = split2(lo, hi);
+            DH_UNROLL for (int p = 0; p < 2; ++p)
+                b[t].p[p] = __builtin_amdgcn_raw_buffer_load_b128(wr, woff + (t * 2 + p) * 1024, kc * (2 * 2 * 64 * 16), 0);
+        DH_UNROLL for (int p = 0; p < 2; ++p) a.p[p] = *reinterpret_cast<const u32x4*>(xrow + p * PLANE_H + kc * 16);
     };
     H2 a0, a1, b0[AUX_NTW], b1[AUX_NTW];
     fetch(a0, b0, 0);
@@ -233,6 +360,25 @@ __device__ __forceinline__ void gemm_auxout_h(f32x16 (&acc2)[AUX_NTW], const flo
             DH_UNROLL for (int t = 0; t < AUX_NTW; ++t) acc2[t] = mfma3(a1, b1[t], acc2[t]);
         }
     }
+}
+
+// per-point dot of the image rows (hi + lo) with a 256-vector: 256 / TM threads per point (point = tid / TPP), result valid on
+// every thread of the group
+__device__ __forceinline__ float row_dot256_hp(const _Float16* img, const float* __restrict__ w, int tid) {
+    constexpr int TPP_ = 256 / TM, SEG = 256 / TPP_;
+    const int p = tid / TPP_, part = tid % TPP_;
+    const f16x8* xh = reinterpret_cast<const f16x8*>(img + p * LDH + part * SEG);
+    const f16x8* xl = reinterpret_cast<const f16x8*>(img + PLANE_H + p * LDH + part * SEG);
+    const f32x4* wr = reinterpret_cast<const f32x4*>(w + part * SEG);
+    float s = 0.f;
+    DH_UNROLL for (int i = 0; i < SEG / 8; ++i) {
+        const f16x8 h = xh[i], l = xl[i];
+        const f32x4 b0 = wr[2 * i], b1 = wr[2 * i + 1];
+        DH_UNROLL for (int j = 0; j < 4; ++j) s = fmaf((float)h[j] + (float)l[j], b0[j], s);
+        DH_UNROLL for (int j = 0; j < 4; ++j) s = fmaf((float)h[4 + j] + (float)l[4 + j], b1[j], s);
+    }
+    DH_UNROLL for (int off = 1; off < TPP_; off <<= 1) s += __shfl_xor(s, off);
+    return s;
 }
 
 }  // namespace dh

@@ -42,5 +42,49 @@ def test_chain_t_listing_is_clean(tmp_path):
     # the no-grad kernel must not spill at all; the training forward keeps a few loop invariants in scratch, reloaded outside the
     # MFMA stream (the scanner above would flag a spilled in-flight register: scratch stores read their data register)
     assert nograd[0][0] == 0 and train[0][0] <= 64, names
-    for scratch, lds in nograd + train:
+    # the shipping (two-piece fp16) forms: no scratch at all
+    nograd_h = [v for k, v in names.items() if "sdf_nograd_h_kernel" in k]
+    train_h = [v for k, v in names.items() if "sdf_fwd_train_h_kernel" in k]
+    assert nograd_h and train_h, names
+    assert nograd_h[0][0] == 0 and train_h[0][0] == 0, names
+    for scratch, lds in nograd + train + nograd_h + train_h:
         assert lds <= 160 * 1024, "one workgroup per CU: the LDS image must fit 160 KB"
+    _no_register_soffset_on_wide_stores(text)
+
+
+@pytest.mark.skipif(shutil.which("hipcc") is None, reason="hipcc not installed")
+def test_tile_resident_chains_fit_two_workgroups_per_cu_and_do_not_spill_in_their_layer_loops(tmp_path):
+    """The five tile-resident chains of the shipping arithmetic (kernels_mlp_h.hip): the piece-plane LDS image + aux image must
+    leave room for TWO workgroups per CU (the second one's epilogue overlaps the first one's MFMAs), and whatever the compiler
+    keeps in scratch must stay outside the GEMM loops (no scratch access between two MFMAs of a k-chunk)."""
+    import re
+    out = tmp_path / "chains_h.s"
+    subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only",
+                    os.path.join(ROOT, "dynhor_amd", "csrc", "kernels_mlp_h.hip"), "-o", str(out)], check=True, timeout=600)
+    text = out.read_text()
+    kernels = re.findall(r"^(_ZN2dh\w+):(.*?); ScratchSize: (\d+).*?; LDSByteSize: (\d+)", text, flags=re.S | re.M)
+    want = ("color_fwd_h_kernel", "sdf_grad_h_kernel", "color_bwd_h_kernel", "sdf_tangent_h_kernel", "sdf_bwd_h_kernel")
+    seen = set()
+    for name, body, scratch, lds in kernels:
+        hit = [w for w in want if w in name]
+        if not hit:
+            continue
+        seen.add(hit[0])
+        assert 2 * int(lds) <= 160 * 1024, (name, lds)
+        # inside a run of MFMAs (one k-chunk = 12 of them) nothing may touch scratch
+        lines = [l.strip() for l in body.split("\n")]
+        idx = [i for i, l in enumerate(lines) if l.startswith("v_mfma")]
+        for a, b in zip(idx, idx[1:]):
+            if b - a <= 6:
+                assert not any(l.startswith("scratch_") for l in lines[a:b]), (name, lines[a:b])
+    assert seen == set(want), seen
+    _no_register_soffset_on_wide_stores(text)
+
+
+def _no_register_soffset_on_wide_stores(text):
+    """hipcc (ROCm 7.2) guards the data registers of a buffer_store_dwordx3/x4 against an immediately following vector write only
+    when soffset is an immediate; with a REGISTER soffset gfx950 stored the overwritten values (profiles/r04_ab_chain_io.json).
+    Every wide buffer store of the library therefore carries its offset in voffset + immediate."""
+    import re
+    bad = [l.strip() for l in text.split("\n") if re.match(r"\s*buffer_store_dwordx[34] .*\], s\d+ ", l)]
+    assert not bad, bad[:5]
