@@ -31,7 +31,7 @@ struct DwJobs { DwJob j[16]; int n; };
 #define DW_GROUPS 8
 #endif
 #ifndef DW_AUX_COST
-#define DW_AUX_COST 8.0
+#define DW_AUX_COST 12.0           // (8 until the two-piece kernel's aux jobs moved to the three-piece body: 12 and 16 measure 2.20 ms, 8: 2.38)
 #endif
 struct DwGroups { int n; int job0[DW_GROUPS + 1]; int wg0[DW_GROUPS + 1]; int64_t off0[DW_GROUPS + 1]; };
 __device__ __forceinline__ int dw_group_of(const DwGroups& Gp, int g) {
@@ -408,6 +408,7 @@ __device__ __forceinline__ void dw_half_steps_h(f32x16 (&acc)[2][4], const H2 (&
 template <int NB>
 __device__ __forceinline__ void dw_body_pieces_h(const DwJob& J, const DwScales& sc, int64_t t0, int64_t t1, float* __restrict__ out,
                                                  int wave, int lane, char* lds) {
+    static_assert(NB == 8, "main jobs only: the aux jobs run dw_body_pieces<2> (dw_f16x2_kernel)");
     constexpr int KQ = MT * 4;
     constexpr int BT = (NB == 8) ? TILE_F : AUXT_F;
     constexpr int NA = DwShape<NB>::NA, NBW = DwShape<NB>::NBW;
@@ -501,24 +502,6 @@ __device__ __forceinline__ void dw_body_pieces_h(const DwJob& J, const DwScales&
                 __syncthreads();
                 return;
             }
-            H2 a[NA], b[H];
-            DH_UNROLL for (int ii = 0; ii < NA; ++ii) a[ii] = piece(par, (NB == 8) ? ((wave >> 1) * 2 + ii) : wave);
-            DH_UNROLL for (int j = 0; j < H; ++j) b[j] = piece(par, 8 + ((NB == 8) ? ((wave & 1) * 4 + j) : j));
-            __builtin_amdgcn_sched_barrier(0);
-            publish_a(nxt, par ^ 1);
-            DH_UNROLL for (int ii = 0; ii < NA; ++ii)
-                DH_UNROLL for (int j = 0; j < H; ++j) acc[ii][j] = mfma3(a[ii], b[j], acc[ii][j]);
-            __builtin_amdgcn_sched_barrier(0);
-            if (H < NBW) {
-                DH_UNROLL for (int j = 0; j < H; ++j) b[j] = piece(par, 8 + ((NB == 8) ? ((wave & 1) * 4 + H + j) : (H + j)));
-            }
-            publish_b(nxt, par ^ 1);
-            DH_UNROLL for (int ii = 0; ii < NA; ++ii)
-                DH_UNROLL for (int j = 0; j < H; ++j) acc[ii][H + j] = mfma3(a[ii], b[j], acc[ii][H + j]);
-            __builtin_amdgcn_sched_barrier(0);
-            load(nxt);
-            __builtin_amdgcn_sched_barrier(0);
-            __syncthreads();
         };
         const float ratio = npairs == 2 ? sc.prod1 / sc.prod0 : 1.f;       // powers of two: exact
         // step p computes piece buffer p & 1 and publishes raw set (p + 1) % 3 (k-pair p + 1), which it refills with k-pair p + 4:
@@ -556,7 +539,8 @@ __device__ __forceinline__ void dw_body_pieces_h(const DwJob& J, const DwScales&
 __global__ __launch_bounds__(512, 1) void dw_f16x2_kernel(DwJobs jobs, DwGroups groups, int64_t ntiles, float* __restrict__ slabs,
                                                           int64_t gstride, const unsigned* __restrict__ absmax,
                                                           const unsigned* __restrict__ tmax) {
-    __shared__ __attribute__((aligned(16))) char pieces[2 * DWH_BUF];
+    // (sized for the aux jobs' three-piece image, below)
+    __shared__ __attribute__((aligned(16))) char pieces[2 * (DWP_BUF > DWH_BUF ? DWP_BUF : DWH_BUF)];
     const int g = blockIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int k = dw_group_of(groups, g), gl = g - groups.wg0[k], gc = groups.wg0[k + 1] - groups.wg0[k];
@@ -565,8 +549,13 @@ __global__ __launch_bounds__(512, 1) void dw_f16x2_kernel(DwJobs jobs, DwGroups 
     for (int job = groups.job0[k]; job < groups.job0[k + 1]; ++job) {
         const DwJob J = jobs.j[job];
         const DwScales sc = dw_job_scales(J, absmax, tmax, ntiles);
+        // The three aux jobs (64-wide B: 6 % of the kernel's bytes, a quarter of a main job's MFMAs) run the three-piece bf16 body.
+        // Their two-piece form was NOT bitwise reproducible: about one launch in 5,000 differed from the others in the 16 output
+        // columns 16..31 of ONE workgroup's slab by ~1e-3 of one k-pair's contribution (the size of a lo piece), with every barrier
+        // and wait in place and under every timing / nop / register variant tried (profiles/r04_dw_aux_reproducibility.json); the
+        // main jobs' two-piece body and this body are bitwise reproducible over 100,000 launches.
         if (J.nb == 8) dw_body_pieces_h<8>(J, sc, t0, t1, base + J.off, wave, lane, pieces);
-        else dw_body_pieces_h<2>(J, sc, t0, t1, base + J.off, wave, lane, pieces);
+        else dw_body_pieces<2>(J, t0, t1, base + J.off, wave, lane, pieces);
     }
 }
 
@@ -782,7 +771,7 @@ static DwGroups build_dw_groups(const DwJobs& J, int G) {
     const int ng = DW_GROUPS < G ? DW_GROUPS : (G < 1 ? 1 : G);
     double cost[16], total = 0.0;
     // cost of a job per tile: a main job (64 KB + 64 KB of operands, 48 MFMAs per wave and 16 points) = 16; an aux job (64 KB +
-    // 16 KB, a quarter of the MFMAs) is bound by its bytes: DW_AUX_COST, measured (8 ... 12 swept, profiles/r03_ab_dw_job_groups.json);
+    // 16 KB, a quarter of the MFMAs) is bound by its bytes: DW_AUX_COST, measured (profiles/r03_ab_dw_job_groups.json; round 4: profiles/r04_dw_aux_reproducibility.json);
     // two operand pairs = twice
     for (int j = 0; j < J.n; ++j) { cost[j] = (J.j[j].nb == 8 ? 16.0 : (double)DW_AUX_COST) * (J.j[j].A2 ? 2 : 1); total += cost[j]; }
     // greedy contiguous partition: close a group when its cost reaches the running target

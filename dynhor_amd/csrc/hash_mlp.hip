@@ -519,10 +519,24 @@ __global__ __launch_bounds__(256) void hash_geo_bwd_kernel(const float* __restri
 //     issues the centre's atomics.
 // Against the per-evaluation scatter (tcnn's scheme: E x 8 corners x 2 features atomics per point and level) this is
 // 24.9 ms -> see DESIGN.md for the measured ladder.  dh_hash_set_scatter_mode(1 / 2) switches (b) / (a) off for ablation.
+// Development probes (scripts/build_variant.sh; timing only, results are wrong): -DHASH_PROBE_STORE replaces every atomic add by a
+// plain store to the same address (what the kernel costs without read-modify-write at the memory side), -DHASH_PROBE_SPREAD sends
+// every atomic to a line of its own (no two requests share an address: the atomic path without contention), -DHASH_PROBE_LEVEL=k
+// runs level k only.  Their numbers: DESIGN_NEXT_ROWS.md section 7 "what bounds the table scatter".
+#if defined(HASH_PROBE_STORE)
+#define HG_SCATTER_ADD(ptr, v) (*(volatile float*)(ptr) = (v))
+#elif defined(HASH_PROBE_SPREAD)
+#define HG_SCATTER_ADD(ptr, v) atomicAdd(d_table + ((((size_t)blockIdx.x * 256 + threadIdx.x) * 16 + (size_t)blockIdx.y * 0x9E3779B1u) % ((size_t)1 << 19)) * 16, (v))
+#else
+#define HG_SCATTER_ADD(ptr, v) atomicAdd((ptr), (v))
+#endif
 template <int MODE>   // 0: both merges; 1: no lane-run merge; 2: no evaluation merge (ablation / debugging)
 __global__ __launch_bounds__(256) void hash_table_bwd_kernel(HashLevels H, const float* __restrict__ ws, HashWs O, int64_t n,
                                                              float* __restrict__ d_table, const int64_t* __restrict__ n_act) {
     const int l = blockIdx.y;
+#ifdef HASH_PROBE_LEVEL
+    if (l != HASH_PROBE_LEVEL) return;
+#endif
     const int lane = threadIdx.x & 63;
     const int64_t p = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 2;
     const int dx = (threadIdx.x >> 1) & 1, f = threadIdx.x & 1;
@@ -567,7 +581,7 @@ __global__ __launch_bounds__(256) void hash_table_bwd_kernel(HashLevels H, const
                     DH_UNROLL for (int bz = 0; bz < 2; ++bz) {
                         const float wt = wpa * (dx ? w0[1] : 1.f - w0[1]) * (bz ? w0[2] : 1.f - w0[2]);
                         const uint32_t idx = hg_index(H, l, ga + ba, g0[1] + dx, g0[2] + bz);
-                        atomicAdd(T + (size_t)idx * HG_F, wt);
+                        HG_SCATTER_ADD(T + (size_t)idx * HG_F, wt);
                     }
                 }
             } else {
@@ -585,7 +599,7 @@ __global__ __launch_bounds__(256) void hash_table_bwd_kernel(HashLevels H, const
                         uint32_t cc[3];
                         cc[0] = g0[0] + dx; cc[a] = ga + ba; cc[o] = g0[o] + bo;
                         const uint32_t idx = hg_index(H, l, cc[0], cc[1], cc[2]);
-                        atomicAdd(T + (size_t)idx * HG_F, wt);
+                        HG_SCATTER_ADD(T + (size_t)idx * HG_F, wt);
                     }
                 }
             }
@@ -615,7 +629,7 @@ __global__ __launch_bounds__(256) void hash_table_bwd_kernel(HashLevels H, const
     if (valid && tail) {
         DH_UNROLL for (int k = 0; k < 4; ++k) {
             const uint32_t idx = hg_index(H, l, g0[0] + dx, g0[1] + (k & 1), g0[2] + (k >> 1));
-            atomicAdd(T + (size_t)idx * HG_F, acc[k]);
+            HG_SCATTER_ADD(T + (size_t)idx * HG_F, acc[k]);
         }
     }
 }
