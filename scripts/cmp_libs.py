@@ -1,5 +1,5 @@
 """dev: per-region fingerprints of one forward + backward on fixed inputs with a given library; diff two runs.
-   python scripts/_cmp_libs.py dynhor_amd/libdynhor_hip_base.so out_a.pt ; python scripts/_cmp_libs.py dynhor_amd/libdynhor_hip.so out_b.pt ; python scripts/_cmp_libs.py --diff out_a.pt out_b.pt"""
+   python scripts/cmp_libs.py dynhor_amd/libdynhor_hip_base.so out_a.pt ; python scripts/cmp_libs.py dynhor_amd/libdynhor_hip.so out_b.pt ; python scripts/cmp_libs.py --diff out_a.pt out_b.pt"""
 import os, sys, torch
 sys.path.insert(0, "/root/repo")
 if sys.argv[1] == "--diff":
