@@ -191,7 +191,7 @@ __device__ __forceinline__ f32x4 tile_ld(rsrc_t r, int loff, int idx) {
 // STORES carry their whole offset in the vector offset + immediate, never in a scalar soffset: with a REGISTER soffset hipcc (ROCm
 // 7.2) schedules a vector write to the store's data registers directly behind a buffer_store_dwordx4 -- it only guards the
 // immediate-soffset form -- and on gfx950 the store then sends the new values (measured: a tile class wrong by O(1), differently on
-// every run; scripts/cmp_libs.py history in profiles/HISTORY.md).
+// every run; located with scripts/cmp_libs.py, record in profiles/r04_ab_chain_io.json).
 __device__ __forceinline__ void tile_st(rsrc_t r, int loff, int idx, const f32x4& v) {
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, loff + idx * 1024, 0, 2);
 }
