@@ -23,6 +23,7 @@ SIGNATURES = {
                                ctypes.POINTER(_i32), ctypes.POINTER(_i32)]),
     "dh_packed_section": (_i32, [_i32, ctypes.POINTER(_i64), ctypes.POINTER(_i64)]),
     "dh_pack_weights": (_i32, [_vp, _vp, _vp]),
+    "dh_pack_weights_ex": (_i32, [_i32, _vp, _vp, _vp]),
     "dh_sdf_nograd": (_i32, [_vp, _vp, _i64, _vp, _vp]),
     "dh_workspace_floats": (_i32, [_i64, ctypes.POINTER(_i64), ctypes.POINTER(_i64), ctypes.POINTER(_i64)]),
     "dh_mlp_forward": (_i32, [_vp, _vp, _vp, _i32, _i64, _vp, _vp, _vp, _vp, _vp]),

@@ -84,7 +84,11 @@ int dh_param_layout(int net, int layer, int64_t* bias_off, int64_t* g_off, int64
 
 int dh_pack_weights(const float* params, float* packed, void* stream) {
     if (!params || !packed || misaligned16(packed)) return DH_ERR_BAD_ARG;
-    return launch_pack_weights(params, packed, static_cast<hipStream_t>(stream));
+    return launch_pack_weights(params, packed, 7, static_cast<hipStream_t>(stream));
+}
+int dh_pack_weights_ex(int arithmetic, const float* params, float* packed, void* stream) {
+    if (!params || !packed || misaligned16(packed) || bad_arith(arithmetic)) return DH_ERR_BAD_ARG;
+    return launch_pack_weights(params, packed, 1 << arithmetic, static_cast<hipStream_t>(stream));
 }
 
 int dh_sdf_nograd_ex(int arithmetic, const float* packed, const float* pts, int64_t npts, float* sdf, void* stream) {

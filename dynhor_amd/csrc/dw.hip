@@ -685,13 +685,20 @@ __global__ __launch_bounds__(256) void fold_kernel(FoldTable T, SlabPtrs S, cons
         const int i = tid + 256 * q;
         if (i < Ln.in) grad[Ln.voff + (int64_t)o * Ln.in + i] = gval * inv * (dw[q] - dot * inv * inv * vv[q]);
     }
-    if (tid == 0) {
-        grad[Ln.goff + o] = dot * inv;
-        float b;
-        if (Ln.special == 2) b = tsum(19, o);
-        else if (Ln.special == 1 && o == 0) b = tsum(11, 0);
-        else b = tsum(Ln.bias_slot, o - Ln.row_shift);
-        grad[Ln.boff + o] = b;
+    if (tid < 64) {
+        // the row's bias gradient: nS tile-partial sums, one per lane of the first wave and a fixed shuffle tree (ONE thread adding
+        // them in a dependent chain of nS L2 loads was the critical path of this kernel: 52 -> 2x us)
+        int slot, c;
+        if (Ln.special == 2) { slot = 19; c = o; }
+        else if (Ln.special == 1 && o == 0) { slot = 11; c = 0; }
+        else { slot = Ln.bias_slot; c = o - Ln.row_shift; }
+        float b = 0.f;
+        for (int k = tid; k < nS; k += 64) b += tred[((int64_t)k * N_TILE_PART + slot) * 256 + c];
+        DH_UNROLL for (int off = 32; off > 0; off >>= 1) b += __shfl_xor(b, off);
+        if (tid == 0) {
+            grad[Ln.goff + o] = dot * inv;
+            grad[Ln.boff + o] = b;
+        }
     }
 }
 

@@ -11,7 +11,7 @@ namespace dh {
 enum : int { ARITH_BF16 = 0, ARITH_FP32 = 1, ARITH_F16 = 2 };
 int hash_scatter_mode();
 
-int launch_pack_weights(const float* params, float* packed, hipStream_t stream);
+int launch_pack_weights(const float* params, float* packed, int arith_mask, hipStream_t stream);
 
 // MLP chains (kernels_mlp.hip).  npts is padded by the caller to a multiple of 128 for saved buffers.
 int launch_sdf_nograd(const float* packed, const float* pts, int64_t npts, float* sdf, int grid, int arith, hipStream_t stream);

@@ -15,19 +15,32 @@ __global__ __launch_bounds__(256) void rowscale_kernel(const float* __restrict__
     int64_t goff, voff;
     if (is_sdf) { out = SDF_DIMS[l].out; in = SDF_DIMS[l].in; goff = sdf_off(l).g; voff = sdf_off(l).v; }
     else        { out = COL_DIMS[l].out; in = COL_DIMS[l].in; goff = col_off(l).g; voff = col_off(l).v; }
-    const int row = blockIdx.x * 4 + wave;
-    if (row >= out) return;
-    const float* v = params + voff + (int64_t)row * in;
-    float s = 0.f, vmax = 0.f;
-    for (int k = lane; k < in; k += 64) { s += v[k] * v[k]; vmax = fmaxf(vmax, fabsf(v[k])); }
-    for (int off = 32; off > 0; off >>= 1) { s += __shfl_xor(s, off); vmax = fmaxf(vmax, __shfl_xor(vmax, off)); }
-    if (lane == 0) {
-        const int64_t ro = PACK.rowscale + (is_sdf ? (int64_t)l * 260 : (int64_t)N_SDF * 260 + (int64_t)l * 256);
+    // a wave per row, 16 rows per workgroup; max |W| of the linear (the two-piece fp16 packs scale by a power of two derived from it:
+    // tile16h.h) is reduced over the workgroup's rows first: ONE atomicMax per workgroup (one per row -- 2,313 atomics on 14
+    // addresses -- made this kernel 40 us instead of 6)
+    __shared__ float wmax[4];
+    float rmax = 0.f;
+    for (int rr = 0; rr < 4; ++rr) {
+        const int row = (blockIdx.x * 4 + rr) * 4 + wave;
+        if (row >= out) break;
+        const float* v = params + voff + (int64_t)row * in;
+        float s = 0.f, vmax = 0.f;
+        for (int k = lane; k < in; k += 64) { s += v[k] * v[k]; vmax = fmaxf(vmax, fabsf(v[k])); }
+        for (int off = 32; off > 0; off >>= 1) { s += __shfl_xor(s, off); vmax = fmaxf(vmax, __shfl_xor(vmax, off)); }
         const float inv = 1.f / sqrtf(s);
-        packed[ro + row] = params[goff + row] * inv;
-        packed[ro + row + (PACK.invnorm - PACK.rowscale)] = inv;
-        // max |W| of the linear (the two-piece fp16 packs scale by a power of two derived from it: tile16h.h)
-        atomicMax(reinterpret_cast<unsigned*>(packed + PACKH.wabs) + job, __builtin_bit_cast(unsigned, fabsf(params[goff + row] * inv) * vmax));
+        const float gi = params[goff + row] * inv;
+        if (lane == 0) {
+            const int64_t ro = PACK.rowscale + (is_sdf ? (int64_t)l * 260 : (int64_t)N_SDF * 260 + (int64_t)l * 256);
+            packed[ro + row] = gi;
+            packed[ro + row + (PACK.invnorm - PACK.rowscale)] = inv;
+        }
+        rmax = fmaxf(rmax, fabsf(gi) * vmax);
+    }
+    if (lane == 0) wmax[wave] = rmax;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float m = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+        if (m > 0.f) atomicMax(reinterpret_cast<unsigned*>(packed + PACKH.wabs) + job, __builtin_bit_cast(unsigned, m));
     }
 }
 
@@ -276,18 +289,26 @@ static PackJobs build_jobs() {
     return J;
 }
 
-int launch_pack_weights(const float* params, float* packed, hipStream_t stream) {
-    static const PackJobs jobs = build_jobs();
+// arith_mask: bit a set = pack the operands of arithmetic a (kernels.h ARITH_*); the row scales, biases and the small fp32 vectors
+// every arithmetic reads are always written
+int launch_pack_weights(const float* params, float* packed, int arith_mask, hipStream_t stream) {
     (void)hipMemsetAsync(packed + PACKH.wabs, 0, 16 * sizeof(unsigned), stream);
-    hipLaunchKernelGGL(rowscale_kernel, dim3(65, N_SDF + N_COL), dim3(256), 0, stream, params, packed);
-    hipLaunchKernelGGL(pack_kernel, dim3(16, jobs.n), dim3(256), 0, stream, params, packed, jobs);
+    hipLaunchKernelGGL(rowscale_kernel, dim3(17, N_SDF + N_COL), dim3(256), 0, stream, params, packed);
     hipLaunchKernelGGL(pack_small_kernel, dim3(N_SDF + 1 + 4 + 1), dim3(256), 0, stream, params, packed);
-    static const PackJobs jobs16 = build_jobs_split(PACK16, PACKT.stream, 3);
-    hipLaunchKernelGGL(pack16_kernel, dim3(8, jobs16.n), dim3(256), 0, stream, params, packed, jobs16);
-    hipLaunchKernelGGL(packt_small_kernel, dim3(10), dim3(256), 0, stream, params, packed);
-    static const PackJobs jobsh = build_jobs_split(PACKH, PACKH.stream, 2);
-    hipLaunchKernelGGL(packh_kernel, dim3(8, jobsh.n), dim3(256), 0, stream, params, packed, jobsh);
-    hipLaunchKernelGGL(packth_small_kernel, dim3(11), dim3(256), 0, stream, params, packed);
+    if (arith_mask & (1 << ARITH_FP32)) {
+        static const PackJobs jobs = build_jobs();
+        hipLaunchKernelGGL(pack_kernel, dim3(16, jobs.n), dim3(256), 0, stream, params, packed, jobs);
+    }
+    if (arith_mask & (1 << ARITH_BF16)) {
+        static const PackJobs jobs16 = build_jobs_split(PACK16, PACKT.stream, 3);
+        hipLaunchKernelGGL(pack16_kernel, dim3(8, jobs16.n), dim3(256), 0, stream, params, packed, jobs16);
+        hipLaunchKernelGGL(packt_small_kernel, dim3(10), dim3(256), 0, stream, params, packed);
+    }
+    if (arith_mask & (1 << ARITH_F16)) {
+        static const PackJobs jobsh = build_jobs_split(PACKH, PACKH.stream, 2);
+        hipLaunchKernelGGL(packh_kernel, dim3(8, jobsh.n), dim3(256), 0, stream, params, packed, jobsh);
+        hipLaunchKernelGGL(packth_small_kernel, dim3(11), dim3(256), 0, stream, params, packed);
+    }
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 

@@ -139,8 +139,12 @@ class ParamStore:
         slices.append((deviation_network.variance, voff, 1))
         return int(L.dh_num_params()), slices, voff, int(L.dh_packed_floats())
 
-    def _pack(self):
-        _lib.check(_lib.lib().dh_pack_weights(_lib.ptr(self.flat), _lib.ptr(self.packed), _lib.stream()))
+    def _pack(self, arithmetic=None):
+        """arithmetic None: the operands of all three arithmetics (dh_pack_weights); else only that one's (dh_pack_weights_ex)."""
+        if arithmetic is None:
+            _lib.check(_lib.lib().dh_pack_weights(_lib.ptr(self.flat), _lib.ptr(self.packed), _lib.stream()))
+        else:
+            _lib.check(_lib.lib().dh_pack_weights_ex(int(arithmetic), _lib.ptr(self.flat), _lib.ptr(self.packed), _lib.stream()))
 
     def params(self):
         return [p for p, _, _ in self.slices]
@@ -158,12 +162,21 @@ class ParamStore:
         """Call after any write to ``flat`` that bypasses torch (the fused Adam kernel)."""
         self._manual_version += 1
 
-    def ensure_packed(self):
+    def ensure_packed(self, arithmetic=None):
+        """The packed-weights buffer, current for ``arithmetic`` (None: for every arithmetic).  The renderers ask for their own
+        arithmetic only, so a training step packs one operand set, not three; which sets are current is tracked per parameter
+        version, so a caller that switches arithmetic on unchanged parameters gets the missing set packed then."""
         # p.data aliases flat but keeps its own version counter, so fold every counter in
         ver = (self.flat._version, self._manual_version, sum(p._version for p, _, _ in self.slices))
         if ver != self._packed_version:
-            self._pack()
             self._packed_version = ver
+            self._packed_sets = set()
+        want = "all" if arithmetic is None else int(arithmetic)
+        have = getattr(self, "_packed_sets", set())
+        if "all" not in have and want not in have:
+            self._pack(arithmetic)
+            have.add(want)
+            self._packed_sets = have
         return self.packed
 
     def inv_s(self) -> torch.Tensor:

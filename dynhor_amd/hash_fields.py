@@ -93,7 +93,7 @@ class HashParamStore(ParamStore):
         slices.append((deviation_network.variance, voff, 1))
         return int(L.dh_hash_num_params()), slices, voff, int(L.dh_hash_packed_floats())
 
-    def _pack(self):
+    def _pack(self, arithmetic=None):          # (one arithmetic in this family)
         _lib.check(_lib.lib().dh_hash_pack_weights(_lib.ptr(self.flat), _lib.ptr(self.packed), _lib.stream()))
 
 

@@ -191,7 +191,7 @@ class NeuSRenderer:
         """sdf_network.sdf(pts) under no_grad: [N,3] -> [N,1]."""
         pts = pts.contiguous().float()
         out = torch.empty(pts.shape[0], device=pts.device)
-        self.store.ensure_packed()
+        self.store.ensure_packed(self._arith())
         self._net_sdf_nograd("sdf_nograd", pts, pts.shape[0], out)
         return out.view(-1, 1)
 
@@ -220,7 +220,7 @@ class NeuSRenderer:
     @torch.no_grad()
     def sample_z(self, rays_o, rays_d, near, far, perturb_overwrite=-1, t_rand=None):
         L = _lib.lib()
-        packed = self.store.ensure_packed()
+        packed = self.store.ensure_packed(self._arith())
         dev = rays_o.device
         B = rays_o.shape[0]
         ns = self.n_samples
@@ -268,7 +268,7 @@ class NeuSRenderer:
                       ray_grads=False):
         L = _lib.lib()
         st = self.store
-        packed = st.ensure_packed()
+        packed = st.ensure_packed(self._arith())
         dev = rays_o.device
         B, n = z_vals.shape
         P = B * n

@@ -147,6 +147,9 @@ int dh_color_backward_rays_ex(int arithmetic, const float* packed, const float* 
 int dh_sdf_backward_rays_ex(int arithmetic, const float* packed, const float* d_sdf, const float* pts, const float* d_normals,
                             int64_t npts, float* ws, float* d_pts, void* stream);
 int dh_weight_grads_gemm_ex(int arithmetic, int64_t npts, float* ws, void* stream);
+/* dh_pack_weights for ONE arithmetic: the row scales, biases and small fp32 vectors every arithmetic reads plus that arithmetic's
+ * MFMA operands only (a training step then packs one operand set instead of three). */
+int dh_pack_weights_ex(int arithmetic, const float* params, float* packed, void* stream);
 
 /* ---- per-ray stages ---------------------------------------------------------------------------------------
  * Mask-conditioned ray generation = upstream Dataset.gen_random_rays_at + near_far_from_sphere (App. A.8) under the

@@ -53,6 +53,7 @@ assert L.dh_workspace_floats(-1, ctypes.byref(i64()), ctypes.byref(i64()), ctype
 # argument validation: null pointers, negative sizes, misaligned buffers, unknown arithmetic
 mis = vp(0x7f0000000004)
 assert L.dh_pack_weights(null, fake, None) == -1 and L.dh_pack_weights(fake, mis, None) == -1
+assert L.dh_pack_weights_ex(9, fake, fake, None) == -1 and L.dh_pack_weights_ex(2, null, fake, None) == -1
 for ar in (0, 1, 2):
     assert L.dh_sdf_nograd_ex(ar, null, null, 0, null, None) == 0
     assert L.dh_sdf_nograd_ex(ar, null, fake, 5, fake, None) == -1 and L.dh_sdf_nograd_ex(ar, fake, fake, -1, fake, None) == -1
@@ -66,6 +67,8 @@ assert L.dh_set_arithmetic(9) == -1 and L.dh_hash_set_scatter_mode(5) == -1
 # host tables behind the launches: without a GPU every launch fails, after the job lists / partitions / descriptors were built
 no_gpu = L.dh_pack_weights(fake, fake, None)
 assert no_gpu in (-3, -2), no_gpu
+for ar in (0, 1, 2):
+    assert L.dh_pack_weights_ex(ar, fake, fake, None) in (-3, -2)
 for ar in (0, 1, 2):
     for n in (64, 100003, 262144):
         for rc in (L.dh_sdf_nograd_ex(ar, fake, fake, n, fake, None), L.dh_sdf_forward_ex(ar, fake, fake, n, fake, fake, None),

@@ -86,3 +86,63 @@ def test_tstream_holds_the_effective_weights_where_layout_h_says(hiplib, arith):
             assert b[10, l].item() == 1.0 / wscale[l]
     assert (b[8] - W[8][0]).abs().max() < 2e-6
     assert (b[9] - sd["lin8.bias"][1:]).abs().max() < 1e-7
+
+
+@pytest.mark.parametrize("ar", [0, 1, 2])
+def test_pack_ex_serves_its_arithmetic_exactly_like_the_full_packer(hiplib, ar):
+    """dh_pack_weights_ex(a) writes the common tables and arithmetic a's operands only: a forward + backward run from it must equal,
+    bit for bit, the run from dh_pack_weights' buffer (a NaN-poisoned buffer shows anything the selective packer forgot)."""
+    from dynhor_amd import _lib
+    dev = torch.device("cuda:0")
+    sdf, col, var = randomized_models(seed=7, device=dev, jitter=0.05)
+    flat = flat_from_oracle(sdf, var, col)
+    full = torch.empty(hiplib.dh_packed_floats(), device=dev)
+    _lib.check(hiplib.dh_pack_weights(_lib.ptr(flat), _lib.ptr(full), _lib.stream()))
+    part = torch.full((hiplib.dh_packed_floats(),), float("nan"), device=dev)
+    _lib.check(hiplib.dh_pack_weights_ex(ar, _lib.ptr(flat), _lib.ptr(part), _lib.stream()))
+    g = torch.Generator(device="cpu").manual_seed(3)
+    nrays, n_per_ray = 32, 64
+    npts = nrays * n_per_ray
+    pts = ((torch.rand(npts, 3, generator=g) * 2 - 1) * 0.9).to(dev)
+    dirs = torch.nn.functional.normalize(torch.randn(nrays, 3, generator=g), dim=-1).to(dev)
+    d_sdf = torch.randn(npts, generator=g).to(dev) * 1e-3
+    d_n = torch.randn(npts, 3, generator=g).to(dev) * 1e-3
+    d_c = torch.randn(npts, 3, generator=g).to(dev) * 1e-3
+    total = _lib.workspace_floats(npts)[2]
+    outs = []
+    for packed in (full, part):
+        ws = torch.zeros(total, device=dev)
+        o_sdf = torch.empty(npts, device=dev); o_n = torch.empty(npts, 3, device=dev); o_c = torch.empty(npts, 3, device=dev)
+        _lib.check(hiplib.dh_mlp_forward_ex(ar, _lib.ptr(packed), _lib.ptr(pts), _lib.ptr(dirs), n_per_ray, npts, _lib.ptr(ws),
+                                            _lib.ptr(o_sdf), _lib.ptr(o_n), _lib.ptr(o_c), _lib.stream()))
+        grad = torch.zeros(flat.numel(), device=dev)
+        dn = d_n.clone()
+        _lib.check(hiplib.dh_mlp_backward_ex(ar, _lib.ptr(packed), _lib.ptr(flat), _lib.ptr(pts), npts, _lib.ptr(ws), _lib.ptr(o_c),
+                                             _lib.ptr(d_sdf), _lib.ptr(dn), _lib.ptr(d_c), _lib.ptr(grad), _lib.stream()))
+        nog = torch.empty(npts, device=dev)
+        _lib.check(hiplib.dh_sdf_nograd_ex(ar, _lib.ptr(packed), _lib.ptr(pts), npts, _lib.ptr(nog), _lib.stream()))
+        torch.cuda.synchronize()
+        outs.append((o_sdf, o_n, o_c, grad, nog))
+    for a, b in zip(*outs):
+        assert torch.isfinite(b).all() and torch.equal(a, b)
+    with pytest.raises(_lib.DynhorHipError):
+        _lib.check(hiplib.dh_pack_weights_ex(5, _lib.ptr(flat), _lib.ptr(part), _lib.stream()))
+
+
+def test_param_store_packs_only_what_a_renderer_asks_for_and_tracks_it(tmp_path):
+    from dynhor_amd import _lib
+    from dynhor_amd.runner import Runner
+    conf = {"seq_name": "pk", "exp_name": "e", "data_info": {"synthetic": {"n_frames": 4, "H": 64, "W": 64, "seed": 3}},
+            "train": {"batch_size": 256, "report_freq": 10 ** 9, "save_freq": 10 ** 9, "val_freq": 0}}
+    r = Runner(conf=conf, device="cuda:0", exp_root=str(tmp_path))
+    st = r.store
+    calls = []
+    orig = st._pack
+    st._pack = lambda arithmetic=None: (calls.append(arithmetic), orig(arithmetic))[1]
+    r.train_iteration()
+    assert calls == [_lib.ARITH_DEFAULT]                       # one operand set per step
+    st.ensure_packed(_lib.ARITH_DEFAULT); assert len(calls) == 2   # (the optimiser step changed the parameters)
+    st.ensure_packed(_lib.ARITH_DEFAULT); assert len(calls) == 2
+    st.ensure_packed(_lib.ARITH_FP32_MFMA); assert calls[-1] == _lib.ARITH_FP32_MFMA and len(calls) == 3
+    st.ensure_packed(); assert calls[-1] is None and len(calls) == 4            # everything
+    st.ensure_packed(_lib.ARITH_SPLIT_BF16); assert len(calls) == 4              # covered by "everything"
