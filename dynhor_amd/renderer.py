@@ -183,7 +183,7 @@ class NeuSRenderer:
               _lib.stream())
             T("sdf_tangent", L.dh_sdf_tangent_ex, ar, _p(st.packed), _p(s.pts), _p(d_normals), P, _p(s.ws), _lib.stream())
             T("sdf_backward", L.dh_sdf_backward_ex, ar, _p(st.packed), _p(d_sdf), P, _p(s.ws), _lib.stream())
-        T("weight_grads_gemm", L.dh_weight_grads_gemm_ex, getattr(self, "_dw_arith", ar), P, _p(s.ws), _lib.stream())
+        T("weight_grads_gemm", L.dh_weight_grads_gemm_ex, ar, P, _p(s.ws), _lib.stream())
         T("weight_grads_fold", L.dh_weight_grads_fold, _p(st.packed), _p(st.flat), P, _p(s.ws), _p(grad), _lib.stream())
 
     # ------------------------------------------------------------------ no-grad SDF queries
