@@ -1,15 +1,19 @@
 // The five tile-resident MLP chains in the two-piece fp16 arithmetic (DH_ARITH_SPLIT_F16; round 4): colour forward, input-gradient
 // (reverse) chain, colour backward, tangent chain, SDF backward.  Same saved tiles, outputs and tile-partial sums as the
 // `<name>_s_kernel` forms in kernels_mlp.hip / kernels_mlp_bwd.hip (whose headers hold the maths); what differs is the GEMM core
-// (tile16h.h: three v_mfma_f32_32x32x16_f16 per fp32 product instead of six bf16 ones, A split on fetch at 2 vector ops per value)
-// and the operand scaling it needs:
-//   * the LDS main image holds S x (fp32), S = the power of two that puts the tile's own maximum into [256, 512): every wave
-//     publishes the maximum of its slice before the barrier the chains already have, everyone derives S behind it;
-//   * the small aux images stay unscaled in LDS and are scaled as they are fetched;
+// (tile16h.h: three v_mfma_f32_32x32x16_f16 per fp32 product instead of six bf16 ones), the LDS image, the tile I/O and the operand
+// scaling:
+//   * the LDS main image holds the PIECES of S x: two fp16 planes, written once by the wave that produces a value (lds_handoff ->
+//     acc_to_lds_split), read as ready MFMA operands; S = the power of two that puts the tile's own maximum into [256, 512): every
+//     wave publishes the maximum of its slice before the barrier the chains already have, everyone derives S behind it;
+//   * the small aux images stay unscaled fp32 in LDS and are scaled and split as they are fetched (gemm_rows_aux_h);
 //   * a GEMM's result carries S * S_w (S_w: the linear's weight scale, layout.h PACKH.wabs): its reciprocal -- a power of two,
 //     so the product is exact -- multiplies the accumulator in the epilogue's first operation;
+//   * saved tiles and weights go through buffer descriptors (tile_rsrc / tile_ld / tile_st, weight_rsrc): scalar bases, one 32-bit
+//     lane offset for every stream; the one-stream kernels request their epilogue's first m-slab inside the GEMM's tail;
 //   * the per-launch maximum of every saved-tile class the weight-gradient kernel reads (workspace.h absmax) is kept as a running
-//     maximum per workgroup and posted with one atomicMax per class at the workgroup's end.
+//     maximum per workgroup and posted with one atomicMax per class at the workgroup's end; per-tile maxima of the heavy-tailed
+//     classes go to workspace.h tmax.
 #include "tile.h"
 #include "kernels.h"
 #include "mlp_common.h"
