@@ -536,6 +536,157 @@ __device__ __forceinline__ void dw_body_pieces_h(const DwJob& J, const DwScales&
         }
 }
 
+#ifdef DW_AUX_PROBE
+// Development probe (scripts/build_variant.sh -DDW_AUX_PROBE; scripts/det_dw.py --probe): the aux jobs in the two-piece arithmetic
+// again -- the body that is not bitwise reproducible (profiles/r04_dw_aux_reproducibility.json) -- instrumented to say WHERE a value
+// goes wrong.  Counters (one word each, atomicAdd; read with dh_dev_read_dw_probe):
+//   [0] a writer wave (0 / 1) reads its own B tile back behind the barrier and finds something else than the registers it wrote
+//   [1] a wave reads B tile 8 twice within one step (the buffer is not written in that step) and the two reads differ
+//   [2] the split of the SAME raw registers, repeated, gives different pieces (vector-ALU / inline-asm hazard)
+//   [3] the raw B registers change between their use and the next load into them (a load landing late)
+//   [4] steps checked
+__device__ unsigned dw_probe_counters[8];
+__device__ __forceinline__ bool h2_differs(const H2& a, const H2& b) {
+    bool d = false;
+    DH_UNROLL for (int p = 0; p < 2; ++p) DH_UNROLL for (int i = 0; i < 4; ++i) d |= a.p[p][i] != b.p[p][i];
+    return d;
+}
+__device__ __forceinline__ void dw_body_aux_probe(const DwJob& J, const DwScales& sc, int64_t t0, int64_t t1, float* __restrict__ out,
+                                                  int wave, int lane, char* lds) {
+    constexpr int KQ = MT * 4;
+    f32x16 acc[2];
+    DH_UNROLL for (int j = 0; j < 2; ++j) DH_UNROLL for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    const int T = (int)(t1 - t0);
+    const int npairs = J.A2 ? 2 : 1;
+    const int NP1 = T * (KQ / 2);
+    const int NP = npairs * NP1;
+    const bool has_b = wave < 2;
+    struct Raw { f32x4 a0, a1, b0, b1; float sa, sb; };
+    int ld_pair = 0, ld_kp = 0;
+    int64_t ld_tile = t0;
+    auto load = [&](Raw& r) {
+        const float* A = ld_pair ? J.A2 : J.A1;
+        const float* Bm = ld_pair ? J.B2 : J.B1;
+        {
+            const unsigned sxb = pow2_scale_bits((ld_pair ? sc.xt1 : sc.xt0)[ld_tile], H2_AT);
+            const float sx = __builtin_bit_cast(float, sxb), sy = (ld_pair ? sc.prod1 : sc.prod0) * __builtin_bit_cast(float, pow2_inv_bits(sxb));
+            const bool ha = ld_pair ? sc.heavy_a1 : sc.heavy_a0;
+            r.sa = ha ? sx : sy;
+            r.sb = ha ? sy : sx;
+        }
+        const int kq = 2 * ld_kp, m = kq >> 2, r4 = kq & 3;
+        const f32x4* ga = reinterpret_cast<const f32x4*>(A + ld_tile * TILE_F) + ((((wave >> 1) * MT + m) * 2 + (wave & 1)) * 4 + r4) * 64 + lane;
+        r.a0 = __builtin_nontemporal_load(ga); r.a1 = __builtin_nontemporal_load(ga + 64);
+        if (has_b) {
+            const f32x4* gb = reinterpret_cast<const f32x4*>(Bm + ld_tile * AUXT_F) + ((m * 2 + (wave & 1)) * 4 + r4) * 64 + lane;
+            r.b0 = __builtin_nontemporal_load(gb); r.b1 = __builtin_nontemporal_load(gb + 64);
+        }
+        if (++ld_kp == KQ / 2) {
+            ld_kp = 0;
+            if (++ld_tile == t1) { ld_tile = t0; if (++ld_pair == npairs) ld_pair = 0; }
+        }
+    };
+    auto piece = [&](int par, int tile) {
+        H2 f;
+        const char* base = lds + par * DWH_BUF + tile * DWH_TILE + lane * 16;
+        DH_UNROLL for (int p = 0; p < 2; ++p) f.p[p] = *reinterpret_cast<const volatile u32x4*>(base + p * 1024);
+        return f;
+    };
+    auto publish_a = [&](const Raw& r, int par) {
+        char* base = lds + par * DWH_BUF + lane * 16;
+        const H2 pa = split2(r.a0 * r.sa, r.a1 * r.sa);
+        DH_UNROLL for (int p = 0; p < 2; ++p) *reinterpret_cast<u32x4*>(base + wave * DWH_TILE + p * 1024) = pa.p[p];
+    };
+    H2 wrote;                                          // what this wave last published as its B tile
+    DH_UNROLL for (int p = 0; p < 2; ++p) DH_UNROLL for (int i = 0; i < 4; ++i) wrote.p[p][i] = 0u;
+    auto publish_b = [&](const Raw& r, int par) {
+        char* base = lds + par * DWH_BUF + lane * 16;
+        if (has_b) {
+            const f32x4 rb0 = r.b0, rb1 = r.b1;
+#ifdef DW_AUX_PROBE_SCALAR_MUL
+            // the scale applied by eight single v_mul_f32 (inline asm: the compiler cannot pair them into v_pk_mul_f32)
+            f32x4 m0, m1;
+            DH_UNROLL for (int i = 0; i < 4; ++i) {
+                asm volatile("v_mul_f32 %0, %1, %2" : "=v"(m0[i]) : "v"(rb0[i]), "v"(r.sb));
+                asm volatile("v_mul_f32 %0, %1, %2" : "=v"(m1[i]) : "v"(rb1[i]), "v"(r.sb));
+            }
+            const H2 pb = split2(m0, m1);
+#else
+            const H2 pb = split2(rb0 * r.sb, rb1 * r.sb);
+#endif
+            DH_UNROLL for (int p = 0; p < 2; ++p) *reinterpret_cast<u32x4*>(base + (8 + (wave & 1)) * DWH_TILE + p * 1024) = pb.p[p];
+#ifndef DW_AUX_PROBE_NOCHECK
+            // [2]: the same split once more, kept apart from the first by an asm barrier the compiler cannot merge across
+            f32x4 c0 = rb0, c1 = rb1;
+            asm volatile("" : "+v"(c0), "+v"(c1));
+            const H2 pb2 = split2(c0 * r.sb, c1 * r.sb);
+            if (h2_differs(pb, pb2)) atomicAdd(&dw_probe_counters[2], 1u);
+            // [3]: the raw registers still hold what was split
+            f32x4 d0 = r.b0, d1 = r.b1;
+            asm volatile("" : "+v"(d0), "+v"(d1));
+            bool ch = false;
+            DH_UNROLL for (int i = 0; i < 4; ++i) ch |= (__builtin_bit_cast(unsigned, d0[i]) != __builtin_bit_cast(unsigned, rb0[i])) | (__builtin_bit_cast(unsigned, d1[i]) != __builtin_bit_cast(unsigned, rb1[i]));
+            if (ch) atomicAdd(&dw_probe_counters[3], 1u);
+            wrote = pb;
+#endif
+        }
+    };
+    if (NP > 0) {
+        Raw r0, r1;
+        load(r0);
+        load(r1);
+        __builtin_amdgcn_sched_barrier(0);
+        publish_a(r0, 0);
+        publish_b(r0, 0);
+        load(r0);
+        __syncthreads();
+        auto step = [&](int par, Raw& nxt) {
+            const H2 a = piece(par, wave), b0 = piece(par, 8), b1 = piece(par, 9);
+#ifndef DW_AUX_PROBE_NOCHECK
+            if (has_b) {                               // [0]: my own tile, as the readers see it now
+                const H2 mine = piece(par, 8 + (wave & 1));
+                if (h2_differs(mine, wrote)) atomicAdd(&dw_probe_counters[0], 1u);
+            }
+#endif
+            __builtin_amdgcn_sched_barrier(0);
+            publish_a(nxt, par ^ 1);
+            acc[0] = mfma3(a, b0, acc[0]);
+            __builtin_amdgcn_sched_barrier(0);
+            publish_b(nxt, par ^ 1);
+            acc[1] = mfma3(a, b1, acc[1]);
+            __builtin_amdgcn_sched_barrier(0);
+#ifndef DW_AUX_PROBE_NOCHECK
+            {                                          // [1]: tile 8 once more, late in the step
+                const H2 again = piece(par, 8);
+                if (h2_differs(again, b0)) atomicAdd(&dw_probe_counters[1], 1u);
+            }
+            if (wave == 0 && lane == 0) atomicAdd(&dw_probe_counters[4], 1u);
+#endif
+            load(nxt);
+            __builtin_amdgcn_sched_barrier(0);
+            __syncthreads();
+        };
+        const float ratio = npairs == 2 ? sc.prod1 / sc.prod0 : 1.f;
+        auto rescale = [&](int p) {
+            if (npairs == 2 && p == NP1) {
+                DH_UNROLL for (int j = 0; j < 2; ++j) DH_UNROLL for (int r = 0; r < 16; ++r) acc[j][r] *= ratio;
+            }
+        };
+        int p = 0;
+        for (; p + 1 < NP; p += 2) {
+            rescale(p); step(0, r1);
+            rescale(p + 1); step(1, r0);
+        }
+        if (p < NP) { rescale(p); step(0, r1); }
+    }
+    const float inv = 1.f / (npairs == 2 ? sc.prod1 : sc.prod0);
+    DH_UNROLL for (int j = 0; j < 2; ++j) {
+        float* o = out + ((int64_t)wave * 2 + j) * 1024 + lane;
+        DH_UNROLL for (int r = 0; r < 16; ++r) o[r * 64] = acc[j][r] * inv;
+    }
+}
+#endif
+
 __global__ __launch_bounds__(512, 1) void dw_f16x2_kernel(DwJobs jobs, DwGroups groups, int64_t ntiles, float* __restrict__ slabs,
                                                           int64_t gstride, const unsigned* __restrict__ absmax,
                                                           const unsigned* __restrict__ tmax) {
@@ -553,9 +704,14 @@ __global__ __launch_bounds__(512, 1) void dw_f16x2_kernel(DwJobs jobs, DwGroups 
         // Their two-piece form was NOT bitwise reproducible: about one launch in 5,000 differed from the others in the 16 output
         // columns 16..31 of ONE workgroup's slab by ~1e-3 of one k-pair's contribution (the size of a lo piece), with every barrier
         // and wait in place and under every timing / nop / register variant tried (profiles/r04_dw_aux_reproducibility.json); the
-        // main jobs' two-piece body and this body are bitwise reproducible over 100,000 launches.
+        // -DDW_AUX_PROBE build above traced it to the packed-fp32 scale multiplies of the B-tile publish (in the shadow of the wave's
+        // own dependent MFMAs).  The main jobs' two-piece body and this body are bitwise reproducible over 350,000 launches.
         if (J.nb == 8) dw_body_pieces_h<8>(J, sc, t0, t1, base + J.off, wave, lane, pieces);
+#ifdef DW_AUX_PROBE
+        else dw_body_aux_probe(J, sc, t0, t1, base + J.off, wave, lane, pieces);
+#else
         else dw_body_pieces<2>(J, t0, t1, base + J.off, wave, lane, pieces);
+#endif
     }
 }
 
@@ -837,3 +993,11 @@ int launch_weight_grads_fold(const Workspace& w, float* slabs, float* tred, int 
 }
 
 }  // namespace dh
+
+#ifdef DW_AUX_PROBE
+extern "C" int dh_dev_read_dw_probe(unsigned* out8, int reset) {
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(dh::dw_probe_counters), 8 * sizeof(unsigned)) != hipSuccess) return -3;
+    if (reset) { unsigned z[8] = {0, 0, 0, 0, 0, 0, 0, 0}; if (hipMemcpyToSymbol(HIP_SYMBOL(dh::dw_probe_counters), z, sizeof(z)) != hipSuccess) return -3; }
+    return 0;
+}
+#endif

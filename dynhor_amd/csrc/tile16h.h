@@ -36,8 +36,15 @@ __device__ __forceinline__ unsigned pack_f16x2(f32x2 v) { return __builtin_bit_c
 // v - float(h.lo), v - float(h.hi): one v_fma_mix_f32 each, the f16 half read in place (exact: |v - h| <= ulp_f16 / 2)
 __device__ __forceinline__ f32x2 resid_f16x2(f32x2 v, unsigned h) {
     f32x2 r;
+#ifdef H2_VISIBLE_RESID
+    // (development: the same residual from instructions the compiler sees -- its hazard recognizer does not look inside inline asm)
+    const f16x2v hv = __builtin_bit_cast(f16x2v, h);
+    r[0] = v[0] - (float)hv[0];
+    r[1] = v[1] - (float)hv[1];
+#else
     asm("v_fma_mix_f32 %0, -%1, 1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r[0]) : "v"(h), "v"(v[0]));
     asm("v_fma_mix_f32 %0, -%1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r[1]) : "v"(h), "v"(v[1]));
+#endif
     return r;
 }
 __device__ __forceinline__ f32x16 mfma_h(const u32x4& a, const u32x4& b, const f32x16& c) {

@@ -55,4 +55,14 @@ for rep in range(N):
                         rel = float((cf - rf).abs().max() / rf.abs().max())
                         lanes = sorted(set(w.nonzero()[:, 2].tolist()))
                         print("rep", rep, "job", j, "wg", wg, "(out tile, n tile, words):", tiles[:16], "max diff / max", rel, "lanes", lanes, "r", sorted(set(w.nonzero()[:, 1].tolist())), flush=True)
+if len(sys.argv) > 4 and sys.argv[4] == "--probe":          # a -DDW_AUX_PROBE build: where did the values go wrong?
+    import ctypes
+    buf = (ctypes.c_uint * 8)()
+    fn = L.dh_dev_read_dw_probe
+    fn.restype = ctypes.c_int
+    fn.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    torch.cuda.synchronize()
+    assert fn(ctypes.cast(buf, ctypes.c_void_p), 0) == 0
+    print("probe counters: own tile read back differs", buf[0], "| two reads of tile 8 in one step differ", buf[1], "| repeated split differs", buf[2],
+          "| raw registers changed", buf[3], "| steps checked", buf[4])
 print("arith", AR, "lib", sys.argv[2] if len(sys.argv) > 2 else "default", "reruns", N - 1, "launches differing from the first:", bad, "by job:", per_job)
