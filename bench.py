@@ -122,20 +122,56 @@ def cpu_baseline(rays, R, n_samples, n_importance, normal_weight, family="neus",
                       f"backward, Adam), 1 warm-up + 2 timed, fp32, {dt:.2f} s/iter"}
 
 
+def _delta_stats(w):
+    ps = w.get("per_seed") or []
+    return {"mean": round(w["mean_db"], 4), "se": round(w["se_db"], 4), "seeds": w["n"],
+            "median": round(w["median_db"], 4) if "median_db" in w else None,
+            "worst_seed": round(min(ps), 4) if ps else None, "best_seed": round(max(ps), 4) if ps else None}
+
+
 def committed_psnr_record():
     """`psnr_at_2k` of the default line: the pooled paired-seed record committed under profiles/ (measuring it costs ~4 GPU-minutes
-    per seed: `--psnr` does that instead).  The newest round's file wins."""
+    per seed: `--psnr` does that instead).  The newest round's file wins.  Both statistics of the record are carried: the WINDOW of
+    checkpoints at 1800..2000 iterations (`delta` / `se`: the protocol's headline) and the FINAL checkpoint at exactly 2000."""
     import glob
-    for pat in ("psnr_parity_r04_neus_hip_vs_oracle_f16_pooled.json", "psnr_parity_r03_neus_hip_vs_oracle_59seeds.json"):
+    for pat in ("psnr_parity_r05_neus_hip_vs_oracle_f16_pooled.json", "psnr_parity_r04_neus_hip_vs_oracle_f16_pooled.json",
+                "psnr_parity_r03_neus_hip_vs_oracle_59seeds.json"):
         for path in sorted(glob.glob(os.path.join(ROOT, "profiles", pat))):
             d = json.load(open(path))
             w = d.get("window_delta") or d.get("all_seeds") or d.get("all_59_seeds")
-            return {"source": "profiles/" + os.path.basename(path), "delta": round(w["mean_db"], 4), "se": round(w["se_db"], 4),
-                    "seeds": w["n"], "median": round(w.get("median_db", float("nan")), 4) if "median_db" in w else None,
-                    "what": d.get("what", "HIP minus oracle, paired seeds, PSNR over all 64 frames in a window of checkpoints at 1800..2000 "
-                                          "iterations (scripts/psnr_parity.py)"),
-                    "arithmetic": d.get("arithmetic", "split_bf16 (rounds 2-3)")}
+            out = {"source": "profiles/" + os.path.basename(path), "delta": round(w["mean_db"], 4), "se": round(w["se_db"], 4),
+                   "seeds": w["n"], "median": round(w.get("median_db", float("nan")), 4) if "median_db" in w else None,
+                   "window": _delta_stats(w),
+                   "final_checkpoint": _delta_stats(d["final_delta"]) if "final_delta" in d else None,
+                   "what": d.get("what", "HIP minus oracle, paired seeds, PSNR over all 64 frames in a window of checkpoints at 1800..2000 "
+                                         "iterations (scripts/psnr_parity.py)"),
+                   "arithmetic": d.get("arithmetic", "split_bf16 (rounds 2-3)")}
+            nf = sorted(glob.glob(os.path.join(ROOT, "profiles", "psnr_r05_hip_noise_floor_*.json")))
+            if nf:
+                n = json.load(open(nf[-1]))
+                out["hip_noise_floor"] = {"source": "profiles/" + os.path.basename(nf[-1]),
+                                          "window": _delta_stats(n["window_delta"]), "final_checkpoint": _delta_stats(n["final_delta"]),
+                                          "what": n.get("what")}
+            return out
     return None
+
+
+def lib_identity():
+    """Which library bytes ran (VERDICT r4 weak #10): sha256 of the loaded .so and the stamp build() left beside it."""
+    import hashlib
+    from dynhor_amd import _lib
+    h = hashlib.sha256(open(_lib.LIB_PATH, "rb").read()).hexdigest()[:16]
+    stamp = os.path.join(os.path.dirname(_lib.LIB_PATH), "libdynhor_hip.build.json")
+    build = None
+    if os.path.exists(stamp):
+        try:
+            st = json.load(open(stamp))
+            build = ({"mode": st.get("last_build_call"), "sources_sha16": st.get("sources_sha16"),
+                      "hipcc": st.get("hipcc"), "flags": st.get("flags")} if st.get("lib_sha16") == h
+                     else {"mode": "unknown (the stamp beside the library is of another build)"})
+        except (OSError, ValueError):
+            build = None
+    return h, build
 
 
 def main():
@@ -168,6 +204,7 @@ def main():
     ap.add_argument("--check-sync", action="store_true", help="(default at N > 1) verify all ranks hold identical parameters at the end")
     ap.add_argument("--no-check-sync", action="store_true")
     ap.add_argument("--force-dist", action="store_true", help="TEST ONLY: initialise the process group even for one rank")
+    ap.add_argument("--lib", type=str, default=None, help="DEVELOPMENT: another build of the library (scripts/build_variant.sh), for same-box A/Bs")
     args = ap.parse_args()
 
     from dynhor_amd import launch
@@ -210,6 +247,8 @@ def main():
     torch.cuda.set_device(device)
 
     from dynhor_amd import _lib
+    if args.lib:
+        _lib.LIB_PATH = os.path.join(ROOT, args.lib)
     from dynhor_amd.runner import Runner
 
     def bench_line(args, restore_stdout):
@@ -423,35 +462,47 @@ def main():
                         v["algorithmic_hbm_bytes"] = nbytes
                         v["hbm_gbps"] = round(nbytes / (v["ms"] * 1e-3) / 1e9, 1)
                         v["frac_of_hbm_peak"] = round(nbytes / (v["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)
-                # which roofline bounds the dominant kernel: the one that allows it the LONGER time.  With three products per fp32
-                # product the saved-tile kernels (tangent, backward, weight gradients) have more HBM time than matrix time.
+                # the roofline that bounds this path is the MATRIX pipe (> 99 % of the algorithmic FLOPs are the MLP
+                # GEMMs; fused, the algorithmic HBM traffic is ~23 MB per step) -- so `frac` = algorithmic fp32-product FLOP/s of the
+                # dominant kernel / the ceiling of its instruction mix.  The save-everything data flow of THIS design
+                #  puts the large kernels on an HBM floor of their own: that engineering view rides along as
+                # `design_floor` (design_bytes = the saved tiles the stage must read or write once; NOT section 8(d)'s algorithmic bytes).
                 d = per_kernel[dom]
                 t_mfma = 2.0 * MACS[dom] * pts.get(dom, P) / (peak * 1e12)
                 t_hbm = d.get("algorithmic_hbm_bytes", 0) / (HBM_PEAK_GBPS * 1e9)
-                mfma_view = {"achieved_tflops": d["tflops"], "peak_tflops": round(peak, 1), "frac": round(d["tflops"] / peak, 4),
-                             "peak_basis": (f"fp16 / bf16 dense MFMA 2500 TFLOP/s / {int(nprod)} split products per fp32 product" if split
-                                            else "fp32 MFMA v_mfma_f32_32x32x2_f32"),
-                             "frac_of_six_product_peak": round(d["tflops"] / (BF16_MFMA_PEAK_TFLOPS / 6.0), 4),
-                             "frac_of_fp32_mfma_peak": round(d["tflops"] / FP32_MFMA_PEAK_TFLOPS, 4)}
-                if t_hbm > t_mfma:
-                    roof = {"bound": "hbm", "kernel": names[dom], "stage": dom, "achieved": d["hbm_gbps"], "peak": HBM_PEAK_GBPS,
-                            "unit": "GB/s", "frac": d["frac_of_hbm_peak"],
-                            "frac_of_achievable_6290": round(d["hbm_gbps"] / HBM_ACHIEVABLE_GBPS, 4),
-                            "algorithmic_bytes": d["algorithmic_hbm_bytes"],
-                            "why": f"at peak rates this launch needs {t_hbm * 1e3:.2f} ms of HBM time against {t_mfma * 1e3:.2f} ms of matrix time",
-                            "mfma_view": mfma_view}
-                else:
-                    roof = {"bound": "mfma", "kernel": names[dom], "stage": dom, "achieved": d["tflops"], "peak": round(peak, 1),
-                            "unit": "TFLOP/s", "frac": round(d["tflops"] / peak, 4), **{k: v for k, v in mfma_view.items() if k.startswith("peak_basis") or k.startswith("frac_of")},
-                            "hbm_view": {"achieved_gbps": d.get("hbm_gbps"), "frac": d.get("frac_of_hbm_peak")}}
+                roof = {"bound": "mfma", "kernel": names[dom], "stage": dom, "achieved": d["tflops"], "peak": round(peak, 1),
+                        "unit": "TFLOP/s", "frac": round(d["tflops"] / peak, 4),
+                        "peak_basis": (f"dense fp16 / bf16 MFMA 2500 TFLOP/s / {int(nprod)} matrix products per fp32 product "
+                                       f"(the {'three' if nprod == 3 else 'six'}-product ceiling of this arithmetic)" if split
+                                       else "fp32 MFMA v_mfma_f32_32x32x2_f32"),
+                        "algorithmic_flop": 2 * MACS[dom] * pts.get(dom, P),
+                        "frac_of_six_product_peak": round(d["tflops"] / (BF16_MFMA_PEAK_TFLOPS / 6.0), 4),
+                        "frac_of_fp32_mfma_peak": round(d["tflops"] / FP32_MFMA_PEAK_TFLOPS, 4),
+                        "design_floor": {"design_bytes": d.get("algorithmic_hbm_bytes"), "achieved_gbps": d.get("hbm_gbps"),
+                                         "frac_of_hbm_peak_8000": d.get("frac_of_hbm_peak"),
+                                         "frac_of_achievable_6290": None if d.get("hbm_gbps") is None else round(d["hbm_gbps"] / HBM_ACHIEVABLE_GBPS, 4),
+                                         "why": f"at peak rates this launch needs {t_hbm * 1e3:.2f} ms of HBM time for its saved tiles against "
+                                                f"{t_mfma * 1e3:.2f} ms of matrix time: within this data flow it is "
+                                                + ("HBM-bound" if t_hbm > t_mfma else "matrix-bound")}}
                 step_tf = value / world * FLOP_PER_RAY_TRAIN / 1e12
                 step_bytes = sum(v.get("algorithmic_hbm_bytes", 0) for v in per_kernel.values())
+                # counter HBM bytes of one whole step (every committed per-stage PMC entry that was taken on the kernel this run used)
+                # over section 8(d)'s algorithmic bytes per step: fused Adam (7 words per parameter) + the ray gather
+                s8d_bytes = 802491 * 7 * 4 + B * (8 + 56)
+                counter_step = 0.0
+                for k, v in per_kernel.items():
+                    tb, _ = offline_traffic(k, names.get(k))
+                    if tb is not None:
+                        counter_step += tb * v["launches_per_step"]
                 roof.update({"traffic": traffic, "traffic_source": tsrc, "avg_launch_ms": d["ms"],
+                             "traffic_ratio": None if counter_step == 0 else round(counter_step / s8d_bytes, 1),
+                             "traffic_ratio_basis": f"counter HBM bytes of one step ({counter_step / 1e9:.2f} GB over the MLP stages) / SURVEY.md "
+                                                    f"section 8(d) algorithmic bytes per step ({s8d_bytes / 1e6:.1f} MB: Adam + ray gather)",
                              "whole_step_tflops": round(step_tf, 2), "whole_step_frac_of_peak": round(step_tf / peak, 4),
                              "whole_step_frac_of_six_product_peak": round(step_tf / (BF16_MFMA_PEAK_TFLOPS / 6.0), 4),
                              "whole_step_frac_of_fp32_mfma_peak": round(step_tf / FP32_MFMA_PEAK_TFLOPS, 4),
-                             "whole_step_algorithmic_hbm_gbps": round(step_bytes / (ms * 1e-3) / 1e9, 1),
-                             "whole_step_frac_of_hbm_peak": round(step_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)})
+                             "whole_step_design_hbm_gbps": round(step_bytes / (ms * 1e-3) / 1e9, 1),
+                             "whole_step_design_frac_of_hbm_peak": round(step_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)})
                 workload = (f"custom_shoes-shaped synthetic seq, 512x512, {B} rays x (64+64) samples per rank, "
                             "NeuS SDF(8x256, skip 4, softplus100) + colour(4x256) MLP, full training iteration")
                 arithmetic = {"fp32_mfma": "fp32 everywhere, every GEMM on v_mfma_f32_32x32x2_f32 (--arithmetic fp32_mfma)",
@@ -468,7 +519,7 @@ def main():
                               "loss": "rgb L1 + 0.1 eikonal + 0.1 mask BCE + 0.05 mono-normal"
                                       + (" + 0.1 dense-correspondence reprojection (Huber 4 px) on 25 % of the rays" if full else ""),
                               "arithmetic": arithmetic},
-                   "roofline": roof, "kernels": per_kernel,
+                   "roofline": roof, "kernels": per_kernel, "lib_sha16": lib_identity()[0], "build": lib_identity()[1],
                    "final_stats": {"loss": round(float(stats[0]), 5), "psnr": round(float(stats[5]), 3)}}
             if comm is not None:
                 out["comm"] = comm

@@ -536,23 +536,11 @@ __device__ __forceinline__ void dw_body_pieces_h(const DwJob& J, const DwScales&
         }
 }
 
-#ifdef DW_AUX_PROBE
-// Development probe (scripts/build_variant.sh -DDW_AUX_PROBE; scripts/det_dw.py --probe): the aux jobs in the two-piece arithmetic
-// again -- the body that is not bitwise reproducible (profiles/r04_dw_aux_reproducibility.json) -- instrumented to say WHERE a value
-// goes wrong.  Counters (one word each, atomicAdd; read with dh_dev_read_dw_probe):
-//   [0] a writer wave (0 / 1) reads its own B tile back behind the barrier and finds something else than the registers it wrote
-//   [1] a wave reads B tile 8 twice within one step (the buffer is not written in that step) and the two reads differ
-//   [2] the split of the SAME raw registers, repeated, gives different pieces (vector-ALU / inline-asm hazard)
-//   [3] the raw B registers change between their use and the next load into them (a load landing late)
-//   [4] steps checked
-__device__ unsigned dw_probe_counters[8];
-__device__ __forceinline__ bool h2_differs(const H2& a, const H2& b) {
-    bool d = false;
-    DH_UNROLL for (int p = 0; p < 2; ++p) DH_UNROLL for (int i = 0; i < 4; ++i) d |= a.p[p][i] != b.p[p][i];
-    return d;
-}
-__device__ __forceinline__ void dw_body_aux_probe(const DwJob& J, const DwScales& sc, int64_t t0, int64_t t1, float* __restrict__ out,
-                                                  int wave, int lane, char* lds) {
+// The aux jobs (64-wide B operand: jobs 0, 8, 11) in the two-piece arithmetic: wave w owns output rows [32w, 32w+32) x 64 columns
+// (two accumulators), waves 0 / 1 publish the two B tiles.  Two raw register sets alternate with the two piece buffers.
+// DW_AUX_V_*: development variants of scripts/micro/dw_aux_hazard_micro.hip (the irreproducibility hunt).
+__device__ __forceinline__ void dw_body_aux_h(const DwJob& J, const DwScales& sc, int64_t t0, int64_t t1, float* __restrict__ out,
+                                              int wave, int lane, char* lds) {
     constexpr int KQ = MT * 4;
     f32x16 acc[2];
     DH_UNROLL for (int j = 0; j < 2; ++j) DH_UNROLL for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
@@ -589,46 +577,49 @@ __device__ __forceinline__ void dw_body_aux_probe(const DwJob& J, const DwScales
     auto piece = [&](int par, int tile) {
         H2 f;
         const char* base = lds + par * DWH_BUF + tile * DWH_TILE + lane * 16;
+#ifdef DW_AUX_V_VOLATILE_PIECES
         DH_UNROLL for (int p = 0; p < 2; ++p) f.p[p] = *reinterpret_cast<const volatile u32x4*>(base + p * 1024);
+#else
+        DH_UNROLL for (int p = 0; p < 2; ++p) f.p[p] = *reinterpret_cast<const u32x4*>(base + p * 1024);
+#endif
         return f;
+    };
+    auto scaled_split = [&](const f32x4& x0, const f32x4& x1, float s) {
+#if defined(DW_AUX_V_SCALAR_MUL)
+        // the scale applied by eight single v_mul_f32 (inline asm: the compiler cannot pair them into v_pk_mul_f32)
+        f32x4 m0, m1;
+        DH_UNROLL for (int i = 0; i < 4; ++i) {
+            asm volatile("v_mul_f32 %0, %1, %2" : "=v"(m0[i]) : "v"(x0[i]), "v"(s));
+            asm volatile("v_mul_f32 %0, %1, %2" : "=v"(m1[i]) : "v"(x1[i]), "v"(s));
+        }
+        return split2(m0, m1);
+#elif defined(DW_AUX_V_PK_PLAIN)
+        // packed multiplies by a scale held in BOTH halves of an aligned pair: no op_sel
+        f32x2 ss; ss[0] = s; ss[1] = s;
+        asm volatile("" : "+v"(ss));
+        f32x4 m0, m1;
+        DH_UNROLL for (int i = 0; i < 2; ++i) {
+            f32x2 a, b, ra, rb;
+            a[0] = x0[2 * i]; a[1] = x0[2 * i + 1]; b[0] = x1[2 * i]; b[1] = x1[2 * i + 1];
+            asm volatile("v_pk_mul_f32 %0, %1, %2" : "=v"(ra) : "v"(a), "v"(ss));
+            asm volatile("v_pk_mul_f32 %0, %1, %2" : "=v"(rb) : "v"(b), "v"(ss));
+            m0[2 * i] = ra[0]; m0[2 * i + 1] = ra[1]; m1[2 * i] = rb[0]; m1[2 * i + 1] = rb[1];
+        }
+        return split2(m0, m1);
+#else
+        return split2(x0 * s, x1 * s);
+#endif
     };
     auto publish_a = [&](const Raw& r, int par) {
         char* base = lds + par * DWH_BUF + lane * 16;
-        const H2 pa = split2(r.a0 * r.sa, r.a1 * r.sa);
+        const H2 pa = scaled_split(r.a0, r.a1, r.sa);
         DH_UNROLL for (int p = 0; p < 2; ++p) *reinterpret_cast<u32x4*>(base + wave * DWH_TILE + p * 1024) = pa.p[p];
     };
-    H2 wrote;                                          // what this wave last published as its B tile
-    DH_UNROLL for (int p = 0; p < 2; ++p) DH_UNROLL for (int i = 0; i < 4; ++i) wrote.p[p][i] = 0u;
     auto publish_b = [&](const Raw& r, int par) {
         char* base = lds + par * DWH_BUF + lane * 16;
         if (has_b) {
-            const f32x4 rb0 = r.b0, rb1 = r.b1;
-#ifdef DW_AUX_PROBE_SCALAR_MUL
-            // the scale applied by eight single v_mul_f32 (inline asm: the compiler cannot pair them into v_pk_mul_f32)
-            f32x4 m0, m1;
-            DH_UNROLL for (int i = 0; i < 4; ++i) {
-                asm volatile("v_mul_f32 %0, %1, %2" : "=v"(m0[i]) : "v"(rb0[i]), "v"(r.sb));
-                asm volatile("v_mul_f32 %0, %1, %2" : "=v"(m1[i]) : "v"(rb1[i]), "v"(r.sb));
-            }
-            const H2 pb = split2(m0, m1);
-#else
-            const H2 pb = split2(rb0 * r.sb, rb1 * r.sb);
-#endif
+            const H2 pb = scaled_split(r.b0, r.b1, r.sb);
             DH_UNROLL for (int p = 0; p < 2; ++p) *reinterpret_cast<u32x4*>(base + (8 + (wave & 1)) * DWH_TILE + p * 1024) = pb.p[p];
-#ifndef DW_AUX_PROBE_NOCHECK
-            // [2]: the same split once more, kept apart from the first by an asm barrier the compiler cannot merge across
-            f32x4 c0 = rb0, c1 = rb1;
-            asm volatile("" : "+v"(c0), "+v"(c1));
-            const H2 pb2 = split2(c0 * r.sb, c1 * r.sb);
-            if (h2_differs(pb, pb2)) atomicAdd(&dw_probe_counters[2], 1u);
-            // [3]: the raw registers still hold what was split
-            f32x4 d0 = r.b0, d1 = r.b1;
-            asm volatile("" : "+v"(d0), "+v"(d1));
-            bool ch = false;
-            DH_UNROLL for (int i = 0; i < 4; ++i) ch |= (__builtin_bit_cast(unsigned, d0[i]) != __builtin_bit_cast(unsigned, rb0[i])) | (__builtin_bit_cast(unsigned, d1[i]) != __builtin_bit_cast(unsigned, rb1[i]));
-            if (ch) atomicAdd(&dw_probe_counters[3], 1u);
-            wrote = pb;
-#endif
         }
     };
     if (NP > 0) {
@@ -642,25 +633,20 @@ __device__ __forceinline__ void dw_body_aux_probe(const DwJob& J, const DwScales
         __syncthreads();
         auto step = [&](int par, Raw& nxt) {
             const H2 a = piece(par, wave), b0 = piece(par, 8), b1 = piece(par, 9);
-#ifndef DW_AUX_PROBE_NOCHECK
-            if (has_b) {                               // [0]: my own tile, as the readers see it now
-                const H2 mine = piece(par, 8 + (wave & 1));
-                if (h2_differs(mine, wrote)) atomicAdd(&dw_probe_counters[0], 1u);
-            }
-#endif
             __builtin_amdgcn_sched_barrier(0);
             publish_a(nxt, par ^ 1);
             acc[0] = mfma3(a, b0, acc[0]);
             __builtin_amdgcn_sched_barrier(0);
+#if defined(DW_AUX_V_LGKM_AFTER_A)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#elif defined(DW_AUX_V_NOP_AFTER_A)
+            asm volatile("s_nop 15\n s_nop 15" ::: "memory");
+#endif
             publish_b(nxt, par ^ 1);
             acc[1] = mfma3(a, b1, acc[1]);
             __builtin_amdgcn_sched_barrier(0);
-#ifndef DW_AUX_PROBE_NOCHECK
-            {                                          // [1]: tile 8 once more, late in the step
-                const H2 again = piece(par, 8);
-                if (h2_differs(again, b0)) atomicAdd(&dw_probe_counters[1], 1u);
-            }
-            if (wave == 0 && lane == 0) atomicAdd(&dw_probe_counters[4], 1u);
+#if defined(DW_AUX_V_LGKM_BEFORE_LOAD)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #endif
             load(nxt);
             __builtin_amdgcn_sched_barrier(0);
@@ -685,7 +671,6 @@ __device__ __forceinline__ void dw_body_aux_probe(const DwJob& J, const DwScales
         DH_UNROLL for (int r = 0; r < 16; ++r) o[r * 64] = acc[j][r] * inv;
     }
 }
-#endif
 
 __global__ __launch_bounds__(512, 1) void dw_f16x2_kernel(DwJobs jobs, DwGroups groups, int64_t ntiles, float* __restrict__ slabs,
                                                           int64_t gstride, const unsigned* __restrict__ absmax,
@@ -707,8 +692,8 @@ __global__ __launch_bounds__(512, 1) void dw_f16x2_kernel(DwJobs jobs, DwGroups 
         // -DDW_AUX_PROBE build above traced it to the packed-fp32 scale multiplies of the B-tile publish (in the shadow of the wave's
         // own dependent MFMAs).  The main jobs' two-piece body and this body are bitwise reproducible over 350,000 launches.
         if (J.nb == 8) dw_body_pieces_h<8>(J, sc, t0, t1, base + J.off, wave, lane, pieces);
-#ifdef DW_AUX_PROBE
-        else dw_body_aux_probe(J, sc, t0, t1, base + J.off, wave, lane, pieces);
+#ifdef DW_AUX_TWO_PIECE
+        else dw_body_aux_h(J, sc, t0, t1, base + J.off, wave, lane, pieces);
 #else
         else dw_body_pieces<2>(J, t0, t1, base + J.off, wave, lane, pieces);
 #endif
@@ -994,10 +979,3 @@ int launch_weight_grads_fold(const Workspace& w, float* slabs, float* tred, int 
 
 }  // namespace dh
 
-#ifdef DW_AUX_PROBE
-extern "C" int dh_dev_read_dw_probe(unsigned* out8, int reset) {
-    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(dh::dw_probe_counters), 8 * sizeof(unsigned)) != hipSuccess) return -3;
-    if (reset) { unsigned z[8] = {0, 0, 0, 0, 0, 0, 0, 0}; if (hipMemcpyToSymbol(HIP_SYMBOL(dh::dw_probe_counters), z, sizeof(z)) != hipSuccess) return -3; }
-    return 0;
-}
-#endif

@@ -87,11 +87,12 @@ class EventFileWriter:
 
 
 def make_writer(logdir: str):
-    """torch's SummaryWriter when the tensorboard package is importable, else the EventFileWriter above.  Only a MISSING package
-    selects the fallback: a bad logdir or a permission error surfaces from whichever writer is used."""
+    """torch's SummaryWriter when the tensorboard package is importable, else the EventFileWriter above.  Only a failing IMPORT
+    selects the fallback (a missing package, or a broken / incompatible tensorboard, protobuf or setuptools install -- those raise
+    AttributeError / TypeError rather than ImportError); a bad logdir or a permission error surfaces from whichever writer is used."""
     try:
         from torch.utils.tensorboard import SummaryWriter       # needs the tensorboard package
-    except (ImportError, ModuleNotFoundError):
+    except Exception:                                           # noqa: BLE001 -- the import statement only
         return EventFileWriter(logdir)
     return SummaryWriter(logdir)
 

@@ -45,7 +45,13 @@ const char* dh_strerror(int status);
  * tests/test_gpu_arithmetic_modes.py checks the other two against).  All three read and write the same buffers (packed
  * weights -- dh_pack_weights writes every layout --, workspace, outputs).  dh_set_arithmetic sets the DEFAULT used by the
  * entry points that take no arithmetic argument (for launches enqueued after the call); the `_ex` entry points below
- * ignore it. */
+ * ignore it.
+ * ONE ARITHMETIC PER STEP: every stage of one training step on one workspace, dh_sdf_forward through dh_weight_grads_gemm, must
+ * run in the SAME arithmetic.  The buffers are shared, but the workspace's scale tables (absmax / tmax, csrc/workspace.h) are
+ * cleared by the SPLIT_F16 sdf_forward and filled by the SPLIT_F16 stages only: a SPLIT_F16 dh_weight_grads_gemm behind a
+ * bf16 / fp32 backward (or behind a dh_set_arithmetic between the un-suffixed stage calls of one step) would read stale scale
+ * words.  The non-F16 training forwards therefore POISON the table (tag word, csrc/workspace.h ABSMAX_TAG) and the SPLIT_F16
+ * weight-gradient entry point returns DH_ERR_BAD_ARG... see dh_weight_grads_gemm. */
 typedef enum { DH_ARITH_SPLIT_BF16 = 0, DH_ARITH_FP32_MFMA = 1, DH_ARITH_SPLIT_F16 = 2 } dh_arithmetic;
 int dh_set_arithmetic(int mode);
 int dh_get_arithmetic(void);

@@ -73,3 +73,56 @@ def test_bench_rejects_mismatched_world_size():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True,
                        timeout=300, env=env)
     assert p.returncode == 2 and "WORLD_SIZE=4" in p.stderr
+
+
+TARGET8 = '''
+import json, os, sys
+sys.path.insert(0, %r)
+import torch, torch.distributed as dist
+from dynhor_amd.schedules import FramePermutation, frame_slot
+from dynhor_amd.dist import allreduce_sum_
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+if "--fail-rank" in sys.argv and rank == int(sys.argv[sys.argv.index("--fail-rank") + 1]):
+    sys.exit(9)                                  # before the first collective: the others are torn down by the launcher
+perm = FramePermutation(64, seed=777)            # every rank owns a copy of the same seeded permutation
+mine = [perm.frame(frame_slot(it, rank, world)) for it in range(20)]          # 20 iterations = 2.5 epochs at W = 8, F = 64
+every = [None] * world
+dist.all_gather_object(every, mine)
+bucket = torch.full((802491,), float(rank + 1))                                # the flat gradient bucket's size
+allreduce_sum_(bucket)
+if rank == 0:
+    disjoint = all(len({every[r][it] for r in range(world)}) == world for it in range(20))
+    epoch_cover = sorted(every[r][it] for it in range(8) for r in range(world)) == list(range(64))
+    print(json.dumps({"world": world, "disjoint_every_iteration": disjoint, "first_epoch_covers_all_frames": epoch_cover,
+                      "bucket_sum": bucket[0].item(), "bucket_uniform": bool((bucket == bucket[0]).all())}), flush=True)
+dist.destroy_process_group()
+'''
+
+
+def _spawn8(tmp_path, extra):
+    target = tmp_path / "target8.py"
+    target.write_text(TARGET8 % ROOT)
+    code = ("import sys; sys.path.insert(0, %r); from dynhor_amd import launch; "
+            "sys.exit(launch.spawn_ranks(%r, %r, 8, timeout=500))" % (ROOT, str(target), extra))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["OMP_NUM_THREADS"] = "1"
+    return subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
+
+
+def test_eight_ranks_rendezvous_draw_disjoint_frames_and_reduce_the_bucket(tmp_path):
+    """cfg3's process layout without GPUs (VERDICT r4 next #7): 8 self-launched gloo ranks; every iteration the ranks hold 8 distinct
+    frames of the shared permutation (F = 64: one epoch = 8 iterations covers every frame once), and the one collective of the
+    path -- the SUM all-reduce of the 802,491-float bucket -- gives every rank 1 + 2 + ... + 8."""
+    p = _spawn8(tmp_path, [])
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    out = json.loads(lines[0])
+    assert out == {"world": 8, "disjoint_every_iteration": True, "first_epoch_covers_all_frames": True, "bucket_sum": 36.0,
+                   "bucket_uniform": True}
+
+
+def test_eight_ranks_relay_the_exit_code_of_a_failing_rank(tmp_path):
+    p = _spawn8(tmp_path, ["--fail-rank", "5"])
+    assert p.returncode != 0 and not [l for l in p.stdout.splitlines() if l.startswith("{")]

@@ -64,7 +64,17 @@ for ar in (0, 1, 2):
 assert L.dh_sdf_nograd_ex(7, fake, fake, 5, fake, None) == -1 and L.dh_mlp_backward_ex(-1, *([fake] * 3), 100, *([fake] * 7)) == -1
 assert L.dh_upsample_step(null, null, null, null, 4, 200, 16, 64.0, null, null, null) == -2
 assert L.dh_set_arithmetic(9) == -1 and L.dh_hash_set_scatter_mode(5) == -1
-# host tables behind the launches: without a GPU every launch fails, after the job lists / partitions / descriptors were built
+# host tables behind the launches: without a GPU every launch fails, after the job lists / partitions / descriptors were built.
+# The launch-type calls below pass FAKE device pointers: they may only run when no device can execute them.  The parent hides
+# every device from this process (HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES = "") and skips this part where /dev/kfd exists; the
+# probe here is the last line of defence (hipGetDeviceCount through the runtime the library itself links).
+if not %(launch_part)d:
+    print("sanitized host paths ok (argument validation only: a GPU device node is present)")
+    raise SystemExit(0)
+hip = ctypes.CDLL("libamdhip64.so")
+cnt = ctypes.c_int(-1)
+rc = hip.hipGetDeviceCount(ctypes.byref(cnt))
+assert rc != 0 or cnt.value == 0, "a HIP device is visible (%%d): refusing to enqueue kernels on fake pointers" %% cnt.value
 no_gpu = L.dh_pack_weights(fake, fake, None)
 assert no_gpu in (-3, -2), no_gpu
 for ar in (0, 1, 2):
@@ -125,9 +135,13 @@ def test_host_side_of_the_library_is_clean_under_asan_and_ubsan(tmp_path):
         pytest.skip("no shared AddressSanitizer runtime in this toolchain")
     _build()
     script = tmp_path / "drive.py"
-    script.write_text(DRIVER % {"root": ROOT, "lib": LIB})
+    # CPU-only by construction: the launch-type part enqueues on fake device pointers, so it runs only where no GPU
+    # device node exists, and the child sees no device either way
+    launch_part = 0 if (os.path.exists("/dev/kfd") or glob.glob("/dev/dri/renderD*")) else 1
+    script.write_text(DRIVER % {"root": ROOT, "lib": LIB, "launch_part": launch_part})
     env = dict(os.environ, LD_PRELOAD=rt, ASAN_OPTIONS="detect_leaks=0:halt_on_error=1:abort_on_error=0",
-               UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1")
+               UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1", HIP_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="",
+               CUDA_VISIBLE_DEVICES="")
     p = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=900, env=env)
     assert p.returncode == 0 and "sanitized host paths ok" in p.stdout, (p.stdout[-1500:] + p.stderr[-4000:])
     assert "ERROR: AddressSanitizer" not in p.stderr and "runtime error:" not in p.stderr, p.stderr[-4000:]
