@@ -26,6 +26,7 @@ SIGNATURES = {
     "dh_pack_weights_ex": (_i32, [_i32, _vp, _vp, _vp]),
     "dh_sdf_nograd": (_i32, [_vp, _vp, _i64, _vp, _vp]),
     "dh_workspace_floats": (_i32, [_i64, ctypes.POINTER(_i64), ctypes.POINTER(_i64), ctypes.POINTER(_i64)]),
+    "dh_range_words": (_i32, [ctypes.POINTER(_i64), ctypes.POINTER(_i64), ctypes.POINTER(_f32)]),
     "dh_mlp_forward": (_i32, [_vp, _vp, _vp, _i32, _i64, _vp, _vp, _vp, _vp, _vp]),
     "dh_sdf_forward": (_i32, [_vp, _vp, _i64, _vp, _vp, _vp]),
     "dh_sdf_gradient": (_i32, [_vp, _vp, _i64, _vp, _vp, _i32, _vp]),
@@ -195,6 +196,13 @@ def packed_section(section: int):
     o, n = _i64(), _i64()
     check(lib().dh_packed_section(int(section), ctypes.byref(o), ctypes.byref(n)))
     return o.value, n.value
+
+
+def range_words():
+    """(float offset of the activation maximum, of the arithmetic tag, limit) in a workspace."""
+    a, t, lim = _i64(), _i64(), _f32()
+    check(lib().dh_range_words(ctypes.byref(a), ctypes.byref(t), ctypes.byref(lim)))
+    return a.value, t.value, lim.value
 
 
 def workspace_floats(npts: int):

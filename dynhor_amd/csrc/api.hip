@@ -107,6 +107,15 @@ int dh_workspace_floats(int64_t npts, int64_t* infer_floats, int64_t* fwd_floats
     return DH_OK;
 }
 
+int dh_range_words(int64_t* act_max_off, int64_t* tag_off, float* limit) {
+    if (!act_max_off || !tag_off || !limit) return DH_ERR_BAD_ARG;
+    // (absmax is the first block of the workspace: carve_workspace)
+    *act_max_off = (int64_t)ABSMAX_ACT * ABSMAX_STRIDE;
+    *tag_off = (int64_t)ABSMAX_TAG * ABSMAX_STRIDE;
+    *limit = 65504.f / H2_XS;
+    return DH_OK;
+}
+
 int dh_sdf_forward_ex(int arithmetic, const float* packed, const float* pts, int64_t npts, float* ws, float* sdf, void* stream) {
     if (bad_arith(arithmetic)) return DH_ERR_BAD_ARG;
     if (npts <= 0) return npts == 0 ? DH_OK : DH_ERR_BAD_ARG;

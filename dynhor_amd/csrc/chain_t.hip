@@ -27,6 +27,7 @@
 #include "mlp_common.h"
 #include "tile16h.h"
 #include "kernels.h"
+#include "workspace.h"
 
 namespace dh {
 
@@ -557,7 +558,7 @@ template <class C>
 __device__ __forceinline__ void sdf_chain_t_body(const void* __restrict__ stream, const float* __restrict__ bias10,
                                                  const float* __restrict__ b8_0, const float* __restrict__ pts, int64_t npts,
                                                  float* __restrict__ sdf_out, float* __restrict__ feat, float* __restrict__ act,
-                                                 float* __restrict__ eaux T_DBG_PARAMS) {
+                                                 float* __restrict__ eaux, unsigned* __restrict__ absmax T_DBG_PARAMS) {
     __shared__ __attribute__((aligned(16))) char lds[t_lds_bytes<C>()];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -675,6 +676,12 @@ __device__ __forceinline__ void sdf_chain_t_body(const void* __restrict__ stream
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the ring runs ahead of the last tile: let its DMAs land before the LDS goes away
+    if constexpr (AR::H && C::TRAIN) {
+        // the arithmetic tag of this step's scale tables (workspace.h ABSMAX_TAG).  (The RANGE WATCH of this chain's constant
+        // activation scale lives in sdf_grad_h_kernel, which reads every activation tile this kernel saves: this kernel has no vector
+        // register left for a running maximum -- one more live value and the compiler spills inside the tile loop.)
+        if (absmax && blockIdx.x == 0 && tid == 0) absmax[ABSMAX_TAG * ABSMAX_STRIDE] = ABSMAX_TAG_F16;
+    }
 }
 
 // (the weight stream is passed as const void*: a bf16 vector type in a kernel's signature leaves rocprofv3 unable to demangle its name)
@@ -686,25 +693,25 @@ __device__ __forceinline__ void sdf_chain_t_body(const void* __restrict__ stream
 __global__ __launch_bounds__(256, 1) void sdf_nograd_t_kernel(const void* __restrict__ stream, const float* __restrict__ bias10,
                                                               const float* __restrict__ b8_0, const float* __restrict__ pts, int64_t npts,
                                                               float* __restrict__ sdf_out T_DBG_PARAMS) {
-    sdf_chain_t_body<TCfgNoGrad<TArB3>>(stream, bias10, b8_0, pts, npts, sdf_out, nullptr, nullptr, nullptr T_DBG_FWD);
+    sdf_chain_t_body<TCfgNoGrad<TArB3>>(stream, bias10, b8_0, pts, npts, sdf_out, nullptr, nullptr, nullptr, nullptr T_DBG_FWD);
 }
 __global__ __launch_bounds__(256, 1) void sdf_fwd_train_t_kernel(const void* __restrict__ stream, const float* __restrict__ bias10,
                                                                  const float* __restrict__ b8_0, const float* __restrict__ pts, int64_t npts,
                                                                  float* __restrict__ sdf_out, float* __restrict__ feat, float* __restrict__ act,
                                                                  float* __restrict__ eaux T_DBG_PARAMS) {
-    sdf_chain_t_body<TCfgTrain<TArB3>>(stream, bias10, b8_0, pts, npts, sdf_out, feat, act, eaux T_DBG_FWD);
+    sdf_chain_t_body<TCfgTrain<TArB3>>(stream, bias10, b8_0, pts, npts, sdf_out, feat, act, eaux, nullptr T_DBG_FWD);
 }
 // the two-piece fp16 arithmetic (DH_ARITH_SPLIT_F16): bias11 = layout.h PACKH.bias11
 __global__ __launch_bounds__(256, 1) void sdf_nograd_h_kernel(const void* __restrict__ stream, const float* __restrict__ bias11,
                                                               const float* __restrict__ b8_0, const float* __restrict__ pts, int64_t npts,
                                                               float* __restrict__ sdf_out T_DBG_PARAMS) {
-    sdf_chain_t_body<TCfgNoGrad<TArH2>>(stream, bias11, b8_0, pts, npts, sdf_out, nullptr, nullptr, nullptr T_DBG_FWD);
+    sdf_chain_t_body<TCfgNoGrad<TArH2>>(stream, bias11, b8_0, pts, npts, sdf_out, nullptr, nullptr, nullptr, nullptr T_DBG_FWD);
 }
 __global__ __launch_bounds__(256, 1) void sdf_fwd_train_h_kernel(const void* __restrict__ stream, const float* __restrict__ bias11,
                                                                  const float* __restrict__ b8_0, const float* __restrict__ pts, int64_t npts,
                                                                  float* __restrict__ sdf_out, float* __restrict__ feat, float* __restrict__ act,
-                                                                 float* __restrict__ eaux T_DBG_PARAMS) {
-    sdf_chain_t_body<TCfgTrain<TArH2>>(stream, bias11, b8_0, pts, npts, sdf_out, feat, act, eaux T_DBG_FWD);
+                                                                 float* __restrict__ eaux, unsigned* __restrict__ absmax T_DBG_PARAMS) {
+    sdf_chain_t_body<TCfgTrain<TArH2>>(stream, bias11, b8_0, pts, npts, sdf_out, feat, act, eaux, absmax T_DBG_FWD);
 }
 
 #ifdef DH_T_DEBUG
@@ -750,12 +757,12 @@ int launch_sdf_nograd_t(const float* packed, const float* pts, int64_t npts, flo
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 int launch_sdf_fwd_train_t(const float* packed, const float* pts, int64_t npts, float* sdf, float* feat, float* act, float* eaux,
-                           bool h2, hipStream_t stream) {
+                           unsigned* absmax, bool h2, hipStream_t stream) {
     const int64_t ntiles = (npts + T_PTS - 1) / T_PTS;
     const int g = h2 ? t_grid<TCfgTrain<TArH2>>(ntiles) : t_grid<TCfgTrain<TArB3>>(ntiles);
     if (g <= 0) return -2;
     if (h2) hipLaunchKernelGGL(sdf_fwd_train_h_kernel, dim3(g), dim3(256), 0, stream, static_cast<const void*>(packed + PACKH.stream),
-                               packed + PACKH.bias11, packed + PACK.sdf_b8_0, pts, npts, sdf, feat, act, eaux T_DBG_ARGS);
+                               packed + PACKH.bias11, packed + PACK.sdf_b8_0, pts, npts, sdf, feat, act, eaux, absmax T_DBG_ARGS);
     else hipLaunchKernelGGL(sdf_fwd_train_t_kernel, dim3(g), dim3(256), 0, stream, static_cast<const void*>(packed + PACKT.stream),
                             packed + PACKT.bias10, packed + PACK.sdf_b8_0, pts, npts, sdf, feat, act, eaux T_DBG_ARGS);
     return hipGetLastError() == hipSuccess ? 0 : -3;

@@ -373,7 +373,8 @@ constexpr int DWH_BUF = 16 * DWH_TILE;
 // per pair (plain scalars, selected with ?: -- an array indexed by the run-time pair number goes to scratch and turns the tile
 // maximum's load into a flat load): prod = S_X(launch) S_Y, also the tame operand's scale before the per-tile division; xt = the
 // heavy operand's per-tile maxima; heavy_a: X is A
-struct DwScales { float prod0, prod1; const unsigned* xt0; const unsigned* xt1; bool heavy_a0, heavy_a1; };
+// poison: 1, or NaN when the workspace's scale tables were not written by this step's SPLIT_F16 stages (workspace.h ABSMAX_TAG)
+struct DwScales { float prod0, prod1; const unsigned* xt0; const unsigned* xt1; bool heavy_a0, heavy_a1; float poison; };
 __device__ __forceinline__ float dw_class_scale(const unsigned* __restrict__ absmax, int cls) {
     return cls < 0 ? H2_XS : __builtin_bit_cast(float, pow2_scale_bits(absmax[cls * ABSMAX_STRIDE], H2_AT));
 }
@@ -388,6 +389,7 @@ __device__ __forceinline__ DwScales dw_job_scales(const DwJob& J, const unsigned
     };
     one(0, s.prod0, s.xt0, s.heavy_a0);
     one(1, s.prod1, s.xt1, s.heavy_a1);
+    s.poison = absmax[ABSMAX_TAG * ABSMAX_STRIDE] == ABSMAX_TAG_F16 ? 1.f : __builtin_nanf("");
     return s;
 }
 template <int I, int JB>
@@ -526,7 +528,7 @@ __device__ __forceinline__ void dw_body_pieces_h(const DwJob& J, const DwScales&
         if (p < NP) { rescale(p); step(1, r1); ++p; }
         if (p < NP) { rescale(p); step(0, r2); ++p; }
     }
-    const float inv = 1.f / (npairs == 2 ? sc.prod1 : sc.prod0);
+    const float inv = sc.poison / (npairs == 2 ? sc.prod1 : sc.prod0);
     DH_UNROLL for (int i = 0; i < NA; ++i)
         DH_UNROLL for (int j = 0; j < NBW; ++j) {
             const int ot = (NB == 8) ? ((wave >> 1) * 2 + i) : wave;
@@ -593,6 +595,31 @@ __device__ __forceinline__ void dw_body_aux_h(const DwJob& J, const DwScales& sc
             asm volatile("v_mul_f32 %0, %1, %2" : "=v"(m1[i]) : "v"(x1[i]), "v"(s));
         }
         return split2(m0, m1);
+#elif defined(DW_AUX_V_PK_OPSEL_HI_DWORD) || defined(DW_AUX_V_PK_OPSEL_LO_DWORD)
+        // packed multiplies that broadcast the scale out of ONE dword of an aligned pair through op_sel, the other dword holding a
+        // constant: HI_DWORD = the form hipcc generates in the failing body (op_sel:[0,1]: both results read src1's high dword),
+        // LO_DWORD = its mirror (op_sel_hi:[1,0]: both results read src1's low dword)
+        f32x2 ss;
+#ifdef DW_AUX_V_PK_OPSEL_HI_DWORD
+        ss[0] = 0.f; ss[1] = s;
+#else
+        ss[0] = s; ss[1] = 0.f;
+#endif
+        asm volatile("" : "+v"(ss));
+        f32x4 m0, m1;
+        DH_UNROLL for (int i = 0; i < 2; ++i) {
+            f32x2 a, b, ra, rb;
+            a[0] = x0[2 * i]; a[1] = x0[2 * i + 1]; b[0] = x1[2 * i]; b[1] = x1[2 * i + 1];
+#ifdef DW_AUX_V_PK_OPSEL_HI_DWORD
+            asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1]" : "=v"(ra) : "v"(a), "v"(ss));
+            asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1]" : "=v"(rb) : "v"(b), "v"(ss));
+#else
+            asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(ra) : "v"(a), "v"(ss));
+            asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(rb) : "v"(b), "v"(ss));
+#endif
+            m0[2 * i] = ra[0]; m0[2 * i + 1] = ra[1]; m1[2 * i] = rb[0]; m1[2 * i + 1] = rb[1];
+        }
+        return split2(m0, m1);
 #elif defined(DW_AUX_V_PK_PLAIN)
         // packed multiplies by a scale held in BOTH halves of an aligned pair: no op_sel
         f32x2 ss; ss[0] = s; ss[1] = s;
@@ -635,7 +662,13 @@ __device__ __forceinline__ void dw_body_aux_h(const DwJob& J, const DwScales& sc
             const H2 a = piece(par, wave), b0 = piece(par, 8), b1 = piece(par, 9);
             __builtin_amdgcn_sched_barrier(0);
             publish_a(nxt, par ^ 1);
+#ifdef DW_AUX_V_NO_MFMA
+            // no matrix instruction in the step: the "accumulators" take a cheap function of the same pieces on the vector ALU
+            DH_UNROLL for (int r = 0; r < 16; ++r)
+                acc[0][r] += __builtin_bit_cast(float, ((a.p[r & 1][(r >> 1) & 3] ^ b0.p[(r >> 3) & 1][(r >> 1) & 3]) & 0x007fffffu) | 0x3f800000u);
+#else
             acc[0] = mfma3(a, b0, acc[0]);
+#endif
             __builtin_amdgcn_sched_barrier(0);
 #if defined(DW_AUX_V_LGKM_AFTER_A)
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -643,7 +676,12 @@ __device__ __forceinline__ void dw_body_aux_h(const DwJob& J, const DwScales& sc
             asm volatile("s_nop 15\n s_nop 15" ::: "memory");
 #endif
             publish_b(nxt, par ^ 1);
+#ifdef DW_AUX_V_NO_MFMA
+            DH_UNROLL for (int r = 0; r < 16; ++r)
+                acc[1][r] += __builtin_bit_cast(float, ((a.p[r & 1][(r >> 1) & 3] ^ b1.p[(r >> 3) & 1][(r >> 1) & 3]) & 0x007fffffu) | 0x3f800000u);
+#else
             acc[1] = mfma3(a, b1, acc[1]);
+#endif
             __builtin_amdgcn_sched_barrier(0);
 #if defined(DW_AUX_V_LGKM_BEFORE_LOAD)
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -665,7 +703,7 @@ __device__ __forceinline__ void dw_body_aux_h(const DwJob& J, const DwScales& sc
         }
         if (p < NP) { rescale(p); step(0, r1); }
     }
-    const float inv = 1.f / (npairs == 2 ? sc.prod1 : sc.prod0);
+    const float inv = sc.poison / (npairs == 2 ? sc.prod1 : sc.prod0);
     DH_UNROLL for (int j = 0; j < 2; ++j) {
         float* o = out + ((int64_t)wave * 2 + j) * 1024 + lane;
         DH_UNROLL for (int r = 0; r < 16; ++r) o[r * 64] = acc[j][r] * inv;
@@ -692,10 +730,10 @@ __global__ __launch_bounds__(512, 1) void dw_f16x2_kernel(DwJobs jobs, DwGroups 
         // -DDW_AUX_PROBE build above traced it to the packed-fp32 scale multiplies of the B-tile publish (in the shadow of the wave's
         // own dependent MFMAs).  The main jobs' two-piece body and this body are bitwise reproducible over 350,000 launches.
         if (J.nb == 8) dw_body_pieces_h<8>(J, sc, t0, t1, base + J.off, wave, lane, pieces);
-#ifdef DW_AUX_TWO_PIECE
-        else dw_body_aux_h(J, sc, t0, t1, base + J.off, wave, lane, pieces);
-#else
+#ifdef DW_AUX_THREE_PIECE          // (development: round 4's shipping form, the aux jobs on the three-piece bf16 body)
         else dw_body_pieces<2>(J, t0, t1, base + J.off, wave, lane, pieces);
+#else
+        else dw_body_aux_h(J, sc, t0, t1, base + J.off, wave, lane, pieces);
 #endif
     }
 }
@@ -897,16 +935,16 @@ static void build_dw_jobs(const Workspace& w, float* red, DwJobs& J, SlabPtrs& S
     for (int l = 1; l <= 7; ++l) {
         J.j[l].A1 = T_(w.zbar, l); J.j[l].B1 = T_(w.act, l - 1);
         J.j[l].A2 = T_(w.asave, l); J.j[l].B2 = T_(w.tsave, l - 1);
-        C_(l, 0, ABSMAX_ZBAR + l, TMAX_ZBAR + l, -1, -1); C_(l, 1, ABSMAX_ASAVE + l, -1, ABSMAX_TSAVE + l - 1, TMAX_TSAVE + l - 1);
+        C_(l, 0, ABSMAX_ZBAR + l, TMAX_ZBAR + l, ABSMAX_ACT, -1); C_(l, 1, ABSMAX_ASAVE + l, -1, ABSMAX_TSAVE + l - 1, TMAX_TSAVE + l - 1);
     }
     J.j[8].A1 = T_(w.zbar, 4); J.j[8].B1 = w.eaux; J.j[8].A2 = T_(w.asave, 4); J.j[8].B2 = w.t0aux;
     C_(8, 0, ABSMAX_ZBAR + 4, TMAX_ZBAR + 4, -1, -1); C_(8, 1, ABSMAX_ASAVE + 4, -1, ABSMAX_T0AUX, TMAX_T0AUX);
     J.j[9].A1 = w.featbar; J.j[9].B1 = T_(w.act, 7); J.j[9].A2 = nullptr; J.j[9].B2 = nullptr;
-    C_(9, 0, ABSMAX_FEATBAR, TMAX_FEATBAR, -1, -1);
+    C_(9, 0, ABSMAX_FEATBAR, TMAX_FEATBAR, ABSMAX_ACT, -1);
     J.j[10].A1 = T_(w.czbar, 0); J.j[10].B1 = w.feat; J.j[10].A2 = nullptr; J.j[10].B2 = nullptr;
     C_(10, 0, ABSMAX_CZBAR + 0, TMAX_CZBAR + 0, ABSMAX_FEAT, -1);
     J.j[11].A1 = T_(w.czbar, 0); J.j[11].B1 = w.caux; J.j[11].A2 = nullptr; J.j[11].B2 = nullptr;
-    C_(11, 0, ABSMAX_CZBAR + 0, TMAX_CZBAR + 0, -1, -1);
+    C_(11, 0, ABSMAX_CZBAR + 0, TMAX_CZBAR + 0, ABSMAX_CAUX, -1);
     for (int l = 1; l <= 3; ++l) {
         J.j[11 + l].A1 = T_(w.czbar, l); J.j[11 + l].B1 = T_(w.cact, l - 1); J.j[11 + l].A2 = nullptr; J.j[11 + l].B2 = nullptr;
         C_(11 + l, 0, ABSMAX_CZBAR + l, TMAX_CZBAR + l, ABSMAX_CACT + l - 1, -1);

@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "layout.h"
 
 namespace dh {
 
@@ -17,7 +18,7 @@ int launch_pack_weights(const float* params, float* packed, int arith_mask, hipS
 int launch_sdf_nograd(const float* packed, const float* pts, int64_t npts, float* sdf, int grid, int arith, hipStream_t stream);
 int launch_sdf_nograd_t(const float* packed, const float* pts, int64_t npts, float* sdf, bool h2, hipStream_t stream);   // chain_t.hip
 int launch_sdf_fwd_train_t(const float* packed, const float* pts, int64_t npts, float* sdf, float* feat, float* act, float* eaux,
-                           bool h2, hipStream_t stream);
+                           unsigned* absmax, bool h2, hipStream_t stream);
 
 // (absmax: workspace.h -- the two-piece fp16 kernels post the per-launch maxima of their saved-tile classes there)
 int launch_sdf_fwd_train(const float* packed, const float* pts, int64_t npts, float* sdf, float* feat, float* act,

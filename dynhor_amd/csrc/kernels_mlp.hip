@@ -379,8 +379,11 @@ static inline int grid_for(int64_t npts, int grid) {
 
 int launch_sdf_fwd_train(const float* packed, const float* pts, int64_t npts, float* sdf, float* feat, float* act,
                          float* eaux, float* absmax, int grid, int arith, hipStream_t stream) {
-    if (arith == ARITH_F16 && absmax) (void)hipMemsetAsync(absmax, 0, ABSMAX_FLOATS * sizeof(float), stream);    // workspace.h: the step's class maxima
-    if (arith != ARITH_FP32) return launch_sdf_fwd_train_t(packed, pts, npts, sdf, feat, act, eaux, arith == ARITH_F16, stream);
+    // workspace.h: the step's class maxima and the arithmetic tag -- cleared by EVERY arithmetic's training forward, so that a SPLIT_F16
+    // weight-gradient launch behind another arithmetic's forward finds no tag (and poisons its result) instead of stale scales
+    if (absmax) (void)hipMemsetAsync(absmax, 0, ABSMAX_FLOATS * sizeof(float), stream);
+    if (arith != ARITH_FP32) return launch_sdf_fwd_train_t(packed, pts, npts, sdf, feat, act, eaux, reinterpret_cast<unsigned*>(absmax),
+                                                           arith == ARITH_F16, stream);
     hipLaunchKernelGGL(sdf_fwd_train_kernel, dim3(grid_for(npts, grid)), dim3(256), 0, stream, make_sdf_ptrs(packed), pts, npts, sdf, feat, act, eaux);
     return ok();
 }

@@ -149,6 +149,7 @@ __global__ __launch_bounds__(256, 2) void color_fwd_h_kernel(ColHPtrs C, const f
         // (the barrier inside also publishes saux; the previous tile ended with one, so the images are free).  The extras [p,
         // embed(view), n] share layer 0's accumulator with feat: one scale for both, from the larger of the two maxima
         TileScale ts = lds_handoff(acc, smain, hs, save ? &hs.lmax[4] : nullptr, tid, wave, lane, 0.f, &hs.sred2[0]);
+        if (save && tid == 0) hs.lmax[5] = fmaxf(hs.lmax[5], hs.sred2[0]);      // the extras' class maximum (sred2[0]: rewritten a tile away)
         if (save) aux_lds_to_native(saux, caux + tile * AUXT_F, wave, lane);
         for (int l = 0; l < 4; ++l) {
             acc_zero(acc);
@@ -170,6 +171,7 @@ __global__ __launch_bounds__(256, 2) void color_fwd_h_kernel(ColHPtrs C, const f
     if (save && absmax) {
         if (tid < 4) post_class_max(absmax, ABSMAX_CACT + tid, hs.lmax[tid]);
         if (tid == 4) post_class_max(absmax, ABSMAX_FEAT, hs.lmax[4]);
+        if (tid == 5) post_class_max(absmax, ABSMAX_CAUX, hs.lmax[5]);
     }
 }
 
@@ -185,6 +187,11 @@ __global__ __launch_bounds__(256, 2) void sdf_grad_h_kernel(SdfHPtrs P, const fl
     const int loff = tile_loff(wave, lane);
     const int64_t ntiles = (npts + TM - 1) / TM;
     hs_init(hs, tid);
+    // RANGE WATCH of the forward chain (chain_t.hip carries its softplus activations at the constant scale H2_XS in fp16; it has no
+    // register left to watch them itself): this kernel reads every activation tile the forward saved -- as fp32, valid even where a
+    // piece overflowed -- and keeps their maximum: the class maximum of `act` for the weight-gradient kernel (workspace.h ABSMAX_ACT)
+    // and what dh_range_words exposes.  One v_max3_f32 per two values.
+    float hmax = 0.f;
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         f32x16 acc[MT][2];
         f32x16 ge[AUX_NTW];
@@ -194,6 +201,8 @@ __global__ __launch_bounds__(256, 2) void sdf_grad_h_kernel(SdfHPtrs P, const fl
         {
             const float w0 = P.w8row0[acc_col(wave, 0, lane)], w1 = P.w8row0[acc_col(wave, 1, lane)];
             acc_load_native_b(acc, tile_rsrc(act + ((int64_t)7 * ntiles + tile) * TILE_F), loff);
+            DH_UNROLL for (int m = 0; m < MT; ++m) DH_UNROLL for (int t = 0; t < 2; ++t)
+                DH_UNROLL for (int r = 0; r < 16; r += 2) hmax = fmaxf(hmax, fmaxf(acc[m][t][r], acc[m][t][r + 1]));
             acc_map(acc, [&](int, int t, int, float h) { float s, em; softplus_deriv_from_h(h, s, em); return (t ? w1 : w0) * s; });
             if (save) acc_store_native_b(acc, tile_rsrc(asave + ((int64_t)7 * ntiles + tile) * TILE_F), loff);
             ts = lds_handoff(acc, smain, hs, &hs.lmax[7], tid, wave, lane);
@@ -216,6 +225,8 @@ __global__ __launch_bounds__(256, 2) void sdf_grad_h_kernel(SdfHPtrs P, const fl
                 DH_UNROLL for (int t = 0; t < 2; ++t)
                     DH_UNROLL for (int r4 = 0; r4 < 4; ++r4) {
                         const f32x4 h = hs_.v[t * 4 + r4];
+                        hmax = fmaxf(hmax, fmaxf(h[0], h[1]));
+                        hmax = fmaxf(hmax, fmaxf(h[2], h[3]));
                         DH_UNROLL for (int rr = 0; rr < 4; ++rr) {
                             float s, em; softplus_deriv_from_h(h[rr], s, em);
                             acc[m][t][4 * r4 + rr] *= s * inv;
@@ -263,6 +274,10 @@ __global__ __launch_bounds__(256, 2) void sdf_grad_h_kernel(SdfHPtrs P, const fl
         __syncthreads();
     }
     if (save && absmax && tid < 8) post_class_max(absmax, ABSMAX_ASAVE + tid, hs.lmax[tid]);
+    if (absmax) {                                      // (also forward-only renders: save == 0)
+        hmax = wave_max(hmax);
+        if (lane == 0) post_class_max(absmax, ABSMAX_ACT, hmax);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ colour backward

@@ -7,6 +7,19 @@
 #pragma once
 #include <stdint.h>
 
+// This library is compiled WITHOUT packed-fp32 VALU instructions (v_pk_mul / v_pk_add / v_pk_fma_f32, v_pk_mov_b32): hipcc flags
+// `-Xclang -target-feature -Xclang -packed-fp32-ops` (__graft_entry__.HIPCC_FLAGS; scripts/build_variant.sh and the micro Makefile
+// carry them too).  Round 5 root cause of the weight-gradient kernel's irreproducible aux body (DESIGN.md section 4 "Reproducibility",
+// profiles/r05_dw_aux_hazard_table.json, scripts/micro/dw_aux_hazard_micro.hip): hipcc turns `vector * scalar` into v_pk_mul_f32 /
+// v_pk_fma_f32 that BROADCAST the scalar out of one dword of an aligned register pair through op_sel (op_sel:[0,1]: both results
+// read src1's HIGH dword), and on gfx950 that form occasionally delivers wrong values in lanes 16-31 / 48-63 -- 1 % of the launches
+// of the product's own kernel on synthetic operands; every launch once the compiler also forms v_pk_fma_f32 ... op_sel:[0,1,0];
+// never with single v_mul_f32, with a packed multiply whose pair holds the scalar in BOTH dwords (no op_sel), or with the target
+// feature off.  The whole step costs the same without it (same-box A/B: 8.09 against 8.12 ms of MLP stages).  A per-kernel
+// __attribute__((target("no-packed-fp32-ops"))) was tried first and rejected: it stops the inliner at every callee that is not
+// always_inline (the HIP headers' __shfl_*, lambdas: 456 real calls in the library).  tests/test_cpu_isa_inflight.py disassembles the
+// built library and fails on any v_pk_*_f32 / v_pk_mov_b32 in it, so a build without the flags cannot ship unnoticed.
+
 namespace dh {
 
 constexpr int TM = 64;         // points per tile (= rows of every tile GEMM).  Fixed: the split-bf16 kernels are written for
@@ -211,6 +224,7 @@ constexpr PackHOff make_packh_off() {
     return p;
 }
 constexpr PackHOff PACKH = make_packh_off();
+constexpr float H2_RANGE = 65504.f;  // the largest SCALED magnitude whose hi piece is finite (fp16 max; the convert rounds to nearest)
 constexpr float H2_XS = 16.f;      // static power-of-two scale of O(1) operands (softplus / ReLU activations, embeddings, features)
 
 }  // namespace dh

@@ -26,6 +26,7 @@
 //   S_w M[k = 16 kc + 8 (lane>>5) + s][n = 32 nt + (lane&31)], s = 0..7  (piece 0 = hi, 1 = lo).
 #pragma once
 #include "tile16.h"
+#include "workspace.h"
 
 namespace dh {
 
@@ -117,8 +118,7 @@ __device__ __forceinline__ TileScale tile_scale(const float* sred, float* lmax, 
     if (lmax && tid == 0) *lmax = fmaxf(*lmax, m);
     return scale_for_max(m);
 }
-// workspace.h: class slot c lives 64 words (256 B) from the next
-constexpr int ABSMAX_STRIDE = 64;
+// (workspace.h ABSMAX_STRIDE: class slot c lives 64 words = 256 B from the next)
 __device__ __forceinline__ void post_class_max(unsigned* absmax, int cls, float m) {
     atomicMax(absmax + cls * ABSMAX_STRIDE, __builtin_bit_cast(unsigned, m));
 }

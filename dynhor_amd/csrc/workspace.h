@@ -11,12 +11,21 @@ constexpr int DW_NS = 64;         // split factor of the tile-partial reduction
 int64_t dw_slab_floats(int G);   // per-tile partial-sum slots of 256 floats (bias grads, lin8 row 0, colour lin4)
 
 // absmax: per-launch maxima of the saved-tile classes whose scale the two-piece fp16 weight-gradient kernel needs (tile16h.h):
-// one u32 (the fp32 bits of the maximum |value|) per class, classes 64 words apart; zeroed by the training forward
-// (launch_sdf_fwd_train, DH_ARITH_SPLIT_F16), raised with atomicMax by the kernels that write the tiles.  Classes without a slot
-// (act, eaux, caux: softplus outputs / embeddings) are scaled by the constant H2_XS.
+// one u32 (the fp32 bits of the maximum |value|) per class, classes ABSMAX_STRIDE words apart; zeroed by every training forward
+// (launch_sdf_fwd_train), raised with atomicMax by the SPLIT_F16 kernels that write (or, for act, first read) the tiles.
+// Round 5: the softplus activations act[0..7] share ABSMAX_ACT (posted by sdf_grad_h_kernel, which reads them all), the colour extras
+// [p, embed(view), n] have ABSMAX_CAUX (the normal is unbounded) -- only the embedding tile eaux is still carried at the constant
+// H2_XS = 16 by the weight-gradient kernel (sin / cos and a point inside the unit sphere: bounded by construction).  The
+// register-resident forward chain carries its activations at the constant H2_XS = 16 too (fp16 overflow beyond |act| = 4094):
+// ABSMAX_ACT is what tells (dh_range_words; the Runner raises at its report iterations).
+// ABSMAX_TAG: ABSMAX_TAG_F16 once the SPLIT_F16 training forward of this step has run (every training forward clears the table
+// first): a SPLIT_F16 weight-gradient launch behind a forward of another arithmetic finds no tag and poisons its slabs with NaN
+// instead of scaling by stale words (include/dynhor_hip.h "ONE ARITHMETIC PER STEP").
 enum : int { ABSMAX_ASAVE = 0, ABSMAX_ZBAR = 8, ABSMAX_TSAVE = 16, ABSMAX_T0AUX = 23, ABSMAX_FEATBAR = 24, ABSMAX_CZBAR = 25,
-             ABSMAX_CACT = 29, ABSMAX_FEAT = 33, ABSMAX_N = 34 };
-constexpr int ABSMAX_FLOATS = 64 * 64;
+             ABSMAX_CACT = 29, ABSMAX_FEAT = 33, ABSMAX_ACT = 34, ABSMAX_CAUX = 35, ABSMAX_TAG = 36, ABSMAX_N = 37 };
+constexpr unsigned ABSMAX_TAG_F16 = 0x00F16F16u;
+constexpr int ABSMAX_STRIDE = 64;         // class slot c lives 64 words (256 B) from the next
+constexpr int ABSMAX_FLOATS = 64 * ABSMAX_STRIDE;
 // tmax: PER-TILE maxima of the heavy-tailed classes (adjoints and tangents: a few sample points near the surface carry almost
 // everything): [TMAX_N][ntiles] u32.  The two-piece fp16 weight-gradient kernel scales such an operand tile by tile (a launch-wide
 // scale set by one outlier would push the typical tile into fp16's subnormals: measured 1.7e-4 on the gradient) and divides the

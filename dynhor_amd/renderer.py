@@ -186,6 +186,23 @@ class NeuSRenderer:
         T("weight_grads_gemm", L.dh_weight_grads_gemm_ex, ar, P, _p(s.ws), _lib.stream())
         T("weight_grads_fold", L.dh_weight_grads_fold, _p(st.packed), _p(st.flat), P, _p(s.ws), _p(grad), _lib.stream())
 
+    # ------------------------------------------------------------------ range watch of the two-piece fp16 arithmetic
+    def check_range(self, state=None):
+        """The SPLIT_F16 forward chain carries its softplus activations at a constant fp16 scale (overflow beyond 4094:
+        include/dynhor_hip.h dh_range_words); the input-gradient stage posts the largest activation of the step into the workspace.
+        ONE device read: call at report iterations, not per step.  Returns (max activation, limit) of the last forward, raises
+        DynhorHipError beyond the limit (the step's results are NaN there): switch to arithmetic 'split_bf16', which has no limit."""
+        s = state if state is not None else getattr(self, "last_state", None)
+        if s is None or getattr(s, "arith", None) != _lib.ARITH_SPLIT_F16:
+            return None
+        a, _, lim = _lib.range_words()
+        m = float(s.ws[a])
+        if not m < lim:                                    # (NaN compares false)
+            raise _lib.DynhorHipError(
+                f"split_f16 range exceeded: max softplus activation of the SDF network = {m:.4g}, limit {lim:.0f} (fp16 overflow at the "
+                "forward chain's constant scale 16): this step's results are not valid; use model.arithmetic = 'split_bf16'")
+        return m, lim
+
     # ------------------------------------------------------------------ no-grad SDF queries
     def sdf(self, pts: torch.Tensor) -> torch.Tensor:
         """sdf_network.sdf(pts) under no_grad: [N,3] -> [N,1]."""
@@ -214,6 +231,10 @@ class NeuSRenderer:
                     gx, gy, gz = torch.meshgrid(ax[0][xi:xi + step], ax[1][yi:yi + step], ax[2][zi:zi + step], indexing="ij")
                     pts = torch.stack([gx, gy, gz], dim=-1).reshape(-1, 3).contiguous()
                     u[xi:xi + step, yi:yi + step, zi:zi + step] = -self.sdf(pts).reshape(gx.shape)
+        if not bool(torch.isfinite(u).all()):
+            # (the no-grad chain has no workspace to post a range status into: beyond the split_f16 range its outputs are NaN)
+            raise _lib.DynhorHipError("extract_geometry: non-finite SDF values on the grid (split_f16 range exceeded, or the network "
+                                      "has diverged); use arithmetic 'split_bf16' for queries this far out")
         return marching_tetrahedra(u, threshold, bound_min, bound_max)
 
     # ------------------------------------------------------------------ hierarchical sampling (App. A.5/A.6)

@@ -9,6 +9,7 @@ iteration, then every rank applies the same fused Adam step.
 from __future__ import annotations
 
 import json
+import math
 import os
 import shutil
 
@@ -224,6 +225,13 @@ class Runner:
 
     def report(self, stats):
         v = dh_dist.mean_stats(stats).tolist()
+        # loud, never silent: the two-piece fp16 arithmetic's range watch (one device read, report iterations
+        # only) and a finite-loss check
+        if hasattr(self.renderer, "check_range"):
+            self.renderer.check_range()
+        if not math.isfinite(v[0]):
+            from ._lib import DynhorHipError
+            raise DynhorHipError(f"non-finite loss at iteration {self.iter_step}: {v[0]}")
         rec = {"iter": self.iter_step, "Loss/loss": v[0], "Loss/color_loss": v[1], "Loss/eikonal_loss": v[2],
                "Loss/mask_loss": v[3], "Loss/normal_loss": v[4], "Statistics/psnr": v[5],
                **({"Loss/corr_loss": float(self.renderer.last_corr_stats[0]), "Statistics/corr_residual_px": float(self.renderer.last_corr_stats[2])}

@@ -48,10 +48,11 @@ const char* dh_strerror(int status);
  * ignore it.
  * ONE ARITHMETIC PER STEP: every stage of one training step on one workspace, dh_sdf_forward through dh_weight_grads_gemm, must
  * run in the SAME arithmetic.  The buffers are shared, but the workspace's scale tables (absmax / tmax, csrc/workspace.h) are
- * cleared by the SPLIT_F16 sdf_forward and filled by the SPLIT_F16 stages only: a SPLIT_F16 dh_weight_grads_gemm behind a
+ * cleared by dh_sdf_forward and filled by the SPLIT_F16 stages only: a SPLIT_F16 dh_weight_grads_gemm behind a
  * bf16 / fp32 backward (or behind a dh_set_arithmetic between the un-suffixed stage calls of one step) would read stale scale
- * words.  The non-F16 training forwards therefore POISON the table (tag word, csrc/workspace.h ABSMAX_TAG) and the SPLIT_F16
- * weight-gradient entry point returns DH_ERR_BAD_ARG... see dh_weight_grads_gemm. */
+ * words.  Guard: every training forward clears the table and only the SPLIT_F16 one then writes a tag word into it
+ * (csrc/workspace.h ABSMAX_TAG); a SPLIT_F16 dh_weight_grads_gemm that finds no tag writes NaN gradients (loud) instead of
+ * gradients scaled by stale words (silently wrong). */
 typedef enum { DH_ARITH_SPLIT_BF16 = 0, DH_ARITH_FP32_MFMA = 1, DH_ARITH_SPLIT_F16 = 2 } dh_arithmetic;
 int dh_set_arithmetic(int mode);
 int dh_get_arithmetic(void);
@@ -82,6 +83,17 @@ int dh_sdf_nograd(const float* packed, const float* pts, int64_t npts, float* sd
  * render (save = 0 below), fwd_floats is what a training forward writes (saved activations), total_floats additionally
  * covers the backward pass. */
 int dh_workspace_floats(int64_t npts, int64_t* infer_floats, int64_t* fwd_floats, int64_t* total_floats);
+
+/* Range watch of the DH_ARITH_SPLIT_F16 arithmetic.  Its register-resident SDF forward chain carries the softplus activations at
+ * the CONSTANT scale 16 in fp16 (csrc/chain_t.hip): an activation beyond *limit = 65504 / 16 = 4094 overflows the hi piece and the
+ * results downstream of it are NaN (every other operand class of the MLPs is scaled dynamically, per tile or per launch, and has no
+ * such limit; the embedding input shares the constant scale but is a point of the unit sphere).  dh_sdf_gradient(_ex) -- which reads
+ * every activation tile the forward saved -- therefore posts the largest activation of the launch into the workspace: one fp32 word
+ * at float offset *act_max_off of ws, valid once dh_sdf_gradient of the step has run.  A caller that can afford a device read (the
+ * Runner: at report iterations) compares it with *limit and switches to DH_ARITH_SPLIT_BF16 / raises.  *tag_off: the word that holds
+ * 0x00F16F16 after a SPLIT_F16 forward (see "ONE ARITHMETIC PER STEP" above).  The no-grad chain has no workspace: beyond the limit
+ * its outputs are NaN (never finite garbage). */
+int dh_range_words(int64_t* act_max_off, int64_t* tag_off, float* limit);
 
 /* The MLP part of upstream NeuSRenderer.render_core (App. A.7) on npts points (point i belongs to ray
  * i / n_per_ray): sdf_network(pts) -> sdf [npts], feature (kept in ws); sdf_network.gradient(pts) -> normals

@@ -64,6 +64,7 @@ int main(int argc, char** argv) {
         const float one = 1.f;
         unsigned ob; memcpy(&ob, &one, 4);
         for (int c = 0; c < 4; ++c) h[c * ABSMAX_STRIDE] = ob;       // every class has its tile 0 at maximum 1.0
+        h[ABSMAX_TAG * ABSMAX_STRIDE] = ABSMAX_TAG_F16;
         CK(hipMemcpy(absmax, h.data(), ABSMAX_FLOATS * 4, hipMemcpyHostToDevice));
     }
     // jobs: naux aux jobs (two operand pairs, as jobs 0 / 8 of the product), then main jobs (two pairs, as jobs 1..7)

@@ -1,8 +1,10 @@
 """Bitwise reproducibility of the training step (no float atomics on the NeuS path, fixed-order reductions).
-Round 4 found the two-piece fp16 weight-gradient kernel's aux jobs differing in about one launch out of 5,000
-(profiles/r04_dw_aux_reproducibility.json); they run the three-piece body since.  A rate that low cannot be excluded by a short
-test -- scripts/det_dw.py (100,000 launches) and scripts/det_soak.py (3,000 training iterations twice) are the tools for that --
-but a gross regression (the timing variants tried on the way failed in 0.2 ... 30 % of the launches) is caught here."""
+Round 4 found the two-piece fp16 weight-gradient kernel's aux jobs differing in about one launch out of 5,000; round 5 traced it to
+packed-fp32 instructions that broadcast a scalar through op_sel (csrc/layout.h, profiles/r05_dw_aux_hazard_table.json) and builds the
+whole library without packed fp32.  A rate that low cannot be excluded by a short test -- scripts/det_dw.py, scripts/det_chain.py
+(>= 1e5 launches per kernel: profiles/r05_det_*.json) and scripts/det_soak.py are the tools for that -- but a gross regression (the
+variants tried on the way failed in 0.2 ... 100 % of the launches) is caught here; tests/test_cpu_isa_inflight.py keeps the
+instruction class out of the built library."""
 import pytest
 import torch
 
@@ -38,6 +40,21 @@ def test_weight_gradient_gemm_relaunched_on_one_workspace_gives_identical_slabs(
             ref = cur.clone()
         else:
             assert torch.equal(cur, ref), f"launch {rep} differs from launch 0"
+
+
+def test_every_chain_stage_relaunched_on_one_workspace_writes_identical_tiles():
+    """VERDICT r4 next #1d: the six tile-writing chain stages and the no-grad chain of the shipping arithmetic, each re-launched 300
+    times on the bench's own workspace (2048 rays x 128 points), every region the stage writes compared through a 64-bit checksum
+    (scripts/det_chain.py; the >= 1e5-launch soaks are recorded under profiles/r05_det_chain_soak.json)."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "scripts", "det_chain.py"), "300"], capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    res = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert set(res["stages"]) == {"sdf_forward", "sdf_gradient", "color_forward", "color_backward", "sdf_tangent", "sdf_backward", "sdf_nograd"}
+    for name, st in res["stages"].items():
+        assert st["differing"] == 0, (name, st)
+        assert st["bytes_compared_per_launch"] > 0
 
 
 @pytest.mark.parametrize("arithmetic", [None, "split_bf16"])
