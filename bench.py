@@ -336,7 +336,11 @@ def main():
                     "bucket_bytes": g.numel() * 4, "bucket_persistent": runner.store.grad_flat.data_ptr() == g.data_ptr(),
                     "allreduce_only_ms": round(float(t.item()), 4),
                     "allreduce_frac_of_step": round(float(t.item()) / (dt / args.steps * 1e3), 4),
-                    "collectives_per_step": 1}
+                    "collectives_per_step": 2 if getattr(runner, "overlap_table_reduce", False) else 1}
+            if getattr(runner, "overlap_table_reduce", False):
+                tf = runner.store.table_floats
+                comm["collective_bytes"] = {"table_gradient (side stream, overlapped with the small weight-gradient GEMMs)": tf * 4,
+                                            "mlp_gradients": (g.numel() - tf) * 4}
         if saved_stdout is not None:
             torch.cuda.synchronize()
             sys.stdout.flush()

@@ -70,6 +70,7 @@ SIGNATURES = {
     "dh_hash_color_backward": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i64, _vp, _vp, _vp, _vp, _vp]),
     "dh_hash_geo_backward": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _f32, _f32, _vp, _vp, _vp]),
     "dh_hash_weight_grads": (_i32, [_vp, _vp, _i64, _vp, _vp, _vp, _vp]),
+    "dh_hash_weight_grads_parts": (_i32, [_vp, _vp, _i64, _vp, _vp, _vp, _i32, _vp]),
     "dh_gen_rays": (_i32, [_vp] * 6 + [_i32, _i32, _i32, _i32, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),
     "dh_coarse_samples": (_i32, [_vp] * 5 + [_i64, _i32, _vp, _vp, _vp]),
     "dh_upsample_step": (_i32, [_vp] * 4 + [_i64, _i32, _i32, _f32, _vp, _vp, _vp]),

@@ -818,30 +818,37 @@ int launch_hash_geo_bwd(const float* params, const float* hp, const float* pts, 
     return ok();
 }
 
-// all parameter gradients of the hash family from the rows the two kernels above left in ws: grad [hash_num_params]
+// all parameter gradients of the hash family from the rows the two kernels above left in ws: grad [hash_num_params].
+// parts: 1 = the table gradient (the first 12,196,240 x 2 floats of grad), 2 = the five small linears, 3 = both -- table FIRST, so that
+// a data-parallel caller can start the 49 MB table all-reduce on a side stream while the small weight-gradient GEMMs still run
+// (dynhor_amd/hash_fields.py).
 int launch_hash_weight_grads(const float* params, const float* hp, int64_t n, float* ws, float* grad, const int64_t* n_act,
-                             hipStream_t st) {
+                             int parts, hipStream_t st) {
     const HashWs O = make_hash_ws(n);
     const HashParamOff P = hash_param_off();
     const int64_t en = (int64_t)HW_E * n;
-    SmallDwJobs J;
-    J.j[0] = {O.da, O.gin, 64, 36, en, O.lde, n};         // geometry lin0 (ones column -> bias)
-    J.j[1] = {O.dout, O.hh, HM_GOUT, 64, en, O.lde, n};   // geometry lin1
-    J.j[2] = {O.dz1, O.cin, 64, 32, n, O.ldn, n};         // colour lin0
-    J.j[3] = {O.dz2, O.h1, 64, 64, n, O.ldn, n};          // colour lin1
-    J.j[4] = {O.d_o, O.h2, 3, 64, n, O.ldn, n};           // colour lin2
-    float* slabs = ws + O.slabs;
-    float* dwsum = ws + O.total;
-    hipLaunchKernelGGL(small_dw_kernel, dim3(HW_SLABS, HW_JOBS), dim3(256), 0, st, ws, J, slabs, n_act);
-    hipLaunchKernelGGL(small_dw_reduce_kernel, dim3((HW_DW_FLOATS + 255) / 256, HW_JOBS), dim3(256), 0, st, slabs, dwsum);
-    hipLaunchKernelGGL(hash_fold_kernel, dim3(64, HW_JOBS), dim3(64), 0, st, params, hp, dwsum, P, grad);
-    // table: scatter the encoding adjoint of all E n evaluations
-    if (hipMemsetAsync(grad + P.table, 0, (size_t)hashgrid_entries() * 2 * sizeof(float), st) != hipSuccess) return -3;
-    const int mode = hash_scatter_mode();      // dh_hash_set_scatter_mode: 0 shipping, 1 / 2 ablations (test / diagnosis only)
-    const dim3 grid((unsigned)((4 * n + 255) / 256), HG_L);
-    if (mode == 1) hipLaunchKernelGGL(hash_table_bwd_kernel<1>, grid, dim3(256), 0, st, hashgrid_levels(), ws, O, n, grad + P.table, n_act);
-    else if (mode == 2) hipLaunchKernelGGL(hash_table_bwd_kernel<2>, grid, dim3(256), 0, st, hashgrid_levels(), ws, O, n, grad + P.table, n_act);
-    else hipLaunchKernelGGL(hash_table_bwd_kernel<0>, grid, dim3(256), 0, st, hashgrid_levels(), ws, O, n, grad + P.table, n_act);
+    if (parts & 1) {
+        // table: scatter the encoding adjoint of all E n evaluations
+        if (hipMemsetAsync(grad + P.table, 0, (size_t)hashgrid_entries() * 2 * sizeof(float), st) != hipSuccess) return -3;
+        const int mode = hash_scatter_mode();      // dh_hash_set_scatter_mode: 0 shipping, 1 / 2 ablations (test / diagnosis only)
+        const dim3 grid((unsigned)((4 * n + 255) / 256), HG_L);
+        if (mode == 1) hipLaunchKernelGGL(hash_table_bwd_kernel<1>, grid, dim3(256), 0, st, hashgrid_levels(), ws, O, n, grad + P.table, n_act);
+        else if (mode == 2) hipLaunchKernelGGL(hash_table_bwd_kernel<2>, grid, dim3(256), 0, st, hashgrid_levels(), ws, O, n, grad + P.table, n_act);
+        else hipLaunchKernelGGL(hash_table_bwd_kernel<0>, grid, dim3(256), 0, st, hashgrid_levels(), ws, O, n, grad + P.table, n_act);
+    }
+    if (parts & 2) {
+        SmallDwJobs J;
+        J.j[0] = {O.da, O.gin, 64, 36, en, O.lde, n};         // geometry lin0 (ones column -> bias)
+        J.j[1] = {O.dout, O.hh, HM_GOUT, 64, en, O.lde, n};   // geometry lin1
+        J.j[2] = {O.dz1, O.cin, 64, 32, n, O.ldn, n};         // colour lin0
+        J.j[3] = {O.dz2, O.h1, 64, 64, n, O.ldn, n};          // colour lin1
+        J.j[4] = {O.d_o, O.h2, 3, 64, n, O.ldn, n};           // colour lin2
+        float* slabs = ws + O.slabs;
+        float* dwsum = ws + O.total;
+        hipLaunchKernelGGL(small_dw_kernel, dim3(HW_SLABS, HW_JOBS), dim3(256), 0, st, ws, J, slabs, n_act);
+        hipLaunchKernelGGL(small_dw_reduce_kernel, dim3((HW_DW_FLOATS + 255) / 256, HW_JOBS), dim3(256), 0, st, slabs, dwsum);
+        hipLaunchKernelGGL(hash_fold_kernel, dim3(64, HW_JOBS), dim3(64), 0, st, params, hp, dwsum, P, grad);
+    }
     return ok();
 }
 

@@ -126,6 +126,6 @@ int launch_sh_color_bwd(const float* hp, const float* feat, const float* normals
 int launch_hash_geo_bwd(const float* params, const float* hp, const float* pts, const float* d_sdf, const float* d_feat,
                         const float* d_grad, int64_t n, float radius, float eps, float* ws, const int64_t* n_act, hipStream_t st);
 int launch_hash_weight_grads(const float* params, const float* hp, int64_t n, float* ws, float* grad, const int64_t* n_act,
-                             hipStream_t st);
+                             int parts, hipStream_t st);
 
 }  // namespace dh

@@ -19,11 +19,17 @@
 #include "mlp_common.h"
 #include "tile16h.h"
 #include "workspace.h"
+#include "stamps.h"
+
+DH_STAMP_READER(dh_dev_read_stamps_h)
 
 namespace dh {
 
 #ifndef H2_LEAN2
 #define H2_LEAN2 true            // development macro: the GEMM form of the two kernels with two saved-tile input streams (tile16h.h)
+#endif
+#ifndef H2_WPRE
+#define H2_WPRE 1                // development macro: 1 = the next GEMM's first weight chunks are requested before the image hand-off (tile16h.h WPre)
 #endif
 
 // tile partial-sum slots (workspace.h: tpart [nt][N_TILE_PART][256]) -- as kernels_mlp_bwd.hip
@@ -88,9 +94,12 @@ __device__ __forceinline__ void hs_init(HScratch& h, int tid) { if (tid < 12) h.
 // tslot: where this tile's maximum goes for the weight-gradient kernel (workspace.h tmax), or nullptr
 __device__ __forceinline__ TileScale lds_handoff(const f32x16 (&acc)[MT][2], _Float16* smain, HScratch& hs, float* lmax, int tid,
                                                  int wave, int lane, float extra_max = 0.f, const float* extra_lds = nullptr,
-                                                 unsigned* tslot = nullptr) {
+                                                 unsigned* tslot = nullptr, int sit = -1, int slayer = 0) {
+    (void)sit; (void)slayer;                          // (-DDH_STAMPS: phase stamps 3..6 of layer slayer; stamps.h)
     tile_max_publish(hs.sred, wave, lane, acc_absmax(acc));
+    DH_STAMP(sit, slayer, 3);
     __syncthreads();
+    DH_STAMP(sit, slayer, 4);
     const float m = tile_max_read(hs.sred);
     if (tid == 0) {
         if (lmax) *lmax = fmaxf(*lmax, m);
@@ -99,7 +108,9 @@ __device__ __forceinline__ TileScale lds_handoff(const f32x16 (&acc)[MT][2], _Fl
     if (extra_lds) extra_max = fmaxf(extra_max, *extra_lds);
     const TileScale ts = scale_for_max(fmaxf(m, extra_max));
     acc_to_lds_split(acc, smain, wave, lane, ts.S);
+    DH_STAMP(sit, slayer, 5);
     __syncthreads();
+    DH_STAMP(sit, slayer, 6);
     return ts;
 }
 
@@ -118,7 +129,9 @@ __global__ __launch_bounds__(256, 2) void color_fwd_h_kernel(ColHPtrs C, const f
     hs_init(hs, tid);
     float winv[4];
     DH_UNROLL for (int l = 0; l < 4; ++l) winv[l] = winv_from_bits(C.wabs[l]);
-    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    int it = 0;
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x, ++it) {
+        (void)it;
         if (tid < TM) {                                  // (TM == 64: exactly wave 0)
             const int64_t gp = tile * TM + tid;
             float* row = saux + tid * LDA;
@@ -148,19 +161,26 @@ __global__ __launch_bounds__(256, 2) void color_fwd_h_kernel(ColHPtrs C, const f
         acc_load_native_b(acc, tile_rsrc(feat + tile * TILE_F), loff);
         // (the barrier inside also publishes saux; the previous tile ended with one, so the images are free).  The extras [p,
         // embed(view), n] share layer 0's accumulator with feat: one scale for both, from the larger of the two maxima
+        WPre wpre;
+        if (H2_WPRE) gemm_preload<false>(wpre, C.main[0], wave, lane);
         TileScale ts = lds_handoff(acc, smain, hs, save ? &hs.lmax[4] : nullptr, tid, wave, lane, 0.f, &hs.sred2[0]);
         if (save && tid == 0) hs.lmax[5] = fmaxf(hs.lmax[5], hs.sred2[0]);      // the extras' class maximum (sred2[0]: rewritten a tile away)
         if (save) aux_lds_to_native(saux, caux + tile * AUXT_F, wave, lane);
         for (int l = 0; l < 4; ++l) {
+            DH_STAMP(it, l, 0);
             acc_zero(acc);
-            gemm_rows_hp(acc, smain, 16, C.main[l], wave, lane);
+            gemm_rows_hp(acc, smain, 16, C.main[l], wave, lane, NoPre(), H2_WPRE ? &wpre : nullptr);
             const float inv = ts.inv * winv[l];
             if (l == 0) gemm_rows_aux_h(acc, saux, C.aux, wave, lane, ts.S);
+            DH_STAMP(it, l, 1);
             const float b0 = C.bias[l][acc_col(wave, 0, lane)], b1 = C.bias[l][acc_col(wave, 1, lane)];
             acc_map(acc, [&](int, int t, int, float v) { return fmaxf(fmaf(v, inv, t ? b1 : b0), 0.f); });
             if (save) acc_store_native_b(acc, tile_rsrc(cact + ((int64_t)l * ntiles + tile) * TILE_F), loff);
-            ts = lds_handoff(acc, smain, hs, save ? &hs.lmax[l] : nullptr, tid, wave, lane);
+            DH_STAMP(it, l, 2);
+            if (H2_WPRE && l < 3) gemm_preload<false>(wpre, C.main[l + 1], wave, lane);
+            ts = lds_handoff(acc, smain, hs, save ? &hs.lmax[l] : nullptr, tid, wave, lane, 0.f, nullptr, nullptr, it, l);
         }
+        DH_STAMP(it, 4, 0);
         const int64_t gp = tile * TM + tid / TPP;
         DH_UNROLL for (int j = 0; j < 3; ++j) {
             const float raw = fmaf(row_dot256_hp(smain, C.w4 + j * 256, tid), ts.inv, C.b4[j]);
@@ -192,11 +212,14 @@ __global__ __launch_bounds__(256, 2) void sdf_grad_h_kernel(SdfHPtrs P, const fl
     // piece overflowed -- and keeps their maximum: the class maximum of `act` for the weight-gradient kernel (workspace.h ABSMAX_ACT)
     // and what dh_range_words exposes.  One v_max3_f32 per two values.
     float hmax = 0.f;
-    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    int it = 0;
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x, ++it) {
+        (void)it;
         f32x16 acc[MT][2];
         f32x16 ge[AUX_NTW];
         aux_zero(ge);
         TileScale ts;
+        WPre wpre;
         // a_7 = W8[0,:] * sigma'(z_7)
         {
             const float w0 = P.w8row0[acc_col(wave, 0, lane)], w1 = P.w8row0[acc_col(wave, 1, lane)];
@@ -205,14 +228,17 @@ __global__ __launch_bounds__(256, 2) void sdf_grad_h_kernel(SdfHPtrs P, const fl
                 DH_UNROLL for (int r = 0; r < 16; r += 2) hmax = fmaxf(hmax, fmaxf(acc[m][t][r], acc[m][t][r + 1]));
             acc_map(acc, [&](int, int t, int, float h) { float s, em; softplus_deriv_from_h(h, s, em); return (t ? w1 : w0) * s; });
             if (save) acc_store_native_b(acc, tile_rsrc(asave + ((int64_t)7 * ntiles + tile) * TILE_F), loff);
+            if (H2_WPRE) gemm_preload<false>(wpre, P.rev[7], wave, lane);
             ts = lds_handoff(acc, smain, hs, &hs.lmax[7], tid, wave, lane);
         }
         for (int l = 7; l >= 1; --l) {
+            DH_STAMP(it, l, 0);
             acc_zero(acc);
             // sigma' comes from act[l-1] == the input of layer l: its first m-slab is requested inside the GEMM's last chunks
             const rsrc_t hr = tile_rsrc(act + ((int64_t)(l - 1) * ntiles + tile) * TILE_F);
             Slab h0, h1;
-            gemm_rows_hp<false>(acc, smain, 16, P.rev[l], wave, lane, [&] { slab_ld(h0, hr, loff, 0); });      // u_l = a_l W_l
+            gemm_rows_hp<false>(acc, smain, 16, P.rev[l], wave, lane, [&] { slab_ld(h0, hr, loff, 0); }, H2_WPRE ? &wpre : nullptr);      // u_l = a_l W_l
+            DH_STAMP(it, l, 1);
             slab_ld(h1, hr, loff, 1);
             const float inv = ts.inv * winv_from_bits(P.wabs[l]);
             if (l == 4) {                                                         // skip path -> ge (true units)
@@ -235,8 +261,11 @@ __global__ __launch_bounds__(256, 2) void sdf_grad_h_kernel(SdfHPtrs P, const fl
                 __builtin_amdgcn_sched_barrier(0);
             }
             if (save) acc_store_native_b(acc, tile_rsrc(asave + ((int64_t)(l - 1) * ntiles + tile) * TILE_F), loff);
-            ts = lds_handoff(acc, smain, hs, &hs.lmax[l - 1], tid, wave, lane);
+            DH_STAMP(it, l, 2);
+            if (H2_WPRE && l > 1) gemm_preload<false>(wpre, P.rev[l - 1], wave, lane);
+            ts = lds_handoff(acc, smain, hs, &hs.lmax[l - 1], tid, wave, lane, 0.f, nullptr, nullptr, it, l);
         }
+        DH_STAMP(it, 0, 0);
         {                                                                         // ge += a_0 W_0
             f32x16 g0[AUX_NTW];
             aux_zero(g0);
@@ -341,12 +370,14 @@ __global__ __launch_bounds__(256, 2) void color_bwd_h_kernel(ColHPtrs C, const f
         }
         acc_store_native_b(acc, tile_rsrc(czbar + ((int64_t)3 * ntiles + tile) * TILE_F), loff);
         tile_colsum(acc, tp + (TP_COL_B0 + 3) * 256, wave, lane);
+        WPre wpre;
+        if (H2_WPRE) gemm_preload<false>(wpre, C.rev[3], wave, lane);
         TileScale ts = lds_handoff(acc, smain, hs, &hs.lmax[3], tid, wave, lane, 0.f, nullptr, tmax + (TMAX_CZBAR + 3) * ntiles + tile);
         for (int l = 3; l >= 1; --l) {
             acc_zero(acc);
             const rsrc_t hr = tile_rsrc(cact + ((int64_t)(l - 1) * ntiles + tile) * TILE_F);
             Slab h0, h1;
-            gemm_rows_hp<false>(acc, smain, 16, C.rev[l], wave, lane, [&] { slab_ld(h0, hr, loff, 0); });      // hbar_l = zbar_l W_l
+            gemm_rows_hp<false>(acc, smain, 16, C.rev[l], wave, lane, [&] { slab_ld(h0, hr, loff, 0); }, H2_WPRE ? &wpre : nullptr);      // hbar_l = zbar_l W_l
             slab_ld(h1, hr, loff, 1);
             const float inv = ts.inv * winv_from_bits(C.wabs[l]);
             DH_UNROLL for (int m = 0; m < MT; ++m) {
@@ -361,12 +392,13 @@ __global__ __launch_bounds__(256, 2) void color_bwd_h_kernel(ColHPtrs C, const f
             }
             acc_store_native_b(acc, tile_rsrc(czbar + ((int64_t)(l - 1) * ntiles + tile) * TILE_F), loff);
             tile_colsum(acc, tp + (TP_COL_B0 + l - 1) * 256, wave, lane);
+            if (H2_WPRE) gemm_preload<false>(wpre, C.rev[l - 1], wave, lane);
             ts = lds_handoff(acc, smain, hs, &hs.lmax[l - 1], tid, wave, lane, 0.f, nullptr, tmax + (TMAX_CZBAR + l - 1) * ntiles + tile);
         }
         // lin0: featbar = zbar_0 W0[:,33:] ; extras adjoint = zbar_0 W0[:,:33] (only the normal columns 30..32 matter)
         const float inv0 = ts.inv * winv_from_bits(C.wabs[0]);
         acc_zero(acc);
-        gemm_rows_hp(acc, smain, 16, C.rev[0], wave, lane);
+        gemm_rows_hp(acc, smain, 16, C.rev[0], wave, lane, NoPre(), H2_WPRE ? &wpre : nullptr);
         acc_map(acc, [&](int, int, int, float v) { return v * inv0; });
         acc_store_native_b(acc, tile_rsrc(featbar + tile * TILE_F), loff);
         tile_max_publish(hs.sred2, wave, lane, acc_absmax(acc));       // featbar's maxima: read behind the barrier that ends the tile

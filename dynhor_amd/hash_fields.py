@@ -83,6 +83,8 @@ class HashParamStore(ParamStore):
         _, _, toff, entries, feats = hash_param_layout(3, 0)
         assert tuple(sdf_network.encoding.table.shape) == (entries, feats)
         slices.append((sdf_network.encoding.table, toff, entries * feats))
+        assert toff == 0, "the table leads the flat vector (the overlapped all-reduce reduces grad[:table_floats])"
+        self.table_floats = entries * feats
         for net, mod, n_layers in ((0, sdf_network, 2), (2, color_network, 3)):
             for l in range(n_layers):
                 b, g, v, out_dim, in_dim = hash_param_layout(net, l)
@@ -200,6 +202,21 @@ class HashNeuSRenderer(NeuSRenderer):
         T("hash_color_forward", L.dh_hash_color_forward, _p(packed), _p(s.feat), _p(s.normals), _p(s.rays_d), s.n, P,
           _p(s.colors), _NULLP, _lib.stream())
 
+    def _weight_grads(self, P, ws, grad, n_dev):
+        """dh_hash_weight_grads; with a table_grad_hook (the data-parallel Runner's) in two parts: the table gradient first, the hook
+        (an asynchronous all-reduce of that 49 MB slice: it runs on the collective's own stream) issued right behind it, then the five
+        small linears' gradients on the compute stream -- the large collective overlaps them.  The hook's
+        handle is left in self.pending_table_reduce for the caller to wait on before the optimiser step."""
+        L, T, st = _lib.lib(), self.timer, self.store
+        hook = getattr(self, "table_grad_hook", None)
+        self.pending_table_reduce = None
+        if hook is None:
+            T("hash_weight_grads", L.dh_hash_weight_grads, _p(st.flat), _p(st.packed), P, _p(ws), _p(grad), n_dev, _lib.stream())
+            return
+        T("hash_weight_grads", L.dh_hash_weight_grads_parts, _p(st.flat), _p(st.packed), P, _p(ws), _p(grad), n_dev, 1, _lib.stream())
+        self.pending_table_reduce = hook(grad[:st.table_floats])
+        T("hash_weight_grads_mlp", L.dh_hash_weight_grads_parts, _p(st.flat), _p(st.packed), P, _p(ws), _p(grad), n_dev, 2, _lib.stream())
+
     def _net_backward(self, s, d_sdf, d_normals, d_colors, grad):
         L, T, st = _lib.lib(), self.timer, self.store
         P = s.B * s.n
@@ -208,7 +225,7 @@ class HashNeuSRenderer(NeuSRenderer):
           _p(d_colors), s.n, P, _p(s.ws), _p(d_feat), _p(d_normals), _NULLP, _lib.stream())
         T("hash_geo_backward", L.dh_hash_geo_backward, _p(st.flat), _p(st.packed), _p(s.pts), _p(d_sdf), _p(d_feat),
           _p(d_normals), P, self.radius, self.fd_eps, _p(s.ws), _NULLP, _lib.stream())
-        T("hash_weight_grads", L.dh_hash_weight_grads, _p(st.flat), _p(st.packed), P, _p(s.ws), _p(grad), _NULLP, _lib.stream())
+        self._weight_grads(P, s.ws, grad, _NULLP)
 
 
     # ------------------------------------------------------------------ occupancy-grid marching path (packed rays)
@@ -331,7 +348,7 @@ class HashNeuSRenderer(NeuSRenderer):
           1, P, _p(s.ws), _p(d_feat), _p(d_normals), _p(m.n_dev), _lib.stream())
         T("hash_geo_backward", L.dh_hash_geo_backward, _p(st.flat), _p(st.packed), _p(m.pts), _p(d_sdf), _p(d_feat),
           _p(d_normals), P, self.radius, self.fd_eps, _p(s.ws), _p(m.n_dev), _lib.stream())
-        T("hash_weight_grads", L.dh_hash_weight_grads, _p(st.flat), _p(st.packed), P, _p(s.ws), _p(grad), _p(m.n_dev), _lib.stream())
+        self._weight_grads(P, s.ws, grad, _p(m.n_dev))
         raw = torch.exp(st.flat[st.var_off] * 10.0)
         passthrough = ((raw >= 1e-6) & (raw <= 1e6)).float()
         grad[st.var_off] = d_inv_s.sum() * 10.0 * raw * passthrough

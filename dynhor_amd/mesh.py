@@ -104,6 +104,164 @@ def marching_tetrahedra(u: torch.Tensor, threshold: float, bound_min, bound_max)
     return verts, faces
 
 
+# ---------------------------------------------------------------------------------------------------- marching cubes
+# Upstream's extract_geometry calls mcubes.marching_cubes.  The 256-case table is GENERATED here from the cube's
+# topology instead of typed in: corner / edge numbering of the classic table (Lorensen & Cline; P. Bourke's layout), every cube face
+# contributes one directed segment per maximal run of inside corners along its boundary (counter-clockwise seen from outside the cube:
+# from the cut edge where the run is entered to the one where it is left), the segments of the six faces chain into closed loops, and
+# every loop is fanned into triangles.  Because the rule is a FACE rule, two cubes always agree on the face they share -- ambiguous
+# faces (diagonal corners inside) always separate the inside corners -- so the mesh is closed without the case-13 style repairs the
+# hand-made tables need; for the unambiguous cases the polygons are the classic ones.  Normals point from inside (u > threshold)
+# to outside, as marching_tetrahedra's.
+_MC_CORNERS = torch.tensor([[0, 0, 0], [1, 0, 0], [1, 1, 0], [0, 1, 0], [0, 0, 1], [1, 0, 1], [1, 1, 1], [0, 1, 1]])
+_MC_EDGES = [(0, 1), (1, 2), (2, 3), (3, 0), (4, 5), (5, 6), (6, 7), (7, 4), (0, 4), (1, 5), (2, 6), (3, 7)]
+_MC_FACES = [(0, 3, 2, 1), (4, 5, 6, 7), (0, 1, 5, 4), (3, 7, 6, 2), (0, 4, 7, 3), (1, 2, 6, 5)]      # CCW seen from outside
+_MC_TABLE = None
+
+
+def _same_face(e0, e1):
+    """Do cube edges e0, e1 lie on a common face?  (A triangle edge between two such crossings lies IN that face, where the
+    neighbouring cube may put the same edge: four triangles around one edge.)"""
+    for face in _MC_FACES:
+        fe = {frozenset((face[k], face[(k + 1) % 4])) for k in range(4)}
+        if frozenset(_MC_EDGES[e0]) in fe and frozenset(_MC_EDGES[e1]) in fe:
+            return True
+    return False
+
+
+def _triangulate_loop(loop):
+    """All triangulations of the (ordered) polygon `loop`, the first one none of whose DIAGONALS lies in a cube face; orientation kept."""
+    n = len(loop)
+    best = None
+
+    def rec(idx):
+        # triangulations of the sub-polygon with vertex indices idx (in order): lists of triangles
+        if len(idx) < 3:
+            yield []
+            return
+        if len(idx) == 3:
+            yield [tuple(idx)]
+            return
+        a, b = idx[0], idx[-1]
+        for k in range(1, len(idx) - 1):
+            for left in rec(idx[:k + 1]):
+                for right in rec(idx[k:]):
+                    yield left + [(a, idx[k], b)] + right
+
+    for tri in rec(list(range(n))):
+        bad = 0
+        for t in tri:
+            for i, j in ((t[0], t[1]), (t[1], t[2]), (t[2], t[0])):
+                if (j - i) % n not in (1, n - 1) and _same_face(loop[i], loop[j]):
+                    bad += 1
+        if best is None or bad < best[0]:
+            best = (bad, tri)
+            if bad == 0:
+                break
+    assert best is not None and best[0] == 0, ("no face-diagonal-free triangulation", loop)
+    return [(loop[a], loop[b], loop[c]) for a, b, c in best[1]]
+
+
+def marching_cubes_table():
+    """(tri [256, 5, 3] int64 edge ids, -1 padded; n_tri [256]).  Bit i of the case index = corner i inside."""
+    global _MC_TABLE
+    if _MC_TABLE is not None:
+        return _MC_TABLE
+    edge_id = {}
+    for i, (a, b) in enumerate(_MC_EDGES):
+        edge_id[(a, b)] = edge_id[(b, a)] = i
+    tri = torch.full((256, 5, 3), -1, dtype=torch.int64)
+    n_tri = torch.zeros(256, dtype=torch.int64)
+    for case in range(256):
+        inside = [(case >> i) & 1 for i in range(8)]
+        nxt = {}
+        for face in _MC_FACES:
+            ins = [inside[c] for c in face]
+            if all(ins) or not any(ins):
+                continue
+            for k in range(4):
+                # a run of inside corners starts at corner k (its predecessor is outside) ...
+                if ins[k] and not ins[k - 1]:
+                    j = k
+                    while ins[(j + 1) % 4]:
+                        j += 1
+                    # ... and ends at corner j: the segment runs from the edge entering the run to the edge leaving it
+                    e_in = edge_id[(face[k - 1], face[k])]
+                    e_out = edge_id[(face[j % 4], face[(j + 1) % 4])]
+                    assert e_in not in nxt
+                    nxt[e_in] = e_out
+        tris = []
+        todo = set(nxt)
+        while todo:
+            start = min(todo)
+            loop, e = [], start
+            while True:
+                loop.append(e); todo.discard(e)
+                e = nxt[e]
+                if e == start:
+                    break
+            tris += _triangulate_loop(loop)
+        assert len(tris) <= 5, (case, tris)
+        n_tri[case] = len(tris)
+        for t, abc in enumerate(tris):
+            tri[case, t] = torch.tensor(abc)
+    _MC_TABLE = (tri, n_tri)
+    return _MC_TABLE
+
+
+def marching_cubes(u: torch.Tensor, threshold: float, bound_min, bound_max):
+    """Table-driven marching cubes on u [N,N,N] (u = -sdf, inside > threshold): same interface, vertex welding (by grid edge) and
+    orientation as marching_tetrahedra; about a third of its triangles."""
+    dev = u.device
+    N = u.shape[0]
+    bmin = torch.as_tensor(bound_min, dtype=torch.float32, device=dev)
+    bmax = torch.as_tensor(bound_max, dtype=torch.float32, device=dev)
+    f = u - threshold
+    sl = (slice(0, N - 1), slice(1, N))
+    case = torch.zeros((N - 1, N - 1, N - 1), dtype=torch.int64, device=dev)
+    for i, (dx, dy, dz) in enumerate(_MC_CORNERS.tolist()):
+        case |= (f[sl[dx], sl[dy], sl[dz]] > 0).to(torch.int64) << i
+    tri_t, n_t = marching_cubes_table()
+    tri_t, n_t = tri_t.to(dev), n_t.to(dev)
+    base = ((case != 0) & (case != 255)).nonzero()                                # [C,3] active cells
+    if base.shape[0] == 0:
+        return torch.zeros(0, 3, device=dev), torch.zeros(0, 3, dtype=torch.int64, device=dev)
+    ccase = case[base[:, 0], base[:, 1], base[:, 2]]
+    ea = torch.tensor([e[0] for e in _MC_EDGES], device=dev)
+    eb = torch.tensor([e[1] for e in _MC_EDGES], device=dev)
+    corners = _MC_CORNERS.to(dev)
+    NN = N * N * N
+    pos_all, key_all = [], []
+    for t in range(5):
+        sel = n_t[ccase] > t
+        if not bool(sel.any()):
+            break
+        cell = base[sel]                                                          # [M,3]
+        edges = tri_t[ccase[sel], t]                                              # [M,3] edge ids
+        ca = cell[:, None, :] + corners[ea[edges]]                                # [M,3,3] corner a of each edge
+        cb = cell[:, None, :] + corners[eb[edges]]
+        ia = (ca[..., 0] * N + ca[..., 1]) * N + ca[..., 2]
+        ib = (cb[..., 0] * N + cb[..., 1]) * N + cb[..., 2]
+        va = f[ca[..., 0], ca[..., 1], ca[..., 2]]
+        vb = f[cb[..., 0], cb[..., 1], cb[..., 2]]
+        # the crossing is computed from the corner with the lower linear index, whichever cell asks (identical bits everywhere)
+        sw = ia > ib
+        p0 = torch.where(sw[..., None], cb, ca).float(); p1 = torch.where(sw[..., None], ca, cb).float()
+        v0 = torch.where(sw, vb, va); v1 = torch.where(sw, va, vb)
+        tt = (v0 / (v0 - v1)).clamp(0, 1).unsqueeze(-1)
+        pos_all.append(p0 + tt * (p1 - p0))
+        key_all.append(torch.minimum(ia, ib) * NN + torch.maximum(ia, ib))
+    flat = torch.cat(pos_all, dim=0).reshape(-1, 3)
+    key = torch.cat(key_all, dim=0).reshape(-1)
+    uniq, inv = torch.unique(key, return_inverse=True)
+    verts = torch.zeros(uniq.shape[0], 3, device=dev).index_copy_(0, inv, flat)
+    faces = inv.reshape(-1, 3)
+    ok = (faces[:, 0] != faces[:, 1]) & (faces[:, 1] != faces[:, 2]) & (faces[:, 0] != faces[:, 2])
+    faces = faces[ok]
+    verts = verts / (N - 1) * (bmax - bmin) + bmin
+    return verts, faces
+
+
 def write_ply(path: str, verts: torch.Tensor, faces: torch.Tensor):
     v = verts.detach().cpu().numpy().astype(np.float32)
     f = faces.detach().cpu().numpy().astype(np.int32)

@@ -214,12 +214,15 @@ class NeuSRenderer:
 
     # ------------------------------------------------------------------ geometry extraction (upstream extract_geometry)
     @torch.no_grad()
-    def extract_geometry(self, bound_min, bound_max, resolution, threshold=0.0):
+    def extract_geometry(self, bound_min, bound_max, resolution, threshold=0.0, method="cubes"):
         """Upstream NeuSRenderer.extract_geometry(bound_min, bound_max, resolution, threshold): -sdf on a regular grid
         (HIP no-grad SDF kernel, 64^3-point chunks), iso-surface at `threshold`.  Returns (vertices [V,3], triangles [F,3])
-        as device tensors; the iso-surface is extracted by marching tetrahedra (dynhor_amd/mesh.py) because PyMCubes,
-        which upstream calls, is not installable here."""
-        from .mesh import marching_tetrahedra
+        as device tensors.  method "cubes" (default since round 5): table-driven marching cubes, upstream's algorithm
+        (mcubes.marching_cubes; PyMCubes itself is not installable here, the case table is generated in dynhor_amd/mesh.py);
+        "tetrahedra": marching tetrahedra (rounds 1-4), three times the triangles."""
+        from .mesh import marching_cubes, marching_tetrahedra
+        if method not in ("cubes", "tetrahedra"):
+            raise ValueError("extract_geometry: method must be 'cubes' or 'tetrahedra'")
         dev = self.store.device
         N = int(resolution)
         ax = [torch.linspace(float(bound_min[i]), float(bound_max[i]), N, device=dev) for i in range(3)]
@@ -235,7 +238,7 @@ class NeuSRenderer:
             # (the no-grad chain has no workspace to post a range status into: beyond the split_f16 range its outputs are NaN)
             raise _lib.DynhorHipError("extract_geometry: non-finite SDF values on the grid (split_f16 range exceeded, or the network "
                                       "has diverged); use arithmetic 'split_bf16' for queries this far out")
-        return marching_tetrahedra(u, threshold, bound_min, bound_max)
+        return (marching_cubes if method == "cubes" else marching_tetrahedra)(u, threshold, bound_min, bound_max)
 
     # ------------------------------------------------------------------ hierarchical sampling (App. A.5/A.6)
     @torch.no_grad()

@@ -123,6 +123,14 @@ class Runner:
                                      store=self.store, device=self.device, **self.conf["model"]["neus_renderer"], **extra)
         if tr.get("roctx"):
             self.renderer.timer.set_markers(True)
+        # hash family, data-parallel: the 49 MB table gradient is reduced by a collective of its own, started the moment the table
+        # scatter has been enqueued and overlapped with the small weight-gradient GEMMs (hash_fields.HashNeuSRenderer._weight_grads);
+        # train.overlap_table_reduce = False keeps the one serial all-reduce of the whole bucket (the two are bitwise identical at
+        # two ranks; at more ranks a ring may add the same numbers in a different order)
+        self.overlap_table_reduce = bool(tr.get("overlap_table_reduce", True)) and hasattr(self.store, "table_floats") \
+            and dist.is_available() and dist.is_initialized()
+        if self.overlap_table_reduce:
+            self.renderer.table_grad_hook = lambda t: dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=True)
         self.pose_refiner = None
         if tr["refine_poses"]:
             from .pose import PoseRefiner
@@ -197,7 +205,14 @@ class Runner:
                 Rn, Tn = self.pose_refiner.poses()
                 self.dataset.R.copy_(Rn); self.dataset.T.copy_(Tn)
         grad = self.store.grad_flat
-        dh_dist.allreduce_sum_(grad)                             # RCCL over xGMI: one 3.2 MB bucket
+        pending = getattr(self.renderer, "pending_table_reduce", None)
+        if pending is not None:
+            # hash family: the table slice is already on its way (started behind the table scatter); reduce the small rest, then join
+            dh_dist.allreduce_sum_(grad[self.store.table_floats:])
+            pending.wait()
+            self.renderer.pending_table_reduce = None
+        else:
+            dh_dist.allreduce_sum_(grad)                         # RCCL over xGMI: one 3.2 MB bucket
         lr = self.current_lr()          # 0 at iter_step 0, as upstream (update_learning_rate() runs before the loop)
         self.store.adam_step(lr, grad=grad, grad_scale=1.0 / self.world)
         self.iter_step += 1
@@ -390,11 +405,12 @@ class Runner:
     @torch.no_grad()
     def validate_mesh(self, resolution=64, threshold=0.0, world_space=False, save=True):
         """Upstream Runner.validate_mesh / NeuSRenderer.extract_geometry: -sdf on a regular grid over
-        the object bounding box (HIP no-grad SDF kernel, 64^3-point chunks), iso-surface by marching tetrahedra
+        the object bounding box (HIP no-grad SDF kernel, 64^3-point chunks), iso-surface by marching cubes (model.mesh_method: 'cubes' | 'tetrahedra')
         (dynhor_amd/mesh.py; mcubes is not available), written as meshes/<iter>.ply.  Returns (vertices, triangles)."""
         from .mesh import write_ply
         bmin, bmax = self.dataset.object_bbox_min, self.dataset.object_bbox_max
-        verts, faces = self.renderer.extract_geometry(bmin, bmax, resolution=resolution, threshold=threshold)
+        verts, faces = self.renderer.extract_geometry(bmin, bmax, resolution=resolution, threshold=threshold,
+                                                      method=self.conf.get("model", {}).get("mesh_method", "cubes"))
         if save and self.rank == 0:
             d = os.path.join(self.base_exp_dir, "meshes")
             os.makedirs(d, exist_ok=True)

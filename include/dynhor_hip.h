@@ -348,6 +348,11 @@ int dh_hash_geo_backward(const float* params, const float* packed, const float* 
                          const int64_t* n_active, void* stream);
 int dh_hash_weight_grads(const float* params, const float* packed, int64_t n, float* ws, float* grad, const int64_t* n_active,
                          void* stream);
+/* The same in two parts, for data-parallel callers: parts = 1 writes the table gradient (the leading dh_hashgrid_entries() x 2 floats
+ * of grad: 49 MB), parts = 2 the five small linears, 3 = both (= dh_hash_weight_grads).  Calling 1, starting the table's all-reduce on
+ * a side stream, then 2, hides the large collective behind the small weight-gradient GEMMs (dynhor_amd/hash_fields.py). */
+int dh_hash_weight_grads_parts(const float* params, const float* packed, int64_t n, float* ws, float* grad, const int64_t* n_active,
+                               int parts, void* stream);
 /* Diagnosis only (scripts/psnr_parity.py ablations): how dh_hash_weight_grads merges table-gradient adds before they
  * reach memory.  0 (default, shipping) = 7-evaluation blending + ray-run merging + quad-lane packing; 1 = no ray-run
  * merging; 2 = neither (one atomic per evaluation corner, tcnn's scheme).  Same sums up to float-atomic ordering. */

@@ -19,6 +19,7 @@ def main():
     ap.add_argument("--out", type=str, default=None)
     ap.add_argument("--blocks", type=int, default=512, help="workgroups that wrote stamps (a -DDH_GRID_DIV=2 build: 256)")
     ap.add_argument("--stamps", action="store_true", help="the library is a -DDH_STAMPS build: dump per-phase cycle stamps")
+    ap.add_argument("--stamps-h", action="store_true", help="-DDH_STAMPS build: phase stamps of the two-piece fp16 chains (kernels_mlp_h.hip)")
     args = ap.parse_args()
     from dynhor_amd import _lib
     if args.lib:
@@ -125,6 +126,41 @@ def main():
             out[key] = d
             print(key, json.dumps(d, indent=1), flush=True)
         res["stamps"] = out
+    if args.stamps_h:
+        import numpy as np
+        n = 512 * 4 * 2 * 10 * 8
+        out = {}
+        # (stage, layers recorded in execution order): slots 0 layer start | 1 GEMM done | 2 epilogue math + tile stores issued |
+        # 3 tile maximum published | 4 behind barrier 1 | 5 pieces written to LDS | 6 behind barrier 2
+        for stage, layers in (("color_forward", [0, 1, 2, 3]), ("sdf_gradient", [7, 6, 5, 4, 3, 2, 1])):
+            _lib.check(stages[stage]())
+            torch.cuda.synchronize()
+            buf = (ctypes.c_ulonglong * n)()
+            fn = L.dh_dev_read_stamps_h
+            fn.restype = ctypes.c_int
+            fn.argtypes = [ctypes.c_void_p, ctypes.c_longlong]
+            assert fn(ctypes.cast(buf, ctypes.c_void_p), n) == 0
+            a = np.frombuffer(buf, dtype=np.uint64).reshape(512, 4, 2, 10, 8).astype(np.float64)[:args.blocks]
+            lay = a[:, :, :, layers[1:-1], :]          # steady layers (not the first, whose input comes from a tile load)
+            names = ["gemm", "epilogue_math+tile_stores", "tile_max", "barrier1", "scale+lds_piece_write", "barrier2"]
+            d = {}
+            for i, nm in enumerate(names):
+                dd = lay[..., i + 1] - lay[..., i]
+                d[nm] = {"mean": float(dd.mean()), "p10": float(np.percentile(dd, 10)), "p90": float(np.percentile(dd, 90))}
+            tot = lay[..., 6] - lay[..., 0]
+            d["layer_total"] = {"mean": float(tot.mean()), "p10": float(np.percentile(tot, 10)), "p90": float(np.percentile(tot, 90))}
+            # the two workgroups of a CU are b and b + 256 (scripts/micro/hwid_probe.hip): their phase offset at a steady layer's start
+            if args.blocks == 512:
+                L0 = layers[2]
+                for itn in (0, 1):
+                    dl = np.mod(a[256:, 0, itn, L0, 0] - a[:256, 0, itn, L0, 0], d["layer_total"]["mean"]) / d["layer_total"]["mean"]
+                    d["cu_pair_phase_hist10_it%d" % itn] = np.histogram(dl, bins=10, range=(0, 1))[0].tolist()
+            # waves of one workgroup: spread of their GEMM-done stamps (who waits for whom at barrier 1)
+            g = a[:, :, :, layers[2], 1]
+            d["gemm_done_spread_within_workgroup"] = {"mean": float((g.max(axis=1) - g.min(axis=1)).mean())}
+            out[stage] = d
+            print(stage, json.dumps(d, indent=1), flush=True)
+        res["stamps_h"] = out
     if args.out:
         os.makedirs(os.path.dirname(os.path.join(ROOT, args.out)), exist_ok=True)
         json.dump(res, open(os.path.join(ROOT, args.out), "w"), indent=1)

@@ -43,7 +43,11 @@ def test_ray_gradients_match_oracle(tiny_dataset, normal_w):
     # the sample points themselves (the tensor render_core hands to the SDF network, the gradient pass and the colour network): their
     # total adjoint is what the HIP path leaves PER POINT in s.d_pts
     seen = {}
-    hook = o_r.sdf_network.register_forward_pre_hook(lambda mod, inp: (seen.setdefault("pts", inp[0]), inp[0].retain_grad())[0] and None)
+    def grab(mod, inp):
+        if "pts" not in seen:
+            seen["pts"] = inp[0]
+            inp[0].retain_grad()
+    hook = o_r.sdf_network.register_forward_pre_hook(grab)
     _oracle_loss(o_r, o, d, near.double(), far.double(), z.double(), r64, R, car, normal_w).backward()
     hook.remove()
     pts_ref = seen["pts"].grad.detach().clone()
