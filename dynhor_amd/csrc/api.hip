@@ -18,7 +18,10 @@ namespace {
 inline bool misaligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) != 0; }
 inline bool bad_arith(int a) { return a != DH_ARITH_SPLIT_BF16 && a != DH_ARITH_FP32_MFMA && a != DH_ARITH_SPLIT_F16; }
 inline int cur_arith() { return __atomic_load_n(&dh::g_arith, __ATOMIC_RELAXED); }
-constexpr int DEFAULT_GRID = 256 * 2;   // persistent workgroups: all that are co-resident (two 64-point tiles per CU)
+#ifndef DH_GRID_DIV
+#define DH_GRID_DIV 1                    // development macro: 2 = ONE workgroup per CU (what a chain's phases cost without a co-resident partner)
+#endif
+constexpr int DEFAULT_GRID = 256 * 2 / DH_GRID_DIV;   // persistent workgroups: all that are co-resident (two 64-point tiles per CU)
 }  // namespace
 
 extern "C" {

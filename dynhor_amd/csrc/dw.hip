@@ -31,7 +31,7 @@ struct DwJobs { DwJob j[16]; int n; };
 #define DW_GROUPS 8
 #endif
 #ifndef DW_AUX_COST
-#define DW_AUX_COST 12.0           // (8 until the two-piece kernel's aux jobs moved to the three-piece body: 12 and 16 measure 2.20 ms, 8: 2.38)
+#define DW_AUX_COST 10.0           // (round 5, two-piece aux body, two same-box sweeps: 8: 2.27, 10: 2.19 / 2.22, 12: 2.22 / 2.26, 16: 2.27 ms)
 #endif
 struct DwGroups { int n; int job0[DW_GROUPS + 1]; int wg0[DW_GROUPS + 1]; int64_t off0[DW_GROUPS + 1]; };
 __device__ __forceinline__ int dw_group_of(const DwGroups& Gp, int g) {

@@ -94,9 +94,28 @@ __device__ __forceinline__ TileScale scale_for_max(float m) {
     t.inv = __builtin_bit_cast(float, pow2_inv_bits(sb));
     return t;
 }
+// maximum over the wave's 64 lanes, valid on EVERY lane.  Round 5: six DPP steps on the vector ALU (row_shr 1 / 2 / 4 / 8, row_bcast 15 /
+// 31: the classic wave64 reduction, the result lands in lane 63) + one v_readlane, instead of six __shfl_xor = six dependent LDS round
+// trips (ds_bpermute, ~150 cycles each): the phase stamps of the fp16 chains showed 2,300 cycles per layer between the epilogue and
+// barrier 1 of the image hand-off (profiles/r05_chain_phase_stamps.json).  Inputs are >= 0 (absolute values): 0 is the identity.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float wave_max_step(float m) {
+    // lanes without a source (and rows outside ROW_MASK) read the identity 0.0f
+    const int o = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, m), CTRL, ROW_MASK, 0xf, false);
+    return fmaxf(m, __builtin_bit_cast(float, o));
+}
 __device__ __forceinline__ float wave_max(float m) {
+#ifdef DH_WAVE_MAX_SHFL                      // (development: rounds 1-4's form, for the A/B of profiles/r05_ab_chain_experiments.json)
     DH_UNROLL for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
     return m;
+#endif
+    m = wave_max_step<0x111, 0xf>(m);        // row_shr:1
+    m = wave_max_step<0x112, 0xf>(m);        // row_shr:2
+    m = wave_max_step<0x114, 0xf>(m);        // row_shr:4
+    m = wave_max_step<0x118, 0xf>(m);        // row_shr:8   -> lane 15 of every 16-lane row holds the row's maximum
+    m = wave_max_step<0x142, 0xa>(m);        // row_bcast:15 into rows 1 and 3
+    m = wave_max_step<0x143, 0xc>(m);        // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave's maximum
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, m), 63));
 }
 // largest |value| of this wave's [TM x 64] slice of a tile
 __device__ __forceinline__ float acc_absmax(const f32x16 (&acc)[MT][2]) {
@@ -239,25 +258,9 @@ __device__ __forceinline__ rsrc_t weight_rsrc(const u32x4* wp) {
 struct NoPre { __device__ __forceinline__ void operator()() const {} };
 // LEAN: two weight buffers one chunk ahead instead of four two ahead (32 registers less; the kernels with two saved-tile input
 // streams per epilogue, whose register file is full), `pre` at the top of the last chunk.
-// WPre / gemm_preload (round 5): the weight pieces of a GEMM's FIRST chunks do not depend on the activation image, so a chain requests
-// them BEFORE the image hand-off that precedes the GEMM (two barriers, the tile maximum, 128 piece writes): the L2 latency of a
-// layer's first weight loads -- exposed once per layer and tile until round 4 -- hides behind the hand-off.  Non-LEAN: chunks 0 and 1
-// (32 registers, free at that point: the epilogue's saved-tile slabs are dead); LEAN: chunk 0.
-struct WPre { H2 b0[2], b1[2]; };
-template <bool LEAN>
-__device__ __forceinline__ void gemm_preload(WPre& w, const u32x4* __restrict__ wp, const int wave, const int lane) {
-    const rsrc_t wr = weight_rsrc(wp);
-    const int woff = ((2 * wave) * 2 * 64 + lane) * 16;
-    DH_UNROLL for (int t = 0; t < 2; ++t)
-        DH_UNROLL for (int p = 0; p < 2; ++p) {
-            w.b0[t].p[p] = __builtin_amdgcn_raw_buffer_load_b128(wr, woff + (t * 2 + p) * 1024, 0, 0);
-            if constexpr (!LEAN) w.b1[t].p[p] = __builtin_amdgcn_raw_buffer_load_b128(wr, woff + (t * 2 + p) * 1024, 8 * 2 * 64 * 16, 0);
-        }
-}
 template <bool LEAN = false, class Pre = NoPre>
 __device__ __forceinline__ void gemm_rows_hp(f32x16 (&acc)[MT][2], const _Float16* img, const int nkc,
-                                             const u32x4* __restrict__ wp, const int wave, const int lane, Pre&& pre = Pre(),
-                                             const WPre* wpre = nullptr) {
+                                             const u32x4* __restrict__ wp, const int wave, const int lane, Pre&& pre = Pre()) {
     static_assert(MT == 2, "");
     const _Float16* xrow = img + (lane & 31) * LDH + 8 * (lane >> 5);
     const rsrc_t wr = weight_rsrc(wp);
@@ -275,8 +278,7 @@ __device__ __forceinline__ void gemm_rows_hp(f32x16 (&acc)[MT][2], const _Float1
     H2 a0[MT], a1[MT];
     if constexpr (LEAN) {
         H2 b0[2], b1[2];
-        if (wpre) { b0[0] = wpre->b0[0]; b0[1] = wpre->b0[1]; } else loadb(b0, 0);
-        loada(a0, 0);
+        loadb(b0, 0); loada(a0, 0);
         _Pragma("unroll 1") for (int kc = 0; kc < nkc; kc += 2) {
             loadb(b1, kc + 1); loada(a1, kc + 1);
             __builtin_amdgcn_sched_barrier(0);
@@ -321,9 +323,7 @@ __device__ __forceinline__ void gemm_rows_hp(f32x16 (&acc)[MT][2], const _Float1
         mfma_only_h<0, 12>(acc, a1, b3);
         __builtin_amdgcn_sched_barrier(0);
     };
-    if (wpre) { bA[0] = wpre->b0[0]; bA[1] = wpre->b0[1]; bB[0] = wpre->b1[0]; bB[1] = wpre->b1[1]; }
-    else { loadb(bA, 0); loadb(bB, 1); }
-    loada(a0, 0);
+    loadb(bA, 0); loadb(bB, 1); loada(a0, 0);
     int kc = 0;
     _Pragma("unroll 1") for (; kc + 8 <= nkc; kc += 4) {
         step2(kc, bA, bB, bC, bD);
