@@ -189,122 +189,6 @@ __global__ __launch_bounds__(256, 2) void color_fwd_h_kernel(ColHPtrs C, const f
     }
 }
 
-// ------------------------------------------------------------------------------------------------ colour forward, PAIRED groups
-// Round 5.  What the phase stamps of the kernel above say (profiles/r05_chain_phase_stamps.json): of a layer's 25,400 cycles the GEMM
-// takes 14,900 -- 2.4 x its 6,144 MFMA cycles -- because the CU's two workgroups drift in phase and are mostly in their GEMMs at the
-// same time: eight waves then pull 32 KB of weight pieces per k-chunk round from L2, which delivers ~37 B/clk per CU (guide: 66-73 GB/s
-// per CU from the XCD's L2), 885 cycles per round against 768 of matrix time; a workgroup ALONE on the CU runs its GEMM in half of that
-// (stamps of a one-workgroup-per-CU build).  Neither workgroup can see the other, so nothing keeps them apart.
-// Here the two 64-point tiles of a CU belong to ONE workgroup of eight waves: group g (waves 4g .. 4g+3) owns tile 2p + g with its own
-// piece-plane image, aux image and scratch, and the groups run in STATIC anti-phase: time is cut into slots, in every slot one group
-// runs a GEMM while the other runs the epilogue + image hand-off of its previous GEMM, and they swap.  Every slot holds exactly two
-// workgroup barriers for both roles (the hand-off's two; the GEMM role takes its first after 10 of the 16 k-chunks, its second at the
-// end), so the anti-phase cannot drift and no flag is polled.  Per tile and group 10 slots: [previous tile's output stage + this
-// tile's loads] | hand-off | GEMM 0 | E0 | GEMM 1 | E1 | GEMM 2 | E2 | GEMM 3 | E3.
-struct PairGroupLds { _Float16 smain[IMG_H]; float saux[TM * LDA]; HScratch hs; };
-__device__ __forceinline__ rsrc_t tile_rsrc_v(const float* tile, bool valid) {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(tile), 0, valid ? TILE_F * 4 : 0, 0x00020000);
-}
-__global__ __launch_bounds__(512, 1) void color_fwd_h2_kernel(ColHPtrs C, const float* __restrict__ pts, const float* __restrict__ dirs,
-                                                             int n_per_ray, const float* __restrict__ normals,
-                                                             const float* __restrict__ feat, int64_t npts,
-                                                             float* __restrict__ color, float* __restrict__ cact,
-                                                             float* __restrict__ caux, int save, unsigned* __restrict__ absmax) {
-    __shared__ __attribute__((aligned(16))) PairGroupLds grp[2];
-    const int g = __builtin_amdgcn_readfirstlane(threadIdx.x >> 8);
-    const int tid = threadIdx.x & 255, wave = tid >> 6, lane = tid & 63;
-    _Float16* smain = grp[g].smain;
-    float* saux = grp[g].saux;
-    HScratch& hs = grp[g].hs;
-    const int loff = tile_loff(wave, lane);
-    const int64_t ntiles = (npts + TM - 1) / TM, npairs = (ntiles + 1) / 2;
-    hs_init(hs, tid);
-    float winv[4];
-    DH_UNROLL for (int l = 0; l < 4; ++l) winv[l] = winv_from_bits(C.wabs[l]);
-    const int np = (int)((npairs - blockIdx.x + gridDim.x - 1) / gridDim.x);        // tile pairs of this workgroup (grid <= npairs)
-    const int nlocal = 10 * np + 1;                                                   // + the last tile's output stage
-    f32x16 acc[MT][2];
-    acc_zero(acc);
-    TileScale ts = scale_for_max(1.f);
-    int64_t tile = 0;
-    bool valid = false;
-    _Pragma("unroll 1") for (int k = 0; k < nlocal + 1; ++k) {
-        const int s = k - g;                             // group 1 runs one slot behind group 0: opposite roles in every slot
-        if (s < 0 || s >= nlocal) { __syncthreads(); __syncthreads(); continue; }
-        const int ph = s % 10, pi = s / 10;
-        if (ph == 0) {
-            if (pi > 0) {                                // output stage of the tile whose last hand-off just ended
-                const int64_t gp = tile * TM + tid / TPP;
-                DH_UNROLL for (int j = 0; j < 3; ++j) {
-                    const float raw = fmaf(row_dot256_hp(smain, C.w4 + j * 256, tid), ts.inv, C.b4[j]);
-                    if (tid % TPP == 0 && gp < npts) color[gp * 3 + j] = 1.f / (1.f + __expf(-raw));
-                }
-            }
-            __syncthreads();                             // (the image and the aux image of the previous tile are free)
-            if (pi < np) {
-                tile = ((int64_t)blockIdx.x + (int64_t)pi * gridDim.x) * 2 + g;
-                valid = tile < ntiles;
-                if (tid < TM) {                          // (TM == 64: exactly the group's wave 0)
-                    const int64_t gp = tile * TM + tid;
-                    float* row = saux + tid * LDA;
-                    float mx = 1.f;                      // sin / cos of the view embedding
-                    if (gp < npts) {
-                        const int64_t ray = gp / n_per_ray;
-                        DH_UNROLL for (int c = 0; c < 3; ++c) {
-                            const float d = dirs[ray * 3 + c], x = pts[gp * 3 + c], nn = normals[gp * 3 + c];
-                            row[c] = x;
-                            row[3 + c] = d;
-                            DH_UNROLL for (int kk = 0; kk < 4; ++kk) {
-                                float sn, co; sincosf(d * (float)(1 << kk), &sn, &co);
-                                row[6 + 6 * kk + c] = sn;
-                                row[6 + 6 * kk + 3 + c] = co;
-                            }
-                            row[30 + c] = nn;
-                            mx = fmaxf(mx, fmaxf(fabsf(x), fmaxf(fabsf(d), fabsf(nn))));
-                        }
-                    } else {
-                        DH_UNROLL for (int c = 0; c < CAUX; ++c) row[c] = 0.f;
-                    }
-                    DH_UNROLL for (int c = CAUX; c < LDA; ++c) row[c] = 0.f;
-                    mx = wave_max(mx);
-                    if (lane == 0) hs.sred2[0] = mx;
-                }
-                acc_load_native_b(acc, tile_rsrc_v(feat + tile * TILE_F, valid), loff);
-            }
-            __syncthreads();
-        } else if (ph & 1) {
-            // hand-off slots: ph 1 = the loaded feature tile; ph 3, 5, 7, 9 = epilogue of layer l = 0 .. 3, then its hand-off
-            if (ph > 1) {
-                const int l = (ph - 3) >> 1;
-                const float inv = ts.inv * winv[l];
-                const float b0 = C.bias[l][acc_col(wave, 0, lane)], b1 = C.bias[l][acc_col(wave, 1, lane)];
-                acc_map(acc, [&](int, int t, int, float v) { return fmaxf(fmaf(v, inv, t ? b1 : b0), 0.f); });
-                if (save) acc_store_native_b(acc, tile_rsrc_v(cact + ((int64_t)l * ntiles + tile) * TILE_F, valid), loff);
-                ts = lds_handoff(acc, smain, hs, save ? &hs.lmax[l] : nullptr, tid, wave, lane);
-            } else {
-                // the extras [p, embed(view), n] share layer 0's accumulator with feat: one scale for both, from the larger maximum
-                ts = lds_handoff(acc, smain, hs, save ? &hs.lmax[4] : nullptr, tid, wave, lane, 0.f, &hs.sred2[0]);
-                if (save && tid == 0) hs.lmax[5] = fmaxf(hs.lmax[5], hs.sred2[0]);
-                if (save && valid) aux_lds_to_native(saux, caux + tile * AUXT_F, wave, lane);
-            }
-        } else {
-            // GEMM slots: ph 2, 4, 6, 8 = layer 0 .. 3; the slot's first barrier after 10 of the 16 k-chunks
-            const int l = (ph >> 1) - 1;
-            acc_zero(acc);
-            gemm_rows_hp(acc, smain, 10, C.main[l], wave, lane);
-            __syncthreads();
-            gemm_rows_hp(acc, smain + 10 * 16, 6, C.main[l] + 10 * (8 * 2 * 64), wave, lane);
-            if (l == 0) gemm_rows_aux_h(acc, saux, C.aux, wave, lane, ts.S);
-            __syncthreads();
-        }
-    }
-    if (save && absmax) {
-        if (tid < 4) post_class_max(absmax, ABSMAX_CACT + tid, hs.lmax[tid]);
-        if (tid == 4) post_class_max(absmax, ABSMAX_FEAT, hs.lmax[4]);
-        if (tid == 5) post_class_max(absmax, ABSMAX_CAUX, hs.lmax[5]);
-    }
-}
-
 // ------------------------------------------------------------------------------------------------ n = d sdf / d x (reverse chain)
 __global__ __launch_bounds__(256, 2) void sdf_grad_h_kernel(SdfHPtrs P, const float* __restrict__ pts, int64_t npts,
                                                            const float* __restrict__ act, float* __restrict__ asave,
@@ -800,16 +684,6 @@ int launch_sdf_grad_h(const float* packed, const float* pts, int64_t npts, const
 int launch_color_fwd_h(const float* packed, const float* pts, const float* dirs, int n_per_ray, const float* normals,
                        const float* feat, int64_t npts, float* color, float* cact, float* caux, int save, unsigned* absmax,
                        int grid, hipStream_t stream) {
-#ifndef H2_PAIRED_COLOR_FWD
-#define H2_PAIRED_COLOR_FWD 1            // development macro: 0 = the two-workgroups-per-CU kernel of round 4
-#endif
-    if (H2_PAIRED_COLOR_FWD) {
-        const int64_t npairs = ((npts + TM - 1) / TM + 1) / 2;
-        const int wgs = grid / 2 < 1 ? 1 : grid / 2;                     // one 8-wave workgroup per CU
-        hipLaunchKernelGGL(color_fwd_h2_kernel, dim3((unsigned)(npairs < wgs ? npairs : wgs)), dim3(512), 0, stream, make_colh_ptrs(packed),
-                           pts, dirs, n_per_ray, normals, feat, npts, color, cact, caux, save, absmax);
-        return ok();
-    }
     hipLaunchKernelGGL(color_fwd_h_kernel, dim3(grid_for(npts, grid)), dim3(256), 0, stream, make_colh_ptrs(packed), pts, dirs,
                        n_per_ray, normals, feat, npts, color, cact, caux, save, absmax);
     return ok();

@@ -186,14 +186,14 @@ __device__ __forceinline__ void split_step_h(H2 (&a)[MT], const RawA& raw, Split
 }
 
 // ---------------------------------------------------------------- MFMA issue order of one k-chunk
-// the 12 MFMAs of a k-chunk (two m-tiles x two n-tiles x three products) product-major, each at raised wave priority
+// the 12 MFMAs of a k-chunk (two m-tiles x two n-tiles x three products) product-major.  (Rounds 2-4 raised the wave priority around
+// every MFMA -- a gain for the six-product bf16 chains; in the three-product chains it costs 0.5-1 %, and 10 % in a synthetic two-wave
+// loop: scripts/micro/mfma_issue_micro.hip, profiles/r05_ab_chain_experiments.json -- removed in round 5.)
 template <int I>
 __device__ __forceinline__ void mfma_step_h(f32x16 (&acc)[MT][2], const H2 (&a)[MT], const H2 (&b)[2]) {
     constexpr int pa[3] = {0, 1, 0}, pb[3] = {1, 0, 0};                      // mfma3's product order
     constexpr int p = I / (2 * MT), mt = I % (2 * MT), m = mt / 2, t = mt % 2;
-    __builtin_amdgcn_s_setprio(1);
     acc[m][t] = mfma_h(a[m].p[pa[p]], b[t].p[pb[p]], acc[m][t]);
-    __builtin_amdgcn_s_setprio(0);
 }
 template <int I, int N>
 __device__ __forceinline__ void mfma_only_h(f32x16 (&acc)[MT][2], const H2 (&ac)[MT], const H2 (&bc)[2]) {
@@ -219,6 +219,7 @@ __device__ __forceinline__ f32x4 tile_ld(rsrc_t r, int loff, int idx) {
 // immediate-soffset form -- and on gfx950 the store then sends the new values (measured: a tile class wrong by O(1), differently on
 // every run; located with scripts/cmp_libs.py, record in profiles/r04_ab_chain_io.json).
 __device__ __forceinline__ void tile_st(rsrc_t r, int loff, int idx, const f32x4& v) {
+    // (cache policy 2 = nt.  Round 5 re-measured plain write-back / sc1 / sc0 stores: 2 % slower, the tiles evict the weights from L2)
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, loff + idx * 1024, 0, 2);
 }
 __device__ __forceinline__ void acc_store_native_b(const f32x16 (&acc)[MT][2], rsrc_t r, int loff) {

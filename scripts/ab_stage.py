@@ -19,6 +19,7 @@ def main():
     ap.add_argument("--out", type=str, default=None)
     ap.add_argument("--blocks", type=int, default=512, help="workgroups that wrote stamps (a -DDH_GRID_DIV=2 build: 256)")
     ap.add_argument("--stamps", action="store_true", help="the library is a -DDH_STAMPS build: dump per-phase cycle stamps")
+    ap.add_argument("--save0", action="store_true", help="colour forward in forward-only mode (save = 0: no saved-tile stores)")
     ap.add_argument("--stamps-h", action="store_true", help="-DDH_STAMPS build: phase stamps of the two-piece fp16 chains (kernels_mlp_h.hip)")
     args = ap.parse_args()
     from dynhor_amd import _lib
@@ -54,7 +55,7 @@ def main():
     stages = {
         "sdf_forward": lambda: L.dh_sdf_forward(_p(packed), _p(s.pts), P, _p(s.ws), _p(s.sdf), stream),
         "sdf_gradient": lambda: L.dh_sdf_gradient(_p(packed), _p(s.pts), P, _p(s.ws), _p(s.normals), 1, stream),
-        "color_forward": lambda: L.dh_color_forward(_p(packed), _p(s.pts), _p(s.rays_d), s.n, _p(s.normals), P, _p(s.ws), _p(s.colors), 1, stream),
+        "color_forward": lambda: L.dh_color_forward(_p(packed), _p(s.pts), _p(s.rays_d), s.n, _p(s.normals), P, _p(s.ws), _p(s.colors), 0 if args.save0 else 1, stream),
         "color_backward": lambda: L.dh_color_backward(_p(packed), _p(s.colors), _p(cap["d_colors"]), P, _p(s.ws), _p(dn.clone()), stream),
         "sdf_tangent": lambda: L.dh_sdf_tangent(_p(packed), _p(s.pts), _p(dn), P, _p(s.ws), stream),
         "sdf_backward": lambda: L.dh_sdf_backward(_p(packed), _p(cap["d_sdf"]), P, _p(s.ws), stream),

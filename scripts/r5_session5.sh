@@ -16,3 +16,4 @@ for k, v in d["stamps_h"].items():
 print({k: round(v["median_ms"], 3) for k, v in d["stages"].items()})
 PY
 timeout 600 python3 bench.py --steps 100 --no-cpu-baseline --no-secondary > gpurun_out/s5/bench_quick.json 2> gpurun_out/s5/bench_quick.err; head -c 300 gpurun_out/s5/bench_quick.json; echo
+python3 scripts/dbg_dpts.py > gpurun_out/s5/dbg_dpts.log 2>&1; tail -30 gpurun_out/s5/dbg_dpts.log

@@ -42,15 +42,18 @@ def test_ray_gradients_match_oracle(tiny_dataset, normal_w):
     R = ds.R[frame].double().clone().requires_grad_(True)
     # the sample points themselves (the tensor render_core hands to the SDF network, the gradient pass and the colour network): their
     # total adjoint is what the HIP path leaves PER POINT in s.d_pts
-    seen = {}
+    seen = {"on": False}
     def grab(mod, inp):
         if "pts" not in seen:
             seen["pts"] = inp[0]
-            inp[0].retain_grad()
+            # (a tensor hook, gated: retain_grad would also collect the gradient of the inner autograd.grad call that forms the normals)
+            inp[0].register_hook(lambda gr: seen.__setitem__("grad", gr.detach().clone()) if seen["on"] else None)
     hook = o_r.sdf_network.register_forward_pre_hook(grab)
-    _oracle_loss(o_r, o, d, near.double(), far.double(), z.double(), r64, R, car, normal_w).backward()
+    loss64 = _oracle_loss(o_r, o, d, near.double(), far.double(), z.double(), r64, R, car, normal_w)
     hook.remove()
-    pts_ref = seen["pts"].grad.detach().clone()
+    seen["on"] = True
+    loss64.backward()
+    pts_ref = seen["grad"]
     gref = torch.cat([p.grad.reshape(-1) for m in mods for p in m.parameters()])
     for m in mods:
         m.float()
