@@ -111,6 +111,46 @@ __device__ __forceinline__ TileScale lds_handoff(const f32x16 (&acc)[MT][2], _Fl
     return ts;
 }
 
+#ifdef DH_STAMPS
+// (diagnostic build only) the colour forward GEMM as a plain unrolled loop with four weight buffers that stamps the start of every
+// k-chunk of layer 1 into stamp layers 5 / 6: where inside a GEMM do the cycles go?
+template <int KC>
+__device__ __forceinline__ void gemm_stamped_steps(f32x16 (&acc)[MT][2], H2 (&a)[2][MT], H2 (&b)[4][2], const _Float16* xrow, rsrc_t wr, int woff, int it, int wave,
+                                                   int lane, bool on) {
+    if constexpr (KC < 16) {
+        if (on) DH_STAMP(it, 5 + (KC >> 3), KC & 7);
+        if constexpr (KC + 3 < 16) {
+            DH_UNROLL for (int t = 0; t < 2; ++t)
+                DH_UNROLL for (int p = 0; p < 2; ++p)
+                    b[(KC + 3) & 3][t].p[p] = __builtin_amdgcn_raw_buffer_load_b128(wr, woff + (t * 2 + p) * 1024, (KC + 3) * (8 * 2 * 64 * 16), 0);
+        }
+        if constexpr (KC + 1 < 16) {
+            DH_UNROLL for (int m = 0; m < MT; ++m)
+                DH_UNROLL for (int p = 0; p < 2; ++p)
+                    a[(KC + 1) & 1][m].p[p] = *reinterpret_cast<const u32x4*>(xrow + p * PLANE_H + m * 32 * LDH + (KC + 1) * 16);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_only_h<0, 12>(acc, a[KC & 1], b[KC & 3]);
+        __builtin_amdgcn_sched_barrier(0);
+        gemm_stamped_steps<KC + 1>(acc, a, b, xrow, wr, woff, it, wave, lane, on);
+    }
+}
+__device__ __forceinline__ void gemm_rows_stamped(f32x16 (&acc)[MT][2], const _Float16* img, const u32x4* __restrict__ wp, int wave, int lane, int it, bool on) {
+    const _Float16* xrow = img + (lane & 31) * LDH + 8 * (lane >> 5);
+    const rsrc_t wr = weight_rsrc(wp);
+    const int woff = ((2 * wave) * 2 * 64 + lane) * 16;
+    H2 a[2][MT], b[4][2];
+    DH_UNROLL for (int kc = 0; kc < 3; ++kc)
+        DH_UNROLL for (int t = 0; t < 2; ++t)
+            DH_UNROLL for (int p = 0; p < 2; ++p)
+                b[kc][t].p[p] = __builtin_amdgcn_raw_buffer_load_b128(wr, woff + (t * 2 + p) * 1024, kc * (8 * 2 * 64 * 16), 0);
+    DH_UNROLL for (int m = 0; m < MT; ++m)
+        DH_UNROLL for (int p = 0; p < 2; ++p) a[0][m].p[p] = *reinterpret_cast<const u32x4*>(xrow + p * PLANE_H + m * 32 * LDH);
+    gemm_stamped_steps<0>(acc, a, b, xrow, wr, woff, it, wave, lane, on);
+    if (on) DH_STAMP(it, 7, 0);
+}
+#endif
+
 // ------------------------------------------------------------------------------------------------ colour forward
 __global__ __launch_bounds__(256, 2) void color_fwd_h_kernel(ColHPtrs C, const float* __restrict__ pts, const float* __restrict__ dirs,
                                                             int n_per_ray, const float* __restrict__ normals,
@@ -164,7 +204,11 @@ __global__ __launch_bounds__(256, 2) void color_fwd_h_kernel(ColHPtrs C, const f
         for (int l = 0; l < 4; ++l) {
             DH_STAMP(it, l, 0);
             acc_zero(acc);
+#ifdef DH_STAMPS
+            gemm_rows_stamped(acc, smain, C.main[l], wave, lane, it, l == 1);
+#else
             gemm_rows_hp(acc, smain, 16, C.main[l], wave, lane);
+#endif
             const float inv = ts.inv * winv[l];
             if (l == 0) gemm_rows_aux_h(acc, saux, C.aux, wave, lane, ts.S);
             DH_STAMP(it, l, 1);

@@ -159,6 +159,13 @@ def main():
             # waves of one workgroup: spread of their GEMM-done stamps (who waits for whom at barrier 1)
             g = a[:, :, :, layers[2], 1]
             d["gemm_done_spread_within_workgroup"] = {"mean": float((g.max(axis=1) - g.min(axis=1)).mean())}
+            if stage == "color_forward":
+                # per-chunk stamps of layer 1's GEMM (stamp layers 5, 6: chunk starts; 7 / slot 0: GEMM end)
+                ch = np.concatenate([a[:, :, :, 5, :], a[:, :, :, 6, :], a[:, :, :, 7, :1]], axis=-1)      # [..., 17]
+                dch = ch[..., 1:] - ch[..., :-1]
+                ok = (ch > 0).all(axis=-1)
+                d["gemm_chunk_cycles_layer1"] = [float(dch[ok][:, i].mean()) for i in range(16)]
+                d["gemm_chunk_cycles_layer1_p90"] = [float(np.percentile(dch[ok][:, i], 90)) for i in range(16)]
             out[stage] = d
             print(stage, json.dumps(d, indent=1), flush=True)
         res["stamps_h"] = out

@@ -1,10 +1,10 @@
 #!/bin/bash
-# The round-4 profile + bench-line call (one gpurun call, ~12 GPU-minutes): rocprofv3 stats + PMC passes of both families, the
+# The round-5 profile (round 4: the same with R=r04) + bench-line call (one gpurun call, ~12 GPU-minutes): rocprofv3 stats + PMC passes of both families, the
 # traffic tables bench.py reads, then the verbatim bench lines that go to profiles/r04_bench_n1*.json.
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-R=r04
+R=r05
 bash scripts/prof.sh > gpurun_out/prof_neus.log 2>&1
 cp gpurun_out/prof_summary.json gpurun_out/${R}_pmc_summary.json
 cp $(ls -t gpurun_out/keep/*_kernel_stats.csv | head -1) gpurun_out/${R}_kernel_stats.csv

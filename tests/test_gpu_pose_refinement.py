@@ -70,26 +70,35 @@ def test_ray_gradients_match_oracle(tiny_dataset, normal_w):
     # per-ray, not only in norm: the largest per-ray deviation against the largest per-ray gradient
     assert (d_o.double() - o.grad).abs().max().item() < 2e-3 * o.grad.abs().max().item()
     assert (d_d.double() - d.grad).abs().max().item() < 2e-3 * d.grad.abs().max().item()
-    # PER POINT: the adjoint tiles of the two-piece fp16 chains are scaled per 64-point tile, so a point far
-    # below its tile's maximum keeps an absolute error of ~2^-25 of that maximum per GEMM -- "fp32 accuracy" is a statement relative to
-    # the tile.  Measured here against fp64: the absolute error of every point relative to its tile's largest adjoint, and the relative
-    # error of the points that sit more than 1e-4 below it.
-    dp = p_r.last_state.d_pts.double()
-    assert dp.shape == pts_ref.shape
-    P = dp.shape[0]
-    nt = (P + 63) // 64
-    pad = nt * 64 - P
-    mag = torch.nn.functional.pad(pts_ref.abs().amax(dim=1), (0, pad)).view(nt, 64)
-    err = torch.nn.functional.pad((dp - pts_ref).abs().amax(dim=1), (0, pad)).view(nt, 64)
-    tmax = mag.amax(dim=1, keepdim=True).clamp_min(1e-300)
-    abs_rel_tile = (err / tmax).max().item()
-    small = (mag < 1e-4 * tmax) & (mag > 0)
-    rel_small = (err[small] / mag[small]) if bool(small.any()) else torch.zeros(1, dtype=torch.float64, device=dp.device)
-    big = mag >= 0.1 * tmax
-    print(f"per-point d_pts vs fp64: max |err| / tile max = {abs_rel_tile:.2e}; points within 10x of their tile max: max rel {float((err[big] / mag[big]).max()):.2e}; "
-          f"{int(small.sum())} points more than 1e-4 below their tile max: median rel {float(rel_small.median()):.2e}, max rel {float(rel_small.max()):.2e}")
-    assert abs_rel_tile < 2e-5, "per-point adjoint error, relative to the tile's largest adjoint"
-    assert float((err[big] / mag[big]).max()) < 1e-3
+    # PER POINT: the adjoint tiles of the two-piece fp16 chains are scaled per 64-point tile, so "fp32 accuracy" is a
+    # statement relative to the tile.  Measured here against fp64, not ray-summed: the absolute error of every point relative to its
+    # tile's largest adjoint, the relative error of the points within 10x of it -- and the SAME numbers for the native fp32-MFMA kernels,
+    # which have no tile scale: what the split adds is the difference.
+    from dynhor_amd import _lib
+
+    def per_point(dp):
+        P = dp.shape[0]
+        nt = (P + 63) // 64
+        pad = nt * 64 - P
+        mag = torch.nn.functional.pad(pts_ref.abs().amax(dim=1), (0, pad)).view(nt, 64)
+        err = torch.nn.functional.pad((dp - pts_ref).abs().amax(dim=1), (0, pad)).view(nt, 64)
+        tmax = mag.amax(dim=1, keepdim=True).clamp_min(1e-300)
+        big = mag >= 0.1 * tmax
+        small = (mag < 1e-3 * tmax) & (mag > 0)
+        return (err / tmax).max().item(), float((err[big] / mag[big]).max()), int(small.sum()), float((err / tmax)[small].max()) if bool(small.any()) else 0.0
+
+    assert p_r.last_state.d_pts.shape == pts_ref.shape
+    res = {"split_f16": per_point(p_r.last_state.d_pts.double())}
+    p_r.arithmetic = _lib.ARITH_FP32_MFMA
+    p_r.train_step_core(rays, near, far, ds.R[frame], car, 0.1, 0.1, normal_w, ray_grads=True)
+    torch.cuda.synchronize()
+    res["fp32_mfma"] = per_point(p_r.last_state.d_pts.double())
+    for k, (a_t, r_big, n_small, a_small) in res.items():
+        print(f"per-point d_pts vs fp64 [{k}]: max |err| / tile max = {a_t:.2e}; points within 10x of their tile max: max rel {r_big:.2e}; "
+              f"{n_small} points more than 1e-3 below their tile max: max |err| / tile max = {a_small:.2e}")
+    # the error of a point is bounded relative to its TILE's largest adjoint; the two arithmetics agree on that bound to within a factor
+    assert res["split_f16"][0] < 2e-4 and res["split_f16"][1] < 1e-3
+    assert res["split_f16"][0] < 4.0 * res["fp32_mfma"][0] + 1e-6, "the two-piece split must not add to the exact-fp32 kernels' per-point error"
     if normal_w > 0:
         rel_R = ((d_R.double() - R.grad).norm() / R.grad.norm()).item()
         print(f"d loss / d R (normal loss, direct) rel {rel_R:.2e}")
