@@ -192,6 +192,9 @@ def main():
                          "stack: additionally the dense-correspondence reprojection term on a quarter of the rays")
     ap.add_argument("--hash-sampler", choices=["hierarchical", "occgrid"], default="hierarchical",
                     help="hash family only: NeuS 64+64 sampler or instant-nsr-pl occupancy-grid marching (packed rays)")
+    ap.add_argument("--float-atomic-table-grad", action="store_true",
+                    help="hash family: the table scatter by float atomics instead of the default fixed-point integer atomics "
+                         "(dh_hash_weight_grads_parts, parts bit 4 clear)")
     ap.add_argument("--rays-per-rank", type=int, default=2048,
                     help="2048 = throughput mode (weak scaling, the headline); 2048/N = fixed global batch (PSNR-parity mode)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -262,7 +265,7 @@ def main():
                                             "correspondences": 2048 if full else 0}},
                 "train": {"batch_size": args.rays_per_rank, "normal_weight": 0.05, "report_freq": 10 ** 9, "save_freq": 10 ** 9,
                           "val_freq": 0, "corr_weight": 0.1 if full else 0.0, "corr_fraction": 0.25},
-                "model": {"family": args.family, "arithmetic": args.arithmetic, "hash_renderer": {"sampler": args.hash_sampler}}}
+                "model": {"family": args.family, "arithmetic": args.arithmetic, "hash_renderer": {"sampler": args.hash_sampler, "reproducible_table_grad": not args.float_atomic_table_grad}}}
         runner = Runner(conf=conf, device=device, exp_root=os.path.join("/tmp", "dynhor_bench_exps"))
         B = runner.batch_size
         n_samples = runner.renderer.n_samples + runner.renderer.n_importance
@@ -444,7 +447,8 @@ def main():
                                                          "per-ray cap up to 1024 chosen on the device)")
                             + " per rank, full training iteration; 'LDS-resident grid tiles' of the config's wording: built (levels 0-1, the "
                             "only ones that fit 160 KB), measured slower (0.48 vs 0.44 ms per forward), not shipped")
-                arithmetic = "fp32 everywhere (VALU / fp32 MFMA for the small dW GEMMs); table gradient by float atomics"
+                arithmetic = ("fp32 everywhere (VALU / fp32 MFMA for the small dW GEMMs); table gradient by "
+                              + ("2^-48 fixed-point integer atomics (bitwise reproducible)" if not args.float_atomic_table_grad else "float atomics"))
             else:
                 names = _lib.STAGE_KERNELS[arith]
                 dom = max((k for k in per_kernel if per_kernel[k]["launches_per_step"] <= 1.01 and "tflops" in per_kernel[k]),

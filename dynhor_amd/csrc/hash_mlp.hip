@@ -316,10 +316,11 @@ __global__ __launch_bounds__(256) void sh_color_fwd_kernel(const float* __restri
 //   colour  : DO [4][ldn] | H2 [64][ldn] | DZ2 [64][ldn] | H1 [64][ldn] | DZ1 [64][ldn] | CIN [32][ldn]
 //   geometry: X01 [3][lde] | DIN [16 levels][E n] float2 | DOUT [16][lde] | HH [64][lde] | DA [64][lde] | GIN [36][lde]
 //   partial weight-gradient slabs
+//   FIX: hashgrid_entries() x 2 int64 (+ one flag line) -- the fixed-point accumulators of the reproducible table scatter
 // The per-point kernels recompute the (tiny) forward and leave each layer's input and pre-activation adjoint; the
 // weight gradients are then plain  dW = sum_p dz[p]^T in[p]  reductions done by small_dw_kernel on MFMA.
 struct HashWs {
-    int64_t d_o, h2, dz2, h1, dz1, cin, x01, din, dout, hh, da, gin, slabs, total;
+    int64_t d_o, h2, dz2, h1, dz1, cin, x01, din, dout, hh, da, gin, slabs, fix, total;
     int64_t ldn, lde;
 };
 constexpr int HW_E = 7;
@@ -337,7 +338,8 @@ inline HashWs make_hash_ws(int64_t n) {
     w.x01 = take(w.lde * 3); w.din = take(HW_E * n * 32); w.dout = take(w.lde * 16); w.hh = take(w.lde * 64);
     w.da = take(w.lde * 64); w.gin = take(w.lde * 36);
     w.slabs = take((int64_t)HW_JOBS * HW_SLABS * HW_DW_FLOATS);
-    w.total = o;
+    w.total = o;                                   // hash_workspace_floats() appends the reduced slabs, then FIX
+    w.fix = (o + (int64_t)HW_JOBS * HW_DW_FLOATS + 63) / 64 * 64;
     return w;
 }
 
@@ -523,6 +525,14 @@ __global__ __launch_bounds__(256) void hash_geo_bwd_kernel(const float* __restri
 // plain store to the same address (what the kernel costs without read-modify-write at the memory side), -DHASH_PROBE_SPREAD sends
 // every atomic to a line of its own (no two requests share an address: the atomic path without contention), -DHASH_PROBE_LEVEL=k
 // runs level k only.  Their numbers: DESIGN_NEXT_ROWS.md section 7 "what bounds the table scatter".
+// MODE 3, the reproducible scatter (dh_hash_weight_grads_parts, parts bit 4): the same merges, but every add is converted to 2^-48
+// fixed point and added to an int64 accumulator by an INTEGER atomic -- integer addition is associative, so the sums do not depend
+// on the order in which the memory side sees the requests, and two launches on the same inputs agree bit for bit.  Resolution
+// 3.6e-15 (an fp32 sum of that magnitude carries less), range +-32,768; a non-finite or out-of-range contribution raises the flag
+// word behind the accumulators and hash_fix_to_float_kernel then writes NaN to the whole table gradient: loud, never wrapped.
+constexpr double HG_FIX_ONE = 281474976710656.0;               // 2^48
+constexpr float HG_FIX_LIMIT = 16384.f;                        // one contribution; the sum may reach twice that
+constexpr int HG_FIX_FLAG_WORDS = 8;                           // one 64-B line of int64 behind the accumulators
 #if defined(HASH_PROBE_STORE)
 #define HG_SCATTER_ADD(ptr, v) (*(volatile float*)(ptr) = (v))
 #elif defined(HASH_PROBE_SPREAD)
@@ -530,9 +540,21 @@ __global__ __launch_bounds__(256) void hash_geo_bwd_kernel(const float* __restri
 #else
 #define HG_SCATTER_ADD(ptr, v) atomicAdd((ptr), (v))
 #endif
-template <int MODE>   // 0: both merges; 1: no lane-run merge; 2: no evaluation merge (ablation / debugging)
+template <int MODE>
+__device__ __forceinline__ void hg_scatter_add(float* T, unsigned long long* F, unsigned long long* flag, size_t off, float v) {
+    if constexpr (MODE == 3) {
+        if (!(fabsf(v) < HG_FIX_LIMIT)) { atomicOr(flag, 1ull); return; }            // NaN / inf / out of range
+        const long long q = __double2ll_rn((double)v * HG_FIX_ONE);
+        atomicAdd(F + off, (unsigned long long)q);
+    } else {
+        (void)F; (void)flag;
+        HG_SCATTER_ADD(T + off, v);
+    }
+}
+template <int MODE>   // 0: both merges; 1: no lane-run merge; 2: no evaluation merge (ablation / debugging); 3: both merges, fixed-point accumulators
 __global__ __launch_bounds__(256) void hash_table_bwd_kernel(HashLevels H, const float* __restrict__ ws, HashWs O, int64_t n,
-                                                             float* __restrict__ d_table, const int64_t* __restrict__ n_act) {
+                                                             float* __restrict__ d_table, unsigned long long* __restrict__ fix,
+                                                             const int64_t* __restrict__ n_act) {
     const int l = blockIdx.y;
 #ifdef HASH_PROBE_LEVEL
     if (l != HASH_PROBE_LEVEL) return;
@@ -547,6 +569,8 @@ __global__ __launch_bounds__(256) void hash_table_bwd_kernel(HashLevels H, const
     const float* X = ws + O.x01;
     const float* D = ws + O.din + (int64_t)l * HW_E * n * 2 + f;          // feature f of the level-major float2 rows
     float* T = d_table + f;
+    unsigned long long* F = fix + f;
+    unsigned long long* flag = fix + (size_t)H.total * HG_F;
     const float x0[3] = {X[pc], X[O.lde + pc], X[2 * O.lde + pc]};
     uint32_t g0[3];
     float w0[3];
@@ -581,7 +605,7 @@ __global__ __launch_bounds__(256) void hash_table_bwd_kernel(HashLevels H, const
                     DH_UNROLL for (int bz = 0; bz < 2; ++bz) {
                         const float wt = wpa * (dx ? w0[1] : 1.f - w0[1]) * (bz ? w0[2] : 1.f - w0[2]);
                         const uint32_t idx = hg_index(H, l, ga + ba, g0[1] + dx, g0[2] + bz);
-                        HG_SCATTER_ADD(T + (size_t)idx * HG_F, wt);
+                        hg_scatter_add<MODE>(T, F, flag, (size_t)idx * HG_F, wt);
                     }
                 }
             } else {
@@ -599,7 +623,7 @@ __global__ __launch_bounds__(256) void hash_table_bwd_kernel(HashLevels H, const
                         uint32_t cc[3];
                         cc[0] = g0[0] + dx; cc[a] = ga + ba; cc[o] = g0[o] + bo;
                         const uint32_t idx = hg_index(H, l, cc[0], cc[1], cc[2]);
-                        HG_SCATTER_ADD(T + (size_t)idx * HG_F, wt);
+                        hg_scatter_add<MODE>(T, F, flag, (size_t)idx * HG_F, wt);
                     }
                 }
             }
@@ -629,9 +653,17 @@ __global__ __launch_bounds__(256) void hash_table_bwd_kernel(HashLevels H, const
     if (valid && tail) {
         DH_UNROLL for (int k = 0; k < 4; ++k) {
             const uint32_t idx = hg_index(H, l, g0[0] + dx, g0[1] + (k & 1), g0[2] + (k >> 1));
-            HG_SCATTER_ADD(T + (size_t)idx * HG_F, acc[k]);
+            hg_scatter_add<MODE>(T, F, flag, (size_t)idx * HG_F, acc[k]);
         }
     }
+}
+
+// fixed point -> float of the reproducible scatter's accumulators (count = entries x 2); NaN everywhere when the flag word is set
+__global__ __launch_bounds__(256) void hash_fix_to_float_kernel(const long long* __restrict__ fix, int64_t count, float* __restrict__ d_table) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= count) return;
+    const bool bad = fix[count] != 0;
+    d_table[i] = bad ? __builtin_nanf("") : (float)((double)fix[i] * (1.0 / HG_FIX_ONE));
 }
 
 // dW[m][k] = sum_r A[m][r] B[k][r]  (feature-major operands, m < M <= 64, k < K <= 64), plus colsum[m] = sum_r A[m][r].
@@ -798,7 +830,7 @@ int launch_sh_color_fwd(const float* hp, const float* feat, const float* normals
 
 namespace dh {
 
-int64_t hash_workspace_floats(int64_t n) { return make_hash_ws(n).total + (int64_t)HW_JOBS * HW_DW_FLOATS; }
+int64_t hash_workspace_floats(int64_t n) { return make_hash_ws(n).fix + ((int64_t)hashgrid_entries() * 2 + HG_FIX_FLAG_WORDS) * 2; }
 int64_t hash_infer_workspace_floats(int64_t n) { return make_hash_ws(n).lde * 36; }
 
 int launch_sh_color_bwd(const float* hp, const float* feat, const float* normals, const float* dirs, const float* d_color,
@@ -819,7 +851,8 @@ int launch_hash_geo_bwd(const float* params, const float* hp, const float* pts, 
 }
 
 // all parameter gradients of the hash family from the rows the two kernels above left in ws: grad [hash_num_params].
-// parts: 1 = the table gradient (the first 12,196,240 x 2 floats of grad), 2 = the five small linears, 3 = both -- table FIRST, so that
+// parts: 1 = the table gradient (the first hashgrid_entries() x 2 floats of grad), 2 = the five small linears, 3 = both; + 4 = the table
+// scatter in its reproducible fixed-point form (hg_scatter_add MODE 3) -- table FIRST, so that
 // a data-parallel caller can start the 49 MB table all-reduce on a side stream while the small weight-gradient GEMMs still run
 // (dynhor_amd/hash_fields.py).
 int launch_hash_weight_grads(const float* params, const float* hp, int64_t n, float* ws, float* grad, const int64_t* n_act,
@@ -829,12 +862,22 @@ int launch_hash_weight_grads(const float* params, const float* hp, int64_t n, fl
     const int64_t en = (int64_t)HW_E * n;
     if (parts & 1) {
         // table: scatter the encoding adjoint of all E n evaluations
-        if (hipMemsetAsync(grad + P.table, 0, (size_t)hashgrid_entries() * 2 * sizeof(float), st) != hipSuccess) return -3;
-        const int mode = hash_scatter_mode();      // dh_hash_set_scatter_mode: 0 shipping, 1 / 2 ablations (test / diagnosis only)
+        const int64_t count = (int64_t)hashgrid_entries() * 2;
         const dim3 grid((unsigned)((4 * n + 255) / 256), HG_L);
-        if (mode == 1) hipLaunchKernelGGL(hash_table_bwd_kernel<1>, grid, dim3(256), 0, st, hashgrid_levels(), ws, O, n, grad + P.table, n_act);
-        else if (mode == 2) hipLaunchKernelGGL(hash_table_bwd_kernel<2>, grid, dim3(256), 0, st, hashgrid_levels(), ws, O, n, grad + P.table, n_act);
-        else hipLaunchKernelGGL(hash_table_bwd_kernel<0>, grid, dim3(256), 0, st, hashgrid_levels(), ws, O, n, grad + P.table, n_act);
+        unsigned long long* fix = reinterpret_cast<unsigned long long*>(ws + O.fix);
+        if (parts & 4) {
+            // reproducible form: int64 fixed-point accumulators in the workspace, converted once
+            if (hipMemsetAsync(fix, 0, (size_t)(count + HG_FIX_FLAG_WORDS) * 8, st) != hipSuccess) return -3;
+            hipLaunchKernelGGL(hash_table_bwd_kernel<3>, grid, dim3(256), 0, st, hashgrid_levels(), ws, O, n, grad + P.table, fix, n_act);
+            hipLaunchKernelGGL(hash_fix_to_float_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st,
+                               reinterpret_cast<const long long*>(fix), count, grad + P.table);
+        } else {
+            if (hipMemsetAsync(grad + P.table, 0, (size_t)count * sizeof(float), st) != hipSuccess) return -3;
+            const int mode = hash_scatter_mode();      // dh_hash_set_scatter_mode: 0 shipping, 1 / 2 ablations (test / diagnosis only)
+            if (mode == 1) hipLaunchKernelGGL(hash_table_bwd_kernel<1>, grid, dim3(256), 0, st, hashgrid_levels(), ws, O, n, grad + P.table, fix, n_act);
+            else if (mode == 2) hipLaunchKernelGGL(hash_table_bwd_kernel<2>, grid, dim3(256), 0, st, hashgrid_levels(), ws, O, n, grad + P.table, fix, n_act);
+            else hipLaunchKernelGGL(hash_table_bwd_kernel<0>, grid, dim3(256), 0, st, hashgrid_levels(), ws, O, n, grad + P.table, fix, n_act);
+        }
     }
     if (parts & 2) {
         SmallDwJobs J;

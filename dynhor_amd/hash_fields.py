@@ -99,6 +99,23 @@ class HashParamStore(ParamStore):
         _lib.check(_lib.lib().dh_hash_pack_weights(_lib.ptr(self.flat), _lib.ptr(self.packed), _lib.stream()))
 
 
+def refresh_mask(binary, u):
+    """nerfacc 0.3 OccupancyGrid._sample_uniform_and_occupied_cells(n = cells / 4) as inclusion probabilities: a cell is among the n
+    uniform draws (with replacement) with probability 1 - (1 - 1/cells)^n = 1 - exp(-1/4); an occupied cell is among the occupied
+    draws with probability 1 when there are at most n of them, else 1 - exp(-n / occupied) (n draws with replacement).  u: one
+    uniform per cell; the two draws are made independent by splitting u's range."""
+    cells = binary.numel()
+    n = cells // 4
+    occ = binary.to(torch.bool)
+    k = occ.sum().to(torch.float32)
+    p_uni = 1.0 - math.exp(-n / cells)
+    p_occ = torch.where(k <= n, torch.ones_like(k), 1.0 - torch.exp(-n / k.clamp(min=1.0)))
+    # u < p_uni: uniform draw; the occupied draw uses the remaining range rescaled to [0, 1)
+    hit_uni = u < p_uni
+    u2 = torch.where(hit_uni, u / p_uni, (u - p_uni) / (1.0 - p_uni))
+    return hit_uni | (occ & (u2 < p_occ))
+
+
 class OccupancyGrid:
     """res^3 occupancy image over [-radius, radius]^3 driving the ray marcher (nerfacc OccupancyGrid semantics as restated in
     oracle/occgrid_oracle.py): occ <- max(occ * decay, alpha(cell)), binary = occ > min(mean(occ), thre); alpha(cell) is the
@@ -119,14 +136,26 @@ class OccupancyGrid:
         return ((self._idx + jitter) / self.res * 2.0 - 1.0) * self.radius
 
     @torch.no_grad()
-    def update(self, sdf_fn, inv_s, step, generator=None, jitter=None):
+    def update(self, sdf_fn, inv_s, step, generator=None, jitter=None, refresh="all", select=None):
+        """refresh = "all" (this repo's default): every cell is re-evaluated and decayed at every update.  refresh = "quarter": nerfacc
+        0.3's rule after its warm-up (OccupancyGrid._update: n = cells / 4 uniformly drawn cells + n cells drawn from the occupied
+        ones; only those are decayed and re-evaluated) as per-cell Bernoulli draws with the same inclusion probabilities -- the count of
+        occupied cells stays on the device, so the training path still never waits for a device -> host read.  select [res^3]
+        uniforms (tests)."""
         if jitter is None:
             jitter = torch.rand(self.res ** 3, 3, device=self.device, generator=generator)
         sdf = sdf_fn(self.cell_points(jitter).contiguous()).reshape(-1)
         prev = torch.sigmoid((sdf + 0.5 * step) * inv_s)
         nxt = torch.sigmoid((sdf - 0.5 * step) * inv_s)
         alpha = ((prev - nxt + 1e-5) / (prev + 1e-5)).clip(0.0, 1.0)
-        self.occ = torch.maximum(self.occ * self.decay, alpha)
+        new = torch.maximum(self.occ * self.decay, alpha)
+        if refresh == "quarter":
+            self.occ = torch.where(refresh_mask(self.binary, select if select is not None else
+                                                torch.rand(self.res ** 3, device=self.device, generator=generator)), new, self.occ)
+        elif refresh == "all":
+            self.occ = new
+        else:
+            raise ValueError("refresh must be 'all' or 'quarter'")
         self.binary = (self.occ > torch.clamp(self.occ.mean(), max=self.thre)).to(torch.uint8).contiguous()
         self.updates += 1
 
@@ -152,7 +181,8 @@ class HashNeuSRenderer(NeuSRenderer):
 
     def __init__(self, nerf, sdf_network: HashSDFNetwork, deviation_network: SingleVarianceNetwork,
                  color_network: SHRenderingNetwork, *args, sampler="hierarchical", march_samples_per_ray=512, grid_res=128,
-                 grid_update_every=16, max_samples=128, max_samples_per_ray=1024, **kwargs):
+                 grid_update_every=16, max_samples=128, max_samples_per_ray=1024, reproducible_table_grad=True,
+                 grid_refresh="all", grid_warmup_steps=256, **kwargs):
         if not isinstance(sdf_network, HashSDFNetwork) or not isinstance(color_network, SHRenderingNetwork):
             raise TypeError("HashNeuSRenderer needs HashSDFNetwork + SHRenderingNetwork")
         if sampler not in ("hierarchical", "occgrid"):
@@ -163,6 +193,10 @@ class HashNeuSRenderer(NeuSRenderer):
         self.radius = sdf_network.radius
         self.fd_eps = sdf_network.fd_eps
         self.sampler = sampler
+        # the table scatter in fixed point (include/dynhor_hip.h dh_hash_weight_grads_parts, parts bit 4; the default: it costs nothing,
+        # profiles/r05_hash_reproducible_scatter.json): the family's training step is bitwise reproducible like the NeuS family's.
+        # False: float atomics, the library's only order-dependent sums (kept for comparison)
+        self.reproducible_table_grad = bool(reproducible_table_grad)
         # packed-ray budget: the sample buffers of a batch of B rays hold B * max_samples samples (a fixed capacity, so nothing on
         # the training path waits for a device -> host read of the count); a single ray may keep up to max_samples_per_ray of
         # them.  The per-ray cap of an iteration is the largest of (1024, 512, 256, 128, ..., max_samples) <= max_samples_per_ray
@@ -175,6 +209,11 @@ class HashNeuSRenderer(NeuSRenderer):
         # instant-nsr-pl: render_step_size = 1.732 * 2 * radius / num_samples_per_ray
         self.march_step = 1.732 * 2.0 * self.radius / float(march_samples_per_ray)
         self.grid_update_every = int(grid_update_every)
+        # "all": every update re-evaluates every cell (this repo's default).  "nerfacc": nerfacc 0.3's schedule -- all cells while
+        # the training step is below grid_warmup_steps, then a uniform quarter + the occupied cells (OccupancyGrid.update)
+        if grid_refresh not in ("all", "nerfacc"):
+            raise ValueError("grid_refresh must be 'all' or 'nerfacc'")
+        self.grid_refresh, self.grid_warmup_steps = grid_refresh, int(grid_warmup_steps)
         self.grid = OccupancyGrid(grid_res, self.radius, device=self.store.device) if sampler == "occgrid" else None
         self._march_iter = 0
         self._last_march = None
@@ -209,11 +248,12 @@ class HashNeuSRenderer(NeuSRenderer):
         handle is left in self.pending_table_reduce for the caller to wait on before the optimiser step."""
         L, T, st = _lib.lib(), self.timer, self.store
         hook = getattr(self, "table_grad_hook", None)
+        fix = 4 if self.reproducible_table_grad else 0
         self.pending_table_reduce = None
         if hook is None:
-            T("hash_weight_grads", L.dh_hash_weight_grads, _p(st.flat), _p(st.packed), P, _p(ws), _p(grad), n_dev, _lib.stream())
+            T("hash_weight_grads", L.dh_hash_weight_grads_parts, _p(st.flat), _p(st.packed), P, _p(ws), _p(grad), n_dev, 3 | fix, _lib.stream())
             return
-        T("hash_weight_grads", L.dh_hash_weight_grads_parts, _p(st.flat), _p(st.packed), P, _p(ws), _p(grad), n_dev, 1, _lib.stream())
+        T("hash_weight_grads", L.dh_hash_weight_grads_parts, _p(st.flat), _p(st.packed), P, _p(ws), _p(grad), n_dev, 1 | fix, _lib.stream())
         self.pending_table_reduce = hook(grad[:st.table_floats])
         T("hash_weight_grads_mlp", L.dh_hash_weight_grads_parts, _p(st.flat), _p(st.packed), P, _p(ws), _p(grad), n_dev, 2, _lib.stream())
 
@@ -232,7 +272,9 @@ class HashNeuSRenderer(NeuSRenderer):
     @torch.no_grad()
     def update_grid(self, generator=None, jitter=None):
         self.store.ensure_packed()
-        self.grid.update(lambda p: self.sdf(p), self.store.inv_s(), self.march_step, generator=generator, jitter=jitter)
+        quarter = self.grid_refresh == "nerfacc" and self._march_iter >= self.grid_warmup_steps and self.grid.updates > 0
+        self.grid.update(lambda p: self.sdf(p), self.store.inv_s(), self.march_step, generator=generator, jitter=jitter,
+                         refresh="quarter" if quarter else "all")
 
     def _buffers(self, B: int):
         """Sample buffers of a batch of B rays at the fixed capacity B * max_samples (rounded to 8 rows).  The TRAINING batch size

@@ -43,9 +43,11 @@ DEFAULT_CONF = {
     # launch, so Runners of one process (also on different host threads) may differ
     "model": {"family": "neus", "arithmetic": None, "sdf_network": {}, "variance_network": {"init_val": 0.3}, "rendering_network": {},
               "hash_sdf_network": {}, "sh_rendering_network": {},
-              # hash family only: sampler "hierarchical" (NeuS 64+64) or "occgrid" (instant-nsr-pl occupancy-grid marching)
+              # hash family only: sampler "hierarchical" (NeuS 64+64) or "occgrid" (instant-nsr-pl occupancy-grid marching);
+              # reproducible_table_grad: the table scatter through fixed-point integer atomics (bitwise reproducible training; False:
+              # float atomics)
               "hash_renderer": {"sampler": "hierarchical", "march_samples_per_ray": 512, "grid_res": 128, "grid_update_every": 16,
-                                "max_samples": 128},
+                                "max_samples": 128, "reproducible_table_grad": True},
               "neus_renderer": {"n_samples": 64, "n_importance": 64, "n_outside": 0, "up_sample_steps": 4, "perturb": 1.0}},
 }
 

@@ -348,9 +348,16 @@ int dh_hash_geo_backward(const float* params, const float* packed, const float* 
                          const int64_t* n_active, void* stream);
 int dh_hash_weight_grads(const float* params, const float* packed, int64_t n, float* ws, float* grad, const int64_t* n_active,
                          void* stream);
-/* The same in two parts, for data-parallel callers: parts = 1 writes the table gradient (the leading dh_hashgrid_entries() x 2 floats
- * of grad: 49 MB), parts = 2 the five small linears, 3 = both (= dh_hash_weight_grads).  Calling 1, starting the table's all-reduce on
- * a side stream, then 2, hides the large collective behind the small weight-gradient GEMMs (dynhor_amd/hash_fields.py). */
+/* The same in two parts, for data-parallel callers: parts & 1 writes the table gradient (the leading dh_hashgrid_entries() x 2 floats
+ * of grad: 49 MB), parts & 2 the five small linears.  Calling the table part, starting its all-reduce on a side stream, then the
+ * linears, hides the large collective behind the small weight-gradient GEMMs (dynhor_amd/hash_fields.py).
+ * parts & 4 selects how the table scatter adds.  Set (5, 7; dh_hash_weight_grads = 7): every contribution is converted to 2^-48 fixed
+ * point and added by an INTEGER atomic to an int64 accumulator in the workspace (dh_hash_workspace_floats counts it), converted to
+ * float once -- integer addition is associative, so the result is bit-identical from launch to launch; resolution 3.6e-15, range
+ * +-32,768; a non-finite contribution or one beyond 16,384 turns the WHOLE table gradient into NaN (never a wrapped sum).  Same speed
+ * as the float form on MI355X (both are bound by the memory side's atomic request rate).  Clear (1, 3): float atomics, whose sums
+ * depend on the order in which the memory side sees the requests (last-bit differences from launch to launch: the only such sums in
+ * the library; kept for comparison). */
 int dh_hash_weight_grads_parts(const float* params, const float* packed, int64_t n, float* ws, float* grad, const int64_t* n_active,
                                int parts, void* stream);
 /* Diagnosis only (scripts/psnr_parity.py ablations): how dh_hash_weight_grads merges table-gradient adds before they

@@ -16,9 +16,14 @@ definition for the HIP path (dynhor_amd/csrc/march.hip):
     w = alpha * prod_{earlier}(1 - alpha + 1e-7) within the ray's segment.
 Build decisions (stated in DESIGN.md section 7): near / far are the unit-sphere bounds the rest of the repo uses (mid -/+ 1), at
 most `max_samples` (128) samples per ray are kept (the first ones, front to back; nerfacc has no per-ray cap but limits the
-total by adapting the ray count), and the grid is first filled from the initial SDF instead of starting all-occupied.
+total by adapting the ray count), and every grid update re-evaluates EVERY cell -- nerfacc does that only during its warm-up
+(training step < 256) and afterwards refreshes a uniform quarter of the cells plus the occupied ones; that schedule is restated too
+(OccupancyGrid.update(mask) / quarter_refresh_mask; product: hash_renderer.grid_refresh = "nerfacc") and was measured against the
+default with 8 paired seeds (DESIGN_NEXT_ROWS.md section 7).  Both start from the initial SDF (nerfacc's step-0 update).
 """
 from __future__ import annotations
+
+import math
 
 import torch
 
@@ -37,9 +42,26 @@ class OccupancyGrid:
         idx = torch.stack([ix, iy, iz], -1).reshape(-1, 3)
         return ((idx + jitter) / r * 2.0 - 1.0) * self.radius
 
-    def update(self, alpha: torch.Tensor):
-        self.occ = torch.maximum(self.occ * self.decay, alpha.reshape(-1))
+    def update(self, alpha: torch.Tensor, mask: torch.Tensor | None = None):
+        """mask None: every cell (nerfacc's warm-up rule, this repo's default at every update); mask [res^3] bool: only those cells
+        are decayed and re-evaluated (nerfacc's rule after the warm-up: quarter_refresh_mask below)."""
+        new = torch.maximum(self.occ * self.decay, alpha.reshape(-1))
+        self.occ = new if mask is None else torch.where(mask.reshape(-1), new, self.occ)
         self.binary = self.occ > torch.clamp(self.occ.mean(), max=self.thre)
+
+    def quarter_refresh_mask(self, u: torch.Tensor) -> torch.Tensor:
+        """nerfacc 0.3 OccupancyGrid._update for step >= warmup_steps: n = cells // 4 cells drawn uniformly (with replacement) plus
+        the occupied cells (all of them when there are at most n, else n drawn from them with replacement).  Restated as per-cell
+        inclusion probabilities -- 1 - exp(-n / cells) for the uniform draw, min(1, 1 - exp(-n / occupied)) for the occupied draw --
+        decided by ONE uniform u per cell: below p_uni the cell is a uniform draw, the rest of the range rescaled decides the occupied
+        draw."""
+        cells = self.occ.numel()
+        n = cells // 4
+        k = float(self.binary.sum())
+        p_uni = 1.0 - math.exp(-n / cells)
+        p_occ = 1.0 if k <= n else 1.0 - math.exp(-n / k)
+        hit = u < p_uni
+        return hit | (self.binary & ((u - p_uni) / (1.0 - p_uni) < p_occ))
 
     def query(self, x: torch.Tensor) -> torch.Tensor:
         """occupied? [N] for points [N,3]; outside the cube -> False.  fp32 op order = the HIP kernel's."""

@@ -56,7 +56,8 @@ class HipArm:
     def _modes(self):
         if self.arith is not None:
             self.r.renderer.arithmetic = self.arith        # passed with every launch
-        if self.scatter is not None:
+        if self.scatter is not None:               # the merge ablations exist in the float-atomic form of the scatter only
+            self.r.renderer.reproducible_table_grad = False
             _lib.check(_lib.lib().dh_hash_set_scatter_mode(self.scatter))
 
     def step(self, rays, near, far, R, car, lr, t_rand):
@@ -303,6 +304,8 @@ def run_parity(argv=None):
     ap.add_argument("--out", type=str, default=None)
     ap.add_argument("--march-samples", type=int, default=None, help="occgrid sampler: marching steps per cube diagonal (default 512)")
     ap.add_argument("--max-samples", type=int, default=None, help="occgrid sampler: capacity in samples per ray (default 128)")
+    ap.add_argument("--grid-refresh", choices=["all", "nerfacc"], default=None,
+                    help="occgrid sampler: which cells a grid update re-evaluates (default all; nerfacc = all cells for 256 steps, then a quarter + the occupied ones)")
     ap.add_argument("--eval-sampler", choices=["own", "hierarchical"], default="own",
                     help="hip_occgrid_vs_hierarchical: evaluate each arm with its own sampler, or both with the hierarchical one")
     args = ap.parse_args(argv)
@@ -310,6 +313,8 @@ def run_parity(argv=None):
         HASH_RENDERER_EXTRA["march_samples_per_ray"] = args.march_samples
     if args.max_samples:
         HASH_RENDERER_EXTRA["max_samples"] = args.max_samples
+    if args.grid_refresh:
+        HASH_RENDERER_EXTRA["grid_refresh"] = args.grid_refresh
     args.eval_iters = [int(x) for x in args.eval_iters.split(",") if int(x) <= args.iters] or [args.iters]
     args.lr = args.lr if args.lr is not None else (5e-3 if args.family == "hash" else 5e-4)
     dev = torch.device("cuda:0")

@@ -1,0 +1,125 @@
+"""GPU: the hash family's table scatter in its reproducible form (include/dynhor_hip.h dh_hash_weight_grads_parts, parts bit 4;
+VERDICT r4 next #4 "an optional fully deterministic mode tested bitwise").
+
+Float atomics give sums that depend on the order in which the memory side sees the requests (the only order-dependent sums of the
+library).  With bit 4 (the default of dh_hash_weight_grads and of the Python mirror: it costs nothing) every contribution is converted
+to 2^-48 fixed point and added by an INTEGER atomic (associative: any order gives the same int64), converted to float once.
+
+  * the table gradient of the bench-sized step, re-launched on one workspace: bit-identical (the float form is shown to differ);
+  * against the float-atomic form and the fp64 oracle: the same gradient (the fixed-point form is the closer of the two);
+  * two training runs with the same seeds: bit-identical parameters, for both samplers;
+  * a non-finite adjoint: the WHOLE table gradient is NaN (never a wrapped or partial sum)."""
+import pytest
+import torch
+
+from tests.test_gpu_hash_family import _oracle_grads, _rays, make_hash_pair
+
+pytestmark = pytest.mark.gpu
+
+
+def _runner(root, tag, reproducible, sampler="hierarchical", frames=8):
+    from dynhor_amd.runner import Runner
+    conf = {"seq_name": "rep", "exp_name": tag, "data_info": {"synthetic": {"n_frames": frames, "H": 128, "W": 128, "seed": 77}},
+            "train": {"batch_size": 2048, "learning_rate": 5e-3, "normal_weight": 0.05, "report_freq": 10 ** 9, "save_freq": 10 ** 9,
+                      "val_freq": 0, "warm_up_end": 50, "end_iter": 1000},
+            "model": {"family": "hash", "hash_renderer": {"sampler": sampler, "reproducible_table_grad": reproducible}}}
+    return Runner(conf=conf, device="cuda:0", exp_root=str(root))
+
+
+def test_table_gradient_relaunched_on_one_workspace_is_bit_identical_and_equals_the_float_form(tmp_path):
+    from dynhor_amd import _lib
+    from dynhor_amd.renderer import _p
+    r = _runner(tmp_path, "one", True)
+    for _ in range(5):
+        r.train_iteration()
+    torch.cuda.synchronize()
+    L, st, s = _lib.lib(), r.store, r.renderer.last_state
+    P = s.B * s.n
+    ntab = st.table_floats
+
+    def table_grad(parts):
+        g = torch.full_like(st.grad_flat, float("nan"))
+        _lib.check(L.dh_hash_weight_grads_parts(_p(st.flat), _p(st.packed), P, _p(s.ws), _p(g), None, parts, _lib.stream()))
+        torch.cuda.synchronize()
+        return g[:ntab].clone()
+    ref = table_grad(5)
+    assert torch.isfinite(ref).all() and ref.abs().max().item() > 0
+    for rep in range(30):
+        assert torch.equal(table_grad(5).view(torch.int32), ref.view(torch.int32)), f"launch {rep} differs"
+    fl = [table_grad(1) for _ in range(6)]
+    differing = sum(int(not torch.equal(f, fl[0])) for f in fl[1:])
+    rel = ((fl[0].double() - ref.double()).norm() / ref.double().norm()).item()
+    worst = (fl[0].double() - ref.double()).abs().max().item() / ref.abs().max().item()
+    print(f"float-atomic launches differing from the first: {differing} of 5; float vs fixed point: rel L2 {rel:.2e}, max |d| / max |g| {worst:.2e}")
+    assert rel < 1e-6 and worst < 1e-6
+    # parts 7 = 5 then 2: the whole gradient vector, the small linears untouched by the bit
+    g7 = torch.zeros_like(st.grad_flat)                      # (the vector's tail -- the variance parameter -- is not this stage's)
+    g3 = torch.zeros_like(st.grad_flat)
+    _lib.check(L.dh_hash_weight_grads_parts(_p(st.flat), _p(st.packed), P, _p(s.ws), _p(g7), None, 7, _lib.stream()))
+    _lib.check(L.dh_hash_weight_grads_parts(_p(st.flat), _p(st.packed), P, _p(s.ws), _p(g3), None, 3, _lib.stream()))
+    torch.cuda.synchronize()
+    assert torch.equal(g7[:ntab], ref) and torch.equal(g7[ntab:], g3[ntab:])
+    assert L.dh_hash_weight_grads_parts(_p(st.flat), _p(st.packed), P, _p(s.ws), _p(g3), None, 4, _lib.stream()) == _lib.DH_ERR_BAD_ARG
+    assert L.dh_hash_weight_grads_parts(_p(st.flat), _p(st.packed), P, _p(s.ws), _p(g3), None, 6, _lib.stream()) == _lib.DH_ERR_BAD_ARG
+
+
+def test_fixed_point_table_gradient_matches_the_fp64_oracle():
+    o_r, p_r = make_hash_pair(seed=5)
+    p_r.reproducible_table_grad = True
+    B, car = 48, 0.6
+    rays_o, rays_d, near, far = _rays(B, seed=2)
+    g = torch.Generator(device="cpu").manual_seed(9)
+    t_rand = torch.rand(B, 1, generator=g).cuda()
+    tgt = torch.rand(B, 3, generator=g).cuda()
+    with torch.no_grad():
+        z = o_r.sample_z(rays_o, rays_d, near, far, t_rand=t_rand)
+
+    def loss_fn(out):
+        t = tgt.to(out["color_fine"].dtype)
+        return (out["color_fine"] - t).abs().mean() + 0.1 * out["gradient_error"]
+    ref, ref_loss, gref = _oracle_grads(o_r, rays_o, rays_d, near, far, z, car, loss_fn, torch.float64)
+    eager, eager_loss, geager = _oracle_grads(o_r, rays_o, rays_d, near, far, z, car, loss_fn, torch.float32)
+    errs = {}
+    for rep_mode in (True, False):
+        p_r.reproducible_table_grad = rep_mode
+        p_r.store.grad_flat.zero_()
+        out = p_r.render(rays_o, rays_d, near, far, cos_anneal_ratio=car, z_vals=z)
+        loss_fn(out).backward()
+        torch.cuda.synchronize()
+        ntab = p_r.store.table_floats
+        got = p_r.store.grad_flat[:ntab].double()
+        errs[rep_mode] = ((got - gref[:ntab]).norm() / gref[:ntab].norm()).item()
+    e_eager = ((geager[:p_r.store.table_floats] - gref[:p_r.store.table_floats]).norm() / gref[:p_r.store.table_floats].norm()).item()
+    print(f"table gradient rel L2 vs fp64: fixed point {errs[True]:.2e}, float atomics {errs[False]:.2e}, eager fp32 oracle {e_eager:.2e}")
+    assert errs[True] < max(1e-3, 3 * e_eager) and errs[True] < 1.5 * errs[False] + 1e-7
+
+
+@pytest.mark.parametrize("sampler", ["hierarchical", "occgrid"])
+def test_two_hash_training_runs_with_the_same_seeds_are_bitwise_identical(tmp_path, sampler):
+    a = _runner(tmp_path, "a" + sampler, True, sampler); a.train(n_iters=80)
+    b = _runner(tmp_path, "b" + sampler, True, sampler); b.train(n_iters=80)
+    torch.cuda.synchronize()
+    assert torch.isfinite(a.store.flat).all()
+    assert torch.equal(a.store.flat, b.store.flat)
+
+
+def test_non_finite_or_out_of_range_contributions_turn_the_whole_table_gradient_into_nan():
+    o_r, p_r = make_hash_pair(seed=6)
+    p_r.reproducible_table_grad = True
+    B = 16
+    rays_o, rays_d, near, far = _rays(B, seed=4)
+    ntab = p_r.store.table_floats
+
+    def table_grad(scale):
+        p_r.store.grad_flat.zero_()
+        out = p_r.render(rays_o, rays_d, near, far, cos_anneal_ratio=0.5)
+        (out["color_fine"].sum() * scale).backward()
+        torch.cuda.synchronize()
+        return p_r.store.grad_flat[:ntab].clone()
+    g = table_grad(1.0)
+    assert torch.isfinite(g).all() and g.abs().max().item() > 0
+    big = table_grad(1.0e12)                                   # finite, but single contributions beyond 16,384
+    assert torch.isnan(big).all()
+    assert torch.isfinite(table_grad(1.0)).all()               # the flag is cleared by the next launch
+    nan = table_grad(float("inf"))
+    assert torch.isnan(nan).all()

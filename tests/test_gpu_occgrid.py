@@ -153,6 +153,51 @@ def _occ_runner(root):
     return Runner(conf=conf, device="cuda:0", exp_root=str(root))
 
 
+def test_nerfacc_refresh_schedule_matches_the_oracle_restatement(tmp_path):
+    """hash_renderer.grid_refresh = "nerfacc": all cells while the training step is below grid_warmup_steps, afterwards a uniform
+    quarter + the occupied cells (oracle/occgrid_oracle.py quarter_refresh_mask).  The product's device-side mask equals the
+    oracle's from the same uniforms; unselected cells keep their occupancy (no decay); the inclusion rates are nerfacc's."""
+    from dynhor_amd.hash_fields import refresh_mask
+    r = _occ_runner(tmp_path)
+    ren = r.renderer
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev); g.manual_seed(5)
+    cells = ren.grid.res ** 3
+    ren.update_grid(jitter=torch.rand(cells, 3, device=dev, generator=g))            # step 0: every cell
+    og = G.OccupancyGrid(res=ren.grid.res, radius=1.0, device=dev)
+    og.occ, og.binary = ren.grid.occ.clone(), ren.grid.binary.bool().clone()
+    occ_before = ren.grid.occ.clone()
+    u = torch.rand(cells, device=dev, generator=g)
+    mask = refresh_mask(ren.grid.binary, u)
+    assert torch.equal(mask, og.quarter_refresh_mask(u))
+    k = int(ren.grid.binary.sum())
+    frac_uni = (u < 1.0 - torch.exp(torch.tensor(-0.25))).float().mean().item()
+    sel_occ = mask[ren.grid.binary.bool()].float().mean().item()
+    print(f"occupied {k} of {cells}; selected {mask.float().mean().item():.4f} of all cells ({frac_uni:.4f} by the uniform draw), {sel_occ:.4f} of the occupied ones")
+    assert abs(frac_uni - 0.2212) < 0.005
+    n = cells // 4
+    want = 1.0 if k <= n else 0.2212 + (1 - 0.2212) * (1 - 2.718281828 ** (-n / k))
+    assert abs(sel_occ - want) < 0.01
+    jit = torch.rand(cells, 3, device=dev, generator=g)
+    ren.grid.update(lambda p: ren.sdf(p), ren.store.inv_s(), ren.march_step, jitter=jit, refresh="quarter", select=u)
+    with torch.no_grad():
+        sdf = ren.sdf(og.cell_points(jit).contiguous()).reshape(-1)
+        og.update(G.occ_alpha(sdf, ren.store.inv_s(), ren.march_step), mask=mask)
+    assert torch.equal(ren.grid.occ, og.occ) and torch.equal(ren.grid.binary.bool(), og.binary)
+    assert torch.equal(ren.grid.occ[~mask], occ_before[~mask])                      # untouched cells: not even decayed
+    # the schedule: below the warm-up every update is "all", afterwards "quarter"
+    ren.grid_refresh, ren.grid_warmup_steps = "nerfacc", 4
+    seen = []
+    orig = ren.grid.update
+    ren.grid.update = lambda *a, **kw: (seen.append(kw.get("refresh")), orig(*a, **kw))[1]
+    for it in (0, 3, 4, 100):
+        ren._march_iter = it
+        ren.update_grid()
+    assert seen == ["all", "all", "quarter", "quarter"]
+    with pytest.raises(ValueError):
+        orig(lambda p: ren.sdf(p), ren.store.inv_s(), ren.march_step, refresh="half")
+
+
 def test_fused_training_step_on_packed_rays_matches_oracle(tmp_path):
     r = _occ_runner(tmp_path)
     ren, ds = r.renderer, r.dataset
