@@ -425,8 +425,10 @@ def main():
                 roof = {"bound": "hbm", "kernel": kernel + " (+ small_dw_kernel, reductions: one C-ABI stage)", "stage": dom,
                         "achieved": None if phys is None else round(phys / tsec / 1e9, 1), "peak": FLOAT_ATOMIC_PEAK_GBPS, "unit": "GB/s",
                         "frac": round(max(fracs), 4) if fracs else None,
-                        "peak_basis": "physical float-atomic bytes / time against the memory-side float-atomic rate, 1.3 TB/s of added bytes "
-                                      "(guide, Global float atomics); frac = max(that, counter HBM bytes / time / 6.29 TB/s)",
+                        "peak_basis": "physical atomic request bytes (64 B each) / time against the memory-side atomic rate the guide measures "
+                                      "for float atomics, 1.3 TB/s (Global float atomics; the int64 atomics of the fixed-point scatter "
+                                      "run at the same request rate: profiles/r05_hash_reproducible_scatter.json); frac = max(that, "
+                                      "counter HBM bytes / time / 6.29 TB/s)",
                         "frac_atomic": None if f_atomic is None else round(f_atomic, 4),
                         "frac_hbm_counters": None if f_hbm is None else round(f_hbm, 4),
                         "merge_ratio_algorithmic_over_physical_adds": None if phys is None else round(add_bytes / phys, 2),

@@ -134,7 +134,7 @@ STAGE_KERNELS = {
 }
 HASH_STAGE_KERNELS = {"hash_weight_grads": "hash_table_bwd_kernel"}
 # every kernel one C-ABI stage of the hash family launches (scripts/make_traffic_json.py sums their counters)
-HASH_STAGE_LAUNCHES = {"hash_weight_grads": ["small_dw_kernel", "small_dw_reduce_kernel", "hash_fold_kernel", "hash_table_bwd_kernel"]}
+HASH_STAGE_LAUNCHES = {"hash_weight_grads": ["small_dw_kernel", "small_dw_reduce_kernel", "hash_fold_kernel", "hash_table_bwd_kernel", "hash_fix_to_float_kernel"]}
 
 
 def set_arithmetic(mode: int):
