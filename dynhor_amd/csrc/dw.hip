@@ -392,15 +392,26 @@ __device__ __forceinline__ DwScales dw_job_scales(const DwJob& J, const unsigned
     s.poison = absmax[ABSMAX_TAG * ABSMAX_STRIDE] == ABSMAX_TAG_F16 ? 1.f : __builtin_nanf("");
     return s;
 }
+// development switches of the main body (scripts/build_variant.sh; same-box A/Bs in profiles/r05_ab_dw_variants.json)
+#ifdef DW_NO_SETPRIO
+#define DW_PRIO(x)
+#else
+#define DW_PRIO(x) __builtin_amdgcn_s_setprio(x)
+#endif
+#ifdef DW_PLAIN_LOADS
+#define DW_LOAD(p) (*(p))
+#else
+#define DW_LOAD(p) __builtin_nontemporal_load(p)
+#endif
 template <int I, int JB>
 __device__ __forceinline__ void dw_half_steps_h(f32x16 (&acc)[2][4], const H2 (&a)[2], const H2 (&b)[2], H2 (&pc)[MT],
                                                 const RawA& raw, SplitStateH& st) {
     if constexpr (I < 12) {
         constexpr int pa[3] = {0, 1, 0}, pb[3] = {1, 0, 0};
         constexpr int p = I / 4, ii = (I % 4) / 2, j = I % 2;
-        __builtin_amdgcn_s_setprio(1);
+        DW_PRIO(1);
         acc[ii][JB + j] = mfma_h(a[ii].p[pa[p]], b[j].p[pb[p]], acc[ii][JB + j]);
-        __builtin_amdgcn_s_setprio(0);
+        DW_PRIO(0);
         __builtin_amdgcn_sched_barrier(0);
         split_step_h<I, true>(pc, raw, st);
         __builtin_amdgcn_sched_barrier(0);
@@ -436,12 +447,12 @@ __device__ __forceinline__ void dw_body_pieces_h(const DwJob& J, const DwScales&
         }
         const int kq = 2 * ld_kp, m = kq >> 2, r4 = kq & 3;
         const f32x4* ga = reinterpret_cast<const f32x4*>(A + ld_tile * TILE_F) + ((((wave >> 1) * MT + m) * 2 + (wave & 1)) * 4 + r4) * 64 + lane;
-        r.a0 = __builtin_nontemporal_load(ga); r.a1 = __builtin_nontemporal_load(ga + 64);
+        r.a0 = DW_LOAD(ga); r.a1 = DW_LOAD(ga + 64);
         if (has_b) {
             const int bn = (NB == 8) ? wave : (wave & 1);
             const int bi = (NB == 8) ? ((((bn >> 1) * MT + m) * 2 + (bn & 1)) * 4 + r4) : ((m * 2 + bn) * 4 + r4);
             const f32x4* gb = reinterpret_cast<const f32x4*>(Bm + ld_tile * BT) + bi * 64 + lane;
-            r.b0 = __builtin_nontemporal_load(gb); r.b1 = __builtin_nontemporal_load(gb + 64);
+            r.b0 = DW_LOAD(gb); r.b1 = DW_LOAD(gb + 64);
         }
         if (++ld_kp == KQ / 2) {
             ld_kp = 0;

@@ -51,7 +51,10 @@ __global__ __launch_bounds__(256, 2) void agpr_form(const f16x8* in, float* out,
 // (two n-tiles x hi / lo) constant (LDSA) or streamed from global memory two chunks ahead (LDSA_GLB); 12 MFMAs product-major
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 constexpr int LDH = 264, PLANE = 64 * LDH;
-template <bool GLB, bool PRIO = false>
+#ifndef SYNC_EVERY
+#define SYNC_EVERY 16
+#endif
+template <bool GLB, bool PRIO = false, bool L1HIT = false>
 __global__ __launch_bounds__(256, 2) void chunk_like(const f16x8* in, float* out, long long* cyc, int iters, const u32x4* wts) {
     __shared__ __attribute__((aligned(16))) _Float16 img[2 * PLANE];
     for (int i = threadIdx.x; i < 2 * PLANE; i += 256) img[i] = (_Float16)((i * 7 % 13) * 0.01f);
@@ -66,7 +69,7 @@ __global__ __launch_bounds__(256, 2) void chunk_like(const f16x8* in, float* out
         for (int m = 0; m < 2; ++m) for (int p = 0; p < 2; ++p) x[m][p] = *reinterpret_cast<const u32x4*>(xrow + p * PLANE + m * 32 * LDH + (kc & 15) * 16);
     };
     auto loadb = [&](u32x4 (&x)[2][2], int kc) {
-        for (int t = 0; t < 2; ++t) for (int p = 0; p < 2; ++p) x[t][p] = GLB ? wp[(kc & 15) * 1024 + (t * 2 + p) * 64] : wp[(t * 2 + p) * 64];
+        for (int t = 0; t < 2; ++t) for (int p = 0; p < 2; ++p) x[t][p] = GLB ? wp[(L1HIT ? 0 : (kc & 15) * 1024) + (t * 2 + p) * 64] : wp[(t * 2 + p) * 64];
     };
     loadb(b[0], 0); loadb(b[1], 1); loadb(b[2], 2); loada(a[0], 0);
     const long long t0 = __builtin_readcyclecounter();
@@ -97,13 +100,75 @@ __global__ __launch_bounds__(256, 2) void chunk_like(const f16x8* in, float* out
     if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
     (void)in;
 }
-template <bool GLB, bool PRIO = false>
+// two tile groups in ONE 8-wave workgroup, in phase: waves w and w + 4 stream the SAME weight chunk at the same time (SHARE) -- does
+// the CU's vector L1 merge the two requests, so that the weights cross the L2 -> CU path once per 128 points? -- or streams of their
+// own (!SHARE: the two-workgroup case in one workgroup)
+template <bool SHARE, int LAG = 0>
+__global__ __launch_bounds__(512, 1) void chunk_paired(float* out, long long* cyc, int iters, const u32x4* wts) {
+    __shared__ __attribute__((aligned(16))) _Float16 img[2 * PLANE];
+    for (int i = threadIdx.x; i < 2 * PLANE; i += 512) img[i] = (_Float16)((i * 7 % 13) * 0.01f);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = (threadIdx.x >> 6) & 3, grp = threadIdx.x >> 8;
+    const _Float16* xrow = img + (lane & 31) * LDH + 8 * (lane >> 5);
+    const u32x4* wp = wts + (2 * wave) * 2 * 64 + lane + (SHARE ? 0 : grp * 16 * 1024);
+    f32x16 acc[2][2];
+    for (int m = 0; m < 2; ++m) for (int t = 0; t < 2; ++t) for (int r = 0; r < 16; ++r) acc[m][t][r] = 0.f;
+    u32x4 a[2][2][2], b[4][2][2];
+    auto loada = [&](u32x4 (&x)[2][2], int kc) {
+        for (int m = 0; m < 2; ++m) for (int p = 0; p < 2; ++p) x[m][p] = *reinterpret_cast<const u32x4*>(xrow + p * PLANE + m * 32 * LDH + (kc & 15) * 16);
+    };
+    auto loadb = [&](u32x4 (&x)[2][2], int kc) {
+        for (int t = 0; t < 2; ++t) for (int p = 0; p < 2; ++p) x[t][p] = wp[(kc & 15) * 1024 + (t * 2 + p) * 64];
+    };
+    // LAG: group 1 prefetches LAG chunks later than group 0 (3 - LAG chunks ahead), so that its loads find group 0's lines in L1
+    const int ahead = 3 - (grp ? LAG : 0);
+    loadb(b[0], 0); loadb(b[1], 1); loadb(b[2], 2); loada(a[0], 0);
+    const long long t0 = __builtin_readcyclecounter();
+    for (int it = 0; it < iters; it += 4) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (LAG == 0 || grp == 0) loadb(b[(u + 3) & 3], it + u + 3);
+            else loadb(b[(u + 3 - LAG) & 3], it + u + 3 - LAG);
+            loada(a[(u + 1) & 1], it + u + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            constexpr int pa[3] = {0, 1, 0}, pb[3] = {1, 0, 0};
+#pragma unroll
+            for (int pr = 0; pr < 3; ++pr)
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int t = 0; t < 2; ++t)
+                        acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[u & 1][m][pa[pr]]), __builtin_bit_cast(f16x8, b[u & 3][t][pb[pr]]), acc[m][t], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (SYNC_EVERY && (it & (SYNC_EVERY - 1)) == 0) __syncthreads();     // a layer boundary every SYNC_EVERY chunks keeps the groups in phase
+    }
+    const long long t1 = __builtin_readcyclecounter();
+    float s = 0.f;
+    for (int m = 0; m < 2; ++m) for (int t = 0; t < 2; ++t) for (int r = 0; r < 16; ++r) s += acc[m][t][r];
+    out[blockIdx.x * 512 + threadIdx.x] = s;
+    if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
+}
+template <bool SHARE, int LAG = 0>
+static void run_paired(const char* name, int grid) {
+    float* out; long long* cyc; u32x4* wts;
+    hipMalloc(&out, grid * 512 * 4); hipMalloc(&cyc, grid * 8); hipMalloc(&wts, 2 * 16 * 1024 * 16 + 65536);
+    hipMemset(wts, 0, 2 * 16 * 1024 * 16 + 65536);
+    const int iters = 4000;
+    for (int rep = 0; rep < 2; ++rep) { hipLaunchKernelGGL((chunk_paired<SHARE, LAG>), dim3(grid), dim3(512), 0, 0, out, cyc, iters, (const u32x4*)wts); hipDeviceSynchronize(); }
+    std::vector<long long> h(grid);
+    hipMemcpy(h.data(), cyc, grid * 8, hipMemcpyDeviceToHost);
+    double m = 0; for (long long v : h) m += v; m /= grid;
+    printf("%-56s grid %3d: %.1f cycles per MFMA per wave (%.0f per 12-MFMA chunk)\n", name, grid, m / (double)(iters * 12), m / iters);
+    hipFree(out); hipFree(cyc); hipFree(wts);
+}
+template <bool GLB, bool PRIO = false, bool L1HIT = false>
 static void run_chunk(const char* name, int grid) {
     f16x8* in; float* out; long long* cyc; u32x4* wts;
     hipMalloc(&in, 512 * 16); hipMalloc(&out, grid * 256 * 4); hipMalloc(&cyc, grid * 8); hipMalloc(&wts, 16 * 1024 * 16 + 65536);
     hipMemset(wts, 0, 16 * 1024 * 16 + 65536);
     const int iters = 4000;
-    for (int rep = 0; rep < 2; ++rep) { hipLaunchKernelGGL((chunk_like<GLB, PRIO>), dim3(grid), dim3(256), 0, 0, (const f16x8*)in, out, cyc, iters, (const u32x4*)wts); hipDeviceSynchronize(); }
+    for (int rep = 0; rep < 2; ++rep) { hipLaunchKernelGGL((chunk_like<GLB, PRIO, L1HIT>), dim3(grid), dim3(256), 0, 0, (const f16x8*)in, out, cyc, iters, (const u32x4*)wts); hipDeviceSynchronize(); }
     std::vector<long long> h(grid);
     hipMemcpy(h.data(), cyc, grid * 8, hipMemcpyDeviceToHost);
     double m = 0; for (long long v : h) m += v; m /= grid;
@@ -136,5 +201,12 @@ int main() {
     run_chunk<true>("chain chunk: A from LDS, B from L2,   2 waves per SIMD", 512);
     run_chunk<true, true>("the same + s_setprio 1 / 0 around every MFMA, 1 wave", 256);
     run_chunk<true, true>("the same + s_setprio 1 / 0 around every MFMA, 2 waves", 512);
+    run_chunk<true, false, true>("B re-loaded every chunk from ONE 16-KB block (L1 hits), 1 wave", 256);
+    run_chunk<true, false, true>("B re-loaded every chunk from ONE 16-KB block (L1 hits), 2 waves", 512);
+    run_paired<false>("paired groups in one workgroup, streams of their own", 256);
+    run_paired<true>("paired groups in one workgroup, ONE shared stream", 256);
+    run_paired<true, 1>("ONE shared stream, group 1 prefetches 1 chunk later", 256);
+    run_paired<true, 2>("ONE shared stream, group 1 prefetches 2 chunks later", 256);
+    run_paired<false, 2>("streams of their own, group 1 prefetches 2 chunks later", 256);
     return 0;
 }
