@@ -180,12 +180,20 @@ static void run(const char* name, K kern, int grid, int nacc) {
     f16x8* in; float* out; long long* cyc;
     hipMalloc(&in, 512 * 16); hipMalloc(&out, grid * 256 * 4); hipMalloc(&cyc, grid * 8);
     hipMemset(in, 0, 512 * 16);
-    const int iters = 2000;
-    for (int rep = 0; rep < 2; ++rep) { hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, 0, (const f16x8*)in, out, cyc, iters); hipDeviceSynchronize(); }
+    const int iters = 200000;
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    float ms = 0.f;
+    for (int rep = 0; rep < 2; ++rep) {
+        hipEventRecord(e0, 0);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, 0, (const f16x8*)in, out, cyc, iters);
+        hipEventRecord(e1, 0); hipDeviceSynchronize(); hipEventElapsedTime(&ms, e0, e1);
+    }
     std::vector<long long> h(grid);
     hipMemcpy(h.data(), cyc, grid * 8, hipMemcpyDeviceToHost);
     double m = 0; for (long long v : h) m += v; m /= grid;
-    printf("%-56s grid %3d: %.1f cycles per MFMA per wave\n", name, grid, m / (double)(iters * 3 * nacc));
+    // counter ticks of the timed loop / event time of the launch: the rate of the counter __builtin_readcyclecounter reads (a lower
+    // bound: the launch also holds the prologue and the epilogue)
+    printf("%-56s grid %3d: %.1f cycles per MFMA per wave   [%.0f ticks in %.3f ms: counter >= %.2f GHz]\n", name, grid, m / (double)(iters * 3 * nacc), m, ms, m / (ms * 1e6));
     hipFree(in); hipFree(out); hipFree(cyc);
 }
 int main() {
