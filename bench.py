@@ -195,6 +195,8 @@ def main():
     ap.add_argument("--float-atomic-table-grad", action="store_true",
                     help="hash family: the table scatter by float atomics instead of the default fixed-point integer atomics "
                          "(dh_hash_weight_grads_parts, parts bit 4 clear)")
+    ap.add_argument("--serial-weight-grads", action="store_true",
+                    help="DEVELOPMENT, hash family: the table scatter and the small weight-gradient GEMMs on one stream (default: two streams)")
     ap.add_argument("--rays-per-rank", type=int, default=2048,
                     help="2048 = throughput mode (weak scaling, the headline); 2048/N = fixed global batch (PSNR-parity mode)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -267,6 +269,8 @@ def main():
                           "val_freq": 0, "corr_weight": 0.1 if full else 0.0, "corr_fraction": 0.25},
                 "model": {"family": args.family, "arithmetic": args.arithmetic, "hash_renderer": {"sampler": args.hash_sampler, "reproducible_table_grad": not args.float_atomic_table_grad}}}
         runner = Runner(conf=conf, device=device, exp_root=os.path.join("/tmp", "dynhor_bench_exps"))
+        if args.serial_weight_grads:
+            runner.renderer.concurrent_weight_grads = False
         B = runner.batch_size
         n_samples = runner.renderer.n_samples + runner.renderer.n_importance
 
@@ -390,9 +394,10 @@ def main():
                 return None, None
 
             if hash_family:
-                # dominant stage of this family: dh_hash_weight_grads (table-gradient scatter + the five small dW reductions), HBM /
-                # memory-side-atomic bound.  Algorithmic bytes per launch = every add the per-evaluation scatter defines (7
-                # evaluations x 16 levels x 8 corners x 2 features x 4 B per sample) + one read of the dW operands.
+                # dominant stage of this family: the table-gradient scatter of dh_hash_weight_grads_parts (memory-side-atomic bound; the
+                # five small dW reductions of the same entry point run beside it on a second stream: hash_weight_grads_mlp).
+                # Algorithmic bytes per launch = every add the per-evaluation scatter defines (7 evaluations x 16 levels x 8 corners x
+                # 2 features x 4 B per sample); dw_operands = one read of the small GEMMs' operands (the concurrent stage).
                 dom = "hash_weight_grads"
                 Pk = runner.renderer.last_march["samples"] if args.hash_sampler == "occgrid" else P     # packed rays: the last step's count
                 add_bytes = 7 * Pk * 16 * 8 * 2 * 4
@@ -422,7 +427,7 @@ def main():
                 f_atomic = None if phys is None else phys / tsec / 1e9 / FLOAT_ATOMIC_PEAK_GBPS
                 f_hbm = None if traffic is None else traffic / tsec / 1e9 / HBM_ACHIEVABLE_GBPS
                 fracs = [f for f in (f_atomic, f_hbm) if f is not None]
-                roof = {"bound": "hbm", "kernel": kernel + " (+ small_dw_kernel, reductions: one C-ABI stage)", "stage": dom,
+                roof = {"bound": "hbm", "kernel": kernel + " (+ hash_fix_to_float_kernel; small_dw_kernel and its reductions run concurrently on a second stream)", "stage": dom,
                         "achieved": None if phys is None else round(phys / tsec / 1e9, 1), "peak": FLOAT_ATOMIC_PEAK_GBPS, "unit": "GB/s",
                         "frac": round(max(fracs), 4) if fracs else None,
                         "peak_basis": "physical atomic request bytes (64 B each) / time against the memory-side atomic rate the guide measures "
@@ -435,7 +440,7 @@ def main():
                         "traffic": traffic, "traffic_source": tsrc,
                         "physical_atomic_bytes_per_launch": phys,
                         "avg_launch_ms": per_kernel[dom]["ms"],
-                        "algorithmic_bytes": {"scatter_adds": add_bytes, "dw_operands": dw_bytes},
+                        "algorithmic_bytes": {"scatter_adds": add_bytes, "dw_operands_of_the_concurrent_stage": dw_bytes},
                         "algorithmic_adds_GBps": round(add_bytes / tsec / 1e9, 1)}
                 if args.hash_sampler == "occgrid":
                     lm = runner.renderer.last_march

@@ -132,9 +132,12 @@ STAGE_KERNELS = {
                       "sdf_backward": "sdf_bwd_kernel", "sdf_nograd_coarse": "sdf_nograd_kernel",
                       "sdf_nograd_fine": "sdf_nograd_kernel"},
 }
-HASH_STAGE_KERNELS = {"hash_weight_grads": "hash_table_bwd_kernel"}
-# every kernel one C-ABI stage of the hash family launches (scripts/make_traffic_json.py sums their counters)
-HASH_STAGE_LAUNCHES = {"hash_weight_grads": ["small_dw_kernel", "small_dw_reduce_kernel", "hash_fold_kernel", "hash_table_bwd_kernel", "hash_fix_to_float_kernel"]}
+# hash family: dh_hash_weight_grads_parts runs as two timed stages on two streams (hash_fields.HashNeuSRenderer._weight_grads): the table
+# scatter (parts & 1) and the five small linears' weight gradients (parts & 2)
+HASH_STAGE_KERNELS = {"hash_weight_grads": "hash_table_bwd_kernel", "hash_weight_grads_mlp": "small_dw_kernel"}
+# every kernel a stage launches (scripts/make_traffic_json.py sums their counters)
+HASH_STAGE_LAUNCHES = {"hash_weight_grads": ["hash_table_bwd_kernel", "hash_fix_to_float_kernel"],
+                       "hash_weight_grads_mlp": ["small_dw_kernel", "small_dw_reduce_kernel", "hash_fold_kernel"]}
 
 
 def set_arithmetic(mode: int):

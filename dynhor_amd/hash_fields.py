@@ -242,20 +242,32 @@ class HashNeuSRenderer(NeuSRenderer):
           _p(s.colors), _NULLP, _lib.stream())
 
     def _weight_grads(self, P, ws, grad, n_dev):
-        """dh_hash_weight_grads; with a table_grad_hook (the data-parallel Runner's) in two parts: the table gradient first, the hook
-        (an asynchronous all-reduce of that 49 MB slice: it runs on the collective's own stream) issued right behind it, then the five
-        small linears' gradients on the compute stream -- the large collective overlaps them.  The hook's
-        handle is left in self.pending_table_reduce for the caller to wait on before the optimiser step."""
+        """dh_hash_weight_grads_parts in its two parts, CONCURRENTLY: the table scatter (bound by the memory side's atomic request rate:
+        3.8 % of its wave-cycles issue an instruction, a quarter of the HBM rate) on the compute stream, the five small linears'
+        weight-gradient GEMMs (an HBM stream) on a side stream that joins before this returns -- the two read and write disjoint parts
+        of the workspace and of grad (DESIGN_NEXT_ROWS.md section 7).  With a table_grad_hook (the data-parallel Runner's) the hook --
+        an asynchronous all-reduce of the 49 MB table slice, on the collective's own stream -- is issued right behind the scatter and
+        overlaps the rest as well; its handle is left in self.pending_table_reduce for the caller to wait on
+        before the optimiser step.  concurrent_weight_grads = False: one stream, table first (timing comparisons)."""
         L, T, st = _lib.lib(), self.timer, self.store
         hook = getattr(self, "table_grad_hook", None)
         fix = 4 if self.reproducible_table_grad else 0
         self.pending_table_reduce = None
-        if hook is None:
-            T("hash_weight_grads", L.dh_hash_weight_grads_parts, _p(st.flat), _p(st.packed), P, _p(ws), _p(grad), n_dev, 3 | fix, _lib.stream())
-            return
+        side = None
+        if getattr(self, "concurrent_weight_grads", True) and grad.is_cuda:
+            side = getattr(self, "_dw_stream", None)
+            if side is None:
+                side = self._dw_stream = torch.cuda.Stream(device=grad.device)
+            side.wait_stream(torch.cuda.current_stream(grad.device))
+            with torch.cuda.stream(side):
+                T("hash_weight_grads_mlp", L.dh_hash_weight_grads_parts, _p(st.flat), _p(st.packed), P, _p(ws), _p(grad), n_dev, 2, _lib.stream())
         T("hash_weight_grads", L.dh_hash_weight_grads_parts, _p(st.flat), _p(st.packed), P, _p(ws), _p(grad), n_dev, 1 | fix, _lib.stream())
-        self.pending_table_reduce = hook(grad[:st.table_floats])
-        T("hash_weight_grads_mlp", L.dh_hash_weight_grads_parts, _p(st.flat), _p(st.packed), P, _p(ws), _p(grad), n_dev, 2, _lib.stream())
+        if hook is not None:
+            self.pending_table_reduce = hook(grad[:st.table_floats])
+        if side is None:
+            T("hash_weight_grads_mlp", L.dh_hash_weight_grads_parts, _p(st.flat), _p(st.packed), P, _p(ws), _p(grad), n_dev, 2, _lib.stream())
+        else:
+            torch.cuda.current_stream(grad.device).wait_stream(side)
 
     def _net_backward(self, s, d_sdf, d_normals, d_colors, grad):
         L, T, st = _lib.lib(), self.timer, self.store

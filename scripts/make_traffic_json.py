@@ -15,8 +15,8 @@ p = json.load(open(src))
 out = {}
 missing = []
 if len(sys.argv) > 3 and sys.argv[3] == "hash":
-    # hash family (BASELINE.json configs[3]): one C-ABI stage = several kernels (dynhor_amd/_lib.py:HASH_STAGE_LAUNCHES); the
-    # table scatter's WRITE_SIZE is the bytes its float atomics send to memory (exact: one dword per lane, guide section HBM)
+    # hash family (BASELINE.json configs[3]): one timed stage = several kernels (dynhor_amd/_lib.py:HASH_STAGE_LAUNCHES); the
+    # table scatter's WRITE_SIZE is the bytes its atomics send to memory (64-byte requests; exact for one dword per lane, guide section HBM)
     for stage, kerns in _lib.HASH_STAGE_LAUNCHES.items():
         tot, parts = 0.0, {}
         for kern in kerns:
@@ -28,7 +28,8 @@ if len(sys.argv) > 3 and sys.argv[3] == "hash":
             parts[kern] = {"fetch_size_kb_raw": f, "write_size_kb_raw": w, "hbm_bytes_per_launch": f * 1024 * 2 + w * 1024}
             tot += f * 1024 * 2 + w * 1024
         out[stage] = {"kernel": _lib.HASH_STAGE_KERNELS[stage], "kernels": parts, "hbm_bytes_per_launch": tot,
-                      "atomic_bytes_per_launch": parts.get(_lib.HASH_STAGE_KERNELS[stage], {}).get("write_size_kb_raw", 0.0) * 1024,
+                      "atomic_bytes_per_launch": (parts.get(_lib.HASH_STAGE_KERNELS[stage], {}).get("write_size_kb_raw", 0.0) * 1024
+                                                  if stage == "hash_weight_grads" else None),
                       "correction": "FETCH_SIZE x2 (gfx950 16-B/lane streaming reads), WRITE_SIZE x1 (exact for float atomics)"}
     if missing:
         sys.exit(f"stale or incomplete PMC profile: no counters for the shipping kernels {missing}")

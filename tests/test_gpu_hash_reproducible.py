@@ -102,6 +102,18 @@ def test_two_hash_training_runs_with_the_same_seeds_are_bitwise_identical(tmp_pa
     assert torch.equal(a.store.flat, b.store.flat)
 
 
+def test_concurrent_and_serial_weight_gradient_parts_give_identical_parameters(tmp_path):
+    """The table scatter and the small linears' weight-gradient GEMMs run on two streams (HashNeuSRenderer._weight_grads): disjoint
+    outputs, joined before the optimiser -- the same bits as one stream."""
+    a = _runner(tmp_path, "conc", True)
+    b = _runner(tmp_path, "serial", True)
+    b.renderer.concurrent_weight_grads = False
+    a.train(n_iters=40); b.train(n_iters=40)
+    torch.cuda.synchronize()
+    assert getattr(a.renderer, "_dw_stream", None) is not None and getattr(b.renderer, "_dw_stream", None) is None
+    assert torch.equal(a.store.flat, b.store.flat)
+
+
 def test_non_finite_or_out_of_range_contributions_turn_the_whole_table_gradient_into_nan():
     o_r, p_r = make_hash_pair(seed=6)
     p_r.reproducible_table_grad = True
