@@ -62,8 +62,16 @@ static_assert(T_STREAM_STAGES_TRAIN * TArH2::STAGE_BYTES == PACKTH_STREAM_FLOATS
 
 // NSTAGE ring slots / DEPTH k-steps in flight (NSTAGE >= DEPTH + 2: the barrier sits mid-step); STAGES: length of the cyclic
 // weight stream (the no-grad kernel stops before lin8's rows 1..256)
-template <class AR_> struct TCfgNoGrad { using AR = AR_; static constexpr bool TRAIN = false; static constexpr int NSTAGE = 5, DEPTH = 3, STAGES = T_STREAM_STAGES_NOGRAD; };
-template <class AR_> struct TCfgTrain { using AR = AR_; static constexpr bool TRAIN = true; static constexpr int NSTAGE = AR_::H ? 5 : 4, DEPTH = AR_::H ? 3 : 2, STAGES = T_STREAM_STAGES_TRAIN; };
+// (development: -DT_NG_DEPTH / -DT_TR_DEPTH_H re-size the rings of the no-grad kernel / the fp16 training kernel, NSTAGE = DEPTH + 2;
+// profiles/r05_ab_chain_t_ring.txt: depths 2 / 3 / 4 time the same within 1 %)
+#ifndef T_NG_DEPTH
+#define T_NG_DEPTH 3
+#endif
+#ifndef T_TR_DEPTH_H
+#define T_TR_DEPTH_H 3
+#endif
+template <class AR_> struct TCfgNoGrad { using AR = AR_; static constexpr bool TRAIN = false; static constexpr int NSTAGE = AR_::H ? T_NG_DEPTH + 2 : 5, DEPTH = AR_::H ? T_NG_DEPTH : 3, STAGES = T_STREAM_STAGES_NOGRAD; };
+template <class AR_> struct TCfgTrain { using AR = AR_; static constexpr bool TRAIN = true; static constexpr int NSTAGE = AR_::H ? T_TR_DEPTH_H + 2 : 4, DEPTH = AR_::H ? T_TR_DEPTH_H : 2, STAGES = T_STREAM_STAGES_TRAIN; };
 template <class C> constexpr int t_lds_bytes() { return C::NSTAGE * C::AR::STAGE_BYTES + C::AR::BIAS_BYTES + 4 * T_EMB_BYTES + (C::TRAIN ? 4 * T_PATCH_BYTES : 0); }
 
 template <class AR> struct TPieces { u32x4 p[AR::NP]; };      // one k-step of the activation (B) operand

@@ -52,7 +52,12 @@ def main():
     stream = _lib.stream()
     dn = cap["d_normals"]          # colour backward ACCUMULATES into d_normals: give it a scratch copy each time
 
+    # the sampler's no-grad passes at their two sizes: 64 coarse samples per ray, 16 new samples per up-sampling step
+    ng_pts = {"coarse": s.pts[:s.B * 64].contiguous(), "fine": s.pts[:s.B * 16].contiguous()}
+    ng_out = torch.empty(s.B * 64, device=s.pts.device)
     stages = {
+        "sdf_nograd_coarse": lambda: L.dh_sdf_nograd(_p(packed), _p(ng_pts["coarse"]), s.B * 64, _p(ng_out), stream),
+        "sdf_nograd_fine": lambda: L.dh_sdf_nograd(_p(packed), _p(ng_pts["fine"]), s.B * 16, _p(ng_out), stream),
         "sdf_forward": lambda: L.dh_sdf_forward(_p(packed), _p(s.pts), P, _p(s.ws), _p(s.sdf), stream),
         "sdf_gradient": lambda: L.dh_sdf_gradient(_p(packed), _p(s.pts), P, _p(s.ws), _p(s.normals), 1, stream),
         "color_forward": lambda: L.dh_color_forward(_p(packed), _p(s.pts), _p(s.rays_d), s.n, _p(s.normals), P, _p(s.ws), _p(s.colors), 0 if args.save0 else 1, stream),
