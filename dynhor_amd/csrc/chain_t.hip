@@ -86,6 +86,9 @@ struct TEpi { f32x2 x, t, e, u, b, hd; unsigned bias_addr, patch_wr; float isw; 
 // hardware drops the stores), loff = the lane's byte offset in it (its half of the tile and its lane slot)
 struct TSave { f32x4 v[2]; unsigned patch_rd, loff; __amdgpu_buffer_rsrc_t rsrc; };
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t t_tile_rsrc(const void* tile, bool ok, int bytes) {
+#ifdef T_PROBE_DROP_STORES                               // timing probe: zero records, the hardware drops every tile store (same instructions)
+    ok = false;
+#endif
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(tile), 0, ok ? bytes : 0, 0x00020000);
 }
 
@@ -130,7 +133,13 @@ __device__ __forceinline__ float t_lds_read32_w(unsigned addr) {
     return v;
 }
 template <int OFF>
-__device__ __forceinline__ void t_lds_write_b32(unsigned addr, float v) { asm volatile("ds_write_b32 %0, %1 offset:%2" ::"v"(addr), "v"(v), "n"(OFF) : "memory"); }
+__device__ __forceinline__ void t_lds_write_b32(unsigned addr, float v) {
+#ifdef T_PROBE_NO_PATCH_WRITES                           // timing probe (results wrong): the save path without its 16 ds_write_b32 per m-tile
+    asm volatile("" ::"v"(addr), "v"(v));
+#else
+    asm volatile("ds_write_b32 %0, %1 offset:%2" ::"v"(addr), "v"(v), "n"(OFF) : "memory");
+#endif
+}
 // bias pair of (m-tile M, pair J): features 32 M + 8 (J / 2) + 2 (J % 2) + 4 h, +1   (addr carries the row and 16 h)
 template <int M, int J, int ROWOFF = 0>
 __device__ __forceinline__ void t_bias_read(f32x2& dst, unsigned addr) {
@@ -299,7 +308,11 @@ __device__ __forceinline__ void t_group_steps(TAcc& A, const TFrag<typename K::C
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (I == DAI && DA >= 0) { t_ring_issue_one<typename K::C, DA>(R); __builtin_amdgcn_sched_barrier(0); }
         if constexpr (I == 9 && DB >= 0) { t_ring_issue_one<typename K::C, DB>(R); __builtin_amdgcn_sched_barrier(0); }
+#ifdef T_PROBE_NO_SAVE_READS_STORES                      // timing probe: no patch reads, no tile stores in the dealt stream
+        if constexpr (false) {
+#else
         if constexpr (K::C::TRAIN && K::SM >= 0 && I < 4) {
+#endif
             if constexpr (G == 0 && I < 2) { t_lds_read<32 * I>(sv.v[I], sv.patch_rd); __builtin_amdgcn_sched_barrier(0); }
             if constexpr (G == 1 && I < 2) { t_save_store<K::SM, I>(sv); __builtin_amdgcn_sched_barrier(0); }
             if constexpr (G == 1 && I >= 2) { t_lds_read<32 * I>(sv.v[I - 2], sv.patch_rd); __builtin_amdgcn_sched_barrier(0); }
@@ -314,6 +327,19 @@ __device__ __forceinline__ void t_group_steps(TAcc& A, const TFrag<typename K::C
     }
 }
 
+// The wait that ends group G: the fragments read at its start (and the bias pair, the patch float4s) must have landed -- but not the
+// patch WRITES of the pair the group deals (training kernel), which are its youngest LDS operations (micro-steps 8..11 of pair
+// j = 4 EH + G: the deferred pair 0 under pair 1, then the pair's own two) and which nobody reads before several later waits.  LDS
+// operations of a wave complete in order, so a counted lgkmcnt leaves exactly those in flight; waiting for them too (lgkmcnt(0))
+// exposed a write's LDS latency four times per k-step: 0.98 -> 0.70 ms of the training forward in the probe that removed the
+// writes (profiles/r05_chain_t_stamps.json).
+template <class K, int G>
+constexpr int t_late_writes() {
+    constexpr int j = 4 * K::EH + G;
+    return (K::C::TRAIN && K::EM >= 0 && K::EM < T_NM) ? (j == 0 ? 0 : j == 1 ? 4 : 2) : 0;
+}
+template <class K, int G>
+__device__ __forceinline__ void t_group_wait() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(t_late_writes<K, G>()) : "memory"); }
 // one k-step: entering, a0 holds group 0's fragments; leaving, a0 holds group 0 of the NEXT stage of the stream.
 // LDS-DMA pieces of the stage being issued: TArB3 6 per wave and k-step (3, 4 | 5 | barrier | 0, 1 | 2), TArH2 4 (2 | 3 | barrier | 0 | 1)
 template <class K>
@@ -325,12 +351,12 @@ __device__ __forceinline__ void t_kstep(TAcc& A, const TPieces<typename K::C::AR
     t_read_group<AR, 1>(a1, R.rd_addr);
     __builtin_amdgcn_sched_barrier(0);
     t_group_steps<K, 0, B3 ? 3 : 2, B3 ? 4 : -1, 0>(A, a0, b, bn, st, R, sv);        // the second half of the stage begun last k-step
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    t_group_wait<K, 0>();
     __builtin_amdgcn_sched_barrier(0);
     t_read_group<AR, 2>(a0, R.rd_addr);
     __builtin_amdgcn_sched_barrier(0);
     t_group_steps<K, 1, B3 ? 5 : 3, -1, 0>(A, a1, b, bn, st, R, sv);                 // the stage is fully issued
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    t_group_wait<K, 1>();
     __builtin_amdgcn_sched_barrier(0);
     // the NEXT k-step's pieces: this wave's DMAs for it have landed once at most DEPTH-1 younger groups are outstanding (tile
     // stores in flight count too and only make the wait stricter); after the barrier everyone's have, and everyone has left the
@@ -340,13 +366,13 @@ __device__ __forceinline__ void t_kstep(TAcc& A, const TPieces<typename K::C::AR
     t_read_group<AR, 3>(a1, R.rd_addr);
     __builtin_amdgcn_sched_barrier(0);
     t_group_steps<K, 2, 0, B3 ? 1 : -1, 0>(A, a0, b, bn, st, R, sv);                 // a new stage: its slot was freed by the barrier
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    t_group_wait<K, 2>();
     __builtin_amdgcn_sched_barrier(0);
     t_ring_advance_read<C>(R);
     t_read_group<AR, 0>(a0, R.rd_addr);
     __builtin_amdgcn_sched_barrier(0);
     t_group_steps<K, 3, B3 ? 2 : 1, -1, 0>(A, a1, b, bn, st, R, sv);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    t_group_wait<K, 3>();
     __builtin_amdgcn_sched_barrier(0);
 }
 template <class C, int NB>
@@ -559,6 +585,33 @@ __device__ __forceinline__ void t_dump(const TAcc& A, float* dbg, int64_t gp, in
 #define T_DBG_PARAMS
 #endif
 
+// Diagnostic build only (-DDH_STAMPS, scripts/stamps.sh): where a tile's time goes in the register-resident chains.  Stamps of the
+// workgroup's SECOND tile are kept in scalar registers (a store inside the tile loop would count in the ring's vmcnt waits) and
+// written after the loop; T_STAMP2 picks a static slot from the run-time q (a run-time index would send the array to scratch).
+#ifdef DH_STAMPS
+constexpr int T_NSTAMP = 16;
+static __device__ unsigned long long dh_stamps_t[1024 * 4 * T_NSTAMP];
+extern "C" int dh_dev_read_stamps_t(unsigned long long* host, long long n) {
+    const long long total = (long long)(sizeof(dh_stamps_t) / sizeof(unsigned long long));
+    if (n > total) n = total;
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(dh_stamps_t), (size_t)n * sizeof(unsigned long long)) == hipSuccess ? 0 : -3;
+}
+#define T_STAMP(k)                                                                                        \
+    do {                                                                                                  \
+        if (t_it == 1) {                                                                                  \
+            unsigned long long t_;                                                                        \
+            __builtin_amdgcn_sched_barrier(0);                                                            \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                    \
+            __builtin_amdgcn_sched_barrier(0);                                                            \
+            t_ts[k] = t_;                                                                                 \
+        }                                                                                                 \
+    } while (0)
+#define T_STAMP2(k0, k1) do { if (q == 0) T_STAMP(k0); else T_STAMP(k1); } while (0)
+#else
+#define T_STAMP(k) do { } while (0)
+#define T_STAMP2(k0, k1) do { } while (0)
+#endif
+
 // C = TCfgNoGrad: sdf only.  C = TCfgTrain: also the saved tiles of the training forward (act[l] = softplus(lin_l), l = 0..7, feat =
 // lin8 rows 1..256, eaux = the embedding) in the layouts of sdf_fwd_train_kernel (tile.h native tiles of 64 points: a workgroup
 // tile is two of them, waves 0-1 and 2-3).
@@ -611,7 +664,16 @@ __device__ __forceinline__ void sdf_chain_t_body(const void* __restrict__ stream
         const int64_t g0 = (int64_t)blockIdx.x * T_PTS + wave * 32 + p;
         if (g0 < npts) { xn[0] = pts[g0 * 3 + 0]; xn[1] = pts[g0 * 3 + 1]; xn[2] = pts[g0 * 3 + 2]; }
     }
+#ifdef DH_STAMPS
+    unsigned long long t_ts[T_NSTAMP];
+    DH_UNROLL for (int k = 0; k < T_NSTAMP; ++k) t_ts[k] = 0;
+    int t_it = -1;
+#endif
     _Pragma("unroll 1") for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+#ifdef DH_STAMPS
+        ++t_it;
+#endif
+        T_STAMP(0);
         // training kernel: this wave's half (m = wave & 1) of native tile tile64; lane part of every native address
         const int64_t tile64 = 2 * tile + (wave >> 1);
         const char* act_tile = nullptr;                 // act[0]'s native tile; act[l] is l * lstride further
@@ -629,23 +691,28 @@ __device__ __forceinline__ void sdf_chain_t_body(const void* __restrict__ stream
                 t_store_eaux<0>(emb_wave + (4 * h * T_EMB_LD + p) * 4, p, t_tile_rsrc(eaux + tile64 * AUXT_F, tile_ok, AUXT_F * 4), sv.loff);
         }
         __builtin_amdgcn_sched_barrier(0);
+        T_STAMP(1);
         // lin0: 3 k-steps of the embedding into set 0
         t_zero<0>(A);
         t_kstep<TBare<C, 0>>(A, bA[0], bB, st, a0, a1, R, sv);
         t_kstep<TBare<C, 0>>(A, bA[1], bB, st, a0, a1, R, sv);
         t_kstep<TBare<C, 0>>(A, bB[0], bA, st, a0, a1, R, sv);
         T_DUMP(0, 0);
+        T_STAMP(2);
         _Pragma("unroll 1") for (int q = 0; q < 2; ++q) {
             // (the training kernel saves the SOURCE layer of each call: act[4q], act[4q+1], act[4q+2], act[3])
             if constexpr (C::TRAIN) sv.rsrc = t_tile_rsrc(act_tile + (4 * q + 0) * lstride, tile_ok, TILE_F * 4);
             t_layer<C, 1, 8>(A, bA, bB, st, a0, a1, R, sv, bias_base + (4 * q + 0) * 1024, q ? isw[4] : isw[0]);        // lin1 / lin5
             T_DUMP(1, 4 * q + 1);
+            T_STAMP2(3, 7);
             if constexpr (C::TRAIN) sv.rsrc = t_tile_rsrc(act_tile + (4 * q + 1) * lstride, tile_ok, TILE_F * 4);
             t_layer<C, 0, 8>(A, bA, bB, st, a0, a1, R, sv, bias_base + (4 * q + 1) * 1024, q ? isw[5] : isw[1]);        // lin2 / lin6
             T_DUMP(0, 4 * q + 2);
+            T_STAMP2(4, 8);
             if constexpr (C::TRAIN) sv.rsrc = t_tile_rsrc(act_tile + (4 * q + 2) * lstride, tile_ok, TILE_F * 4);
             t_layer<C, 1, 8>(A, bA, bB, st, a0, a1, R, sv, bias_base + (4 * q + 2) * 1024, q ? isw[6] : isw[2]);        // lin3 / lin7
             T_DUMP(1, 4 * q + 3);
+            T_STAMP2(5, 9);
             if (q == 0) {
                 // lin4: 14 k-steps of lin3's output (217 valid features: the packer zeroes the rest), then the embedding again
                 if constexpr (C::TRAIN) sv.rsrc = t_tile_rsrc(act_tile + 3 * lstride, tile_ok, TILE_F * 4);
@@ -662,6 +729,7 @@ __device__ __forceinline__ void sdf_chain_t_body(const void* __restrict__ stream
                 t_kstep<TBare<C, 0>>(A, bA[1], bB, st, a0, a1, R, sv);
                 t_kstep<TBare<C, 0>>(A, bB[0], bA, st, a0, a1, R, sv);
                 T_DUMP(0, 4);
+                T_STAMP(6);
             }
         }
         // lin8 row 0 (the sdf) on softplus(lin7 + bias): per lane 128 features of its point, the two half-waves add up.  The training
@@ -675,15 +743,22 @@ __device__ __forceinline__ void sdf_chain_t_body(const void* __restrict__ stream
             s += __shfl_xor(s, 32);
             if (h == 0 && gp < npts) sdf_out[gp] = s + b8_0[0];
         }
+        T_STAMP(10);
         if constexpr (C::TRAIN) {
             // lin8 rows 1..256 from softplus(lin7 + bias) into set 0 (its epilogue saves act[7]), then the feature tile
             sv.rsrc = t_tile_rsrc(act_tile + 7 * lstride, tile_ok, TILE_F * 4);
             t_layer<C, 0, 8>(A, bA, bB, st, a0, a1, R, sv, bias_base + 7 * 1024, isw[7]);
             sv.rsrc = t_tile_rsrc(feat + tile64 * TILE_F, tile_ok, TILE_F * 4);
             t_store_feat<0>(A, bias_base, st, sv, AR::H ? isw[8] * (1.f / H2_XS) : 1.f);
+            T_STAMP(11);
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the ring runs ahead of the last tile: let its DMAs land before the LDS goes away
+#ifdef DH_STAMPS
+    if (lane == 0 && blockIdx.x < 1024) {
+        DH_UNROLL for (int k = 0; k < T_NSTAMP; ++k) dh_stamps_t[((size_t)blockIdx.x * 4 + wave) * T_NSTAMP + k] = t_ts[k];
+    }
+#endif
     if constexpr (AR::H && C::TRAIN) {
         // the arithmetic tag of this step's scale tables (workspace.h ABSMAX_TAG).  (The RANGE WATCH of this chain's constant
         // activation scale lives in sdf_grad_h_kernel, which reads every activation tile this kernel saves: this kernel has no vector

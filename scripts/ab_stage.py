@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--blocks", type=int, default=512, help="workgroups that wrote stamps (a -DDH_GRID_DIV=2 build: 256)")
     ap.add_argument("--stamps", action="store_true", help="the library is a -DDH_STAMPS build: dump per-phase cycle stamps")
     ap.add_argument("--save0", action="store_true", help="colour forward in forward-only mode (save = 0: no saved-tile stores)")
+    ap.add_argument("--stamps-t", action="store_true", help="-DDH_STAMPS build: per-layer stamps of the register-resident SDF chains (chain_t.hip)")
     ap.add_argument("--stamps-h", action="store_true", help="-DDH_STAMPS build: phase stamps of the two-piece fp16 chains (kernels_mlp_h.hip)")
     args = ap.parse_args()
     from dynhor_amd import _lib
@@ -174,6 +175,32 @@ def main():
             out[stage] = d
             print(stage, json.dumps(d, indent=1), flush=True)
         res["stamps_h"] = out
+    if args.stamps_t:
+        import numpy as np
+        n = 1024 * 4 * 16
+        names = ["embedding", "lin0 (3 k-steps)", "lin1", "lin2", "lin3", "lin4 (14 + 3 k-steps)", "lin5", "lin6", "lin7", "lin8 row 0 + sdf store + next points"]
+        out = {}
+        for stage, last in (("sdf_nograd_coarse", 10), ("sdf_forward", 11)):
+            _lib.check(stages[stage]())
+            torch.cuda.synchronize()
+            buf = (ctypes.c_ulonglong * n)()
+            fn = L.dh_dev_read_stamps_t
+            fn.restype = ctypes.c_int
+            fn.argtypes = [ctypes.c_void_p, ctypes.c_longlong]
+            assert fn(ctypes.cast(buf, ctypes.c_void_p), n) == 0
+            a = np.frombuffer(buf, dtype=np.uint64).reshape(1024, 4, 16).astype(np.float64)
+            a = a[(a[:, :, 0] > 0).all(axis=1)]                       # workgroups that ran a second tile
+            d = {"workgroups": int(a.shape[0])}
+            nm = names + (["lin8 rows 1..256 + feature tile"] if last == 11 else [])
+            for i, k in enumerate(nm):
+                dd = a[:, :, i + 1] - a[:, :, i]
+                d[k] = {"mean": float(dd.mean()), "p10": float(np.percentile(dd, 10)), "p90": float(np.percentile(dd, 90))}
+            tot = a[:, :, last] - a[:, :, 0]
+            d["tile_total"] = {"mean": float(tot.mean()), "p10": float(np.percentile(tot, 10)), "p90": float(np.percentile(tot, 90))}
+            d["per_k_step_in_the_256_wide_layers"] = float(np.mean([d[k]["mean"] for k in ("lin1", "lin2", "lin3", "lin5", "lin6", "lin7")]) / 16.0)
+            out[stage] = d
+            print(stage, json.dumps(d, indent=1), flush=True)
+        res["stamps_t"] = out
     if args.out:
         os.makedirs(os.path.dirname(os.path.join(ROOT, args.out)), exist_ok=True)
         json.dump(res, open(os.path.join(ROOT, args.out), "w"), indent=1)

@@ -28,6 +28,22 @@ def test_scanner_sees_both_hazard_kinds():
     assert scan(clean) == (1, [])
 
 
+def test_scanner_understands_counted_waits():
+    """lgkmcnt(N) completes all but the N youngest LDS operations of the wave (they return in order) -- the training chain leaves its
+    patch writes in flight that way; a scalar memory operation in between makes the count meaningless."""
+    from isa_inflight_check import scan
+    head = ["ds_read_b128 v[10:13], v1", "ds_write_b32 v2, v3", "ds_write_b32 v2, v4 offset:160"]
+    assert scan(head + ["s_waitcnt lgkmcnt(2)", "v_mfma_f32_32x32x16_f16 a[0:15], v[10:13], v[20:23], a[0:15]"])[1] == []
+    late = scan(head + ["s_waitcnt lgkmcnt(3)", "v_mfma_f32_32x32x16_f16 a[0:15], v[10:13], v[20:23], a[0:15]"])[1]
+    assert late and all(f[3] == "read" for f in late)
+    # the read is the YOUNGEST operation: a count of 1 leaves it in flight
+    young = scan(["ds_write_b32 v2, v3", "ds_read_b128 v[10:13], v1", "s_waitcnt lgkmcnt(1)", "v_add_f32 v5, v10, v11"])[1]
+    assert young and all(f[3] == "read" for f in young)
+    smem = scan(head[:1] + ["s_load_dwordx2 s[4:5], s[0:1], 0x0", "ds_write_b32 v2, v3", "s_waitcnt lgkmcnt(1)", "v_add_f32 v5, v10, v11"])[1]
+    assert smem and all(f[3] == "read" for f in smem)
+    assert scan(head[:1] + ["s_load_dwordx2 s[4:5], s[0:1], 0x0", "s_waitcnt lgkmcnt(0)", "v_add_f32 v5, v10, v11"])[1] == []
+
+
 @pytest.mark.skipif(shutil.which("hipcc") is None, reason="hipcc not installed")
 def test_chain_t_listing_is_clean(tmp_path):
     from isa_inflight_check import scan
