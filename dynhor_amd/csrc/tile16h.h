@@ -161,6 +161,9 @@ __device__ __forceinline__ void acc_to_lds_split(const f32x16 (&acc)[MT][2], _Fl
                 _Float16* q = base + ((r & 3) + 8 * (r >> 2)) * LDH;
                 q[0] = hv[0]; q[LDH] = hv[1];
                 q[PLANE_H] = lv[0]; q[PLANE_H + LDH] = lv[1];
+#ifdef H_PROBE_EXTRA_WRITES                              // timing probe (results unchanged): the lo plane's 64 ds_write_b16 per layer issued a second time
+                asm volatile("ds_write_b16 %0, %1 offset:%2\n\tds_write_b16_d16_hi %0, %1 offset:%3" ::"v"((unsigned)(uintptr_t)q), "v"(l), "n"(PLANE_H * 2), "n"((PLANE_H + LDH) * 2) : "memory");
+#endif
             }
         }
 }
