@@ -147,6 +147,10 @@ constexpr int PLANE_H = TM * LDH;        // halves per plane; the image is hi pl
 constexpr int IMG_H = 2 * PLANE_H;
 // accumulators -> scaled, split, into the two planes.  A lane holds 16 rows of ONE column per accumulator: a converted pair is two
 // rows of that column, written as two 16-bit stores per plane (ds_write_b16 / ds_write_b16_d16_hi).
+// (Round 5 built the 32-bit form -- lanes 2i / 2i + 1 trade halves by one DPP exchange + one v_perm_b32 per word, pairs (r, r + 4) so
+// that the even and odd lanes' rows lie 32 banks apart: 64 ds_write_b32 instead of 128 ds_write_b16 per layer, bit-identical planes --
+// and measured it at the same stage times: the 128 extra vector operations cost what the 64 writes save.  Removed;
+// profiles/r05_ab_chain_experiments.json.)
 __device__ __forceinline__ void acc_to_lds_split(const f32x16 (&acc)[MT][2], _Float16* img, int wave, int lane, float S) {
     DH_UNROLL for (int m = 0; m < MT; ++m)
         DH_UNROLL for (int t = 0; t < 2; ++t) {
