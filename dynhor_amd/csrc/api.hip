@@ -115,7 +115,7 @@ int dh_range_words(int64_t* act_max_off, int64_t* tag_off, float* limit) {
     // (absmax is the first block of the workspace: carve_workspace)
     *act_max_off = (int64_t)ABSMAX_ACT * ABSMAX_STRIDE;
     *tag_off = (int64_t)ABSMAX_TAG * ABSMAX_STRIDE;
-    *limit = 65504.f / H2_XS;
+    *limit = H2_RANGE / H2_XS;
     return DH_OK;
 }
 
