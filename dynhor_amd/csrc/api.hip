@@ -547,12 +547,14 @@ int dh_hash_geo_backward(const float* params, const float* packed, const float* 
 int dh_hash_weight_grads(const float* params, const float* packed, int64_t n, float* ws, float* grad, const int64_t* n_active,
                          void* stream) {
     if (n <= 0 || !params || !packed || !ws || !grad || !al16(ws) || (n_active && n % 8)) return DH_ERR_BAD_ARG;
+    if (hash_scatter_mode() != 0) return DH_ERR_BAD_ARG;        // the merge ablations exist for the float-atomic form only (header)
     return launch_hash_weight_grads(params, packed, n, ws, grad, n_active, 7, static_cast<hipStream_t>(stream));
 }
 
 int dh_hash_weight_grads_parts(const float* params, const float* packed, int64_t n, float* ws, float* grad, const int64_t* n_active,
                                int parts, void* stream) {
     if (n <= 0 || !params || !packed || !ws || !grad || !al16(ws) || (n_active && n % 8) || parts < 1 || parts > 7 || parts == 4 || parts == 6) return DH_ERR_BAD_ARG;
+    if ((parts & 4) && hash_scatter_mode() != 0) return DH_ERR_BAD_ARG;      // (as above)
     return launch_hash_weight_grads(params, packed, n, ws, grad, n_active, parts, static_cast<hipStream_t>(stream));
 }
 

@@ -159,6 +159,21 @@ __device__ __forceinline__ void t_bias_read_w(f32x2& dst, unsigned addr) {
 // (16 ln2 / beta) log2(1 + exp2(-|zs| beta log2e / 16)); the accumulator carries 16 S_w (W x), the bias row 16 b.  Split: convert,
 // two residuals, convert.  SAVE: the activation itself (x 1/16, exact) goes to the patch in steps 10 / 11 -- behind the last read
 // of the previous m-tile's patch (group 1, MFMA slots 2-3 = pair 1's steps 4..7); pair 0's waits in hd until pair 1's steps 8 / 9.
+// How many patch writes (ds_write_b32) micro-step s of pair j issues in the SAVE forms -- the ONE table behind both the emitters
+// below and the counted wait that ends a group (t_late_writes / t_group_wait: a hand-copied tally there was ADVICE r5's finding).
+// H: the two-piece fp16 chain (pair 0's two writes deferred to pair 1's steps 8 / 9, a pair's own in steps 10 / 11); B: bf16x3
+// (deferred in steps 4 / 5, own in steps 7 / 8).  The last LDS READ a pair issues is the bias read of step 1: every write comes later.
+constexpr int t_epi_writes_h(int j, int s) { return (s == 8 || s == 9) ? (j == 1) : (s == 10 || s == 11) ? (j > 0) : 0; }
+constexpr int t_epi_writes_b(int j, int s) { return (s == 4 || s == 5) ? (j == 1) : (s == 7 || s == 8) ? (j > 0) : 0; }
+template <bool H>
+constexpr int t_epi_writes(int j, int s) { return H ? t_epi_writes_h(j, s) : t_epi_writes_b(j, s); }
+template <bool H>
+constexpr int t_epi_pair_writes(int j) {                 // all writes of pair j; none may precede the pair's last LDS read (step 1)
+    int n = 0;
+    for (int s = 2; s < 12; ++s) n += t_epi_writes<H>(j, s);
+    return n;
+}
+static_assert(t_epi_writes<true>(1, 0) + t_epi_writes<true>(1, 1) + t_epi_writes<false>(1, 0) + t_epi_writes<false>(1, 1) == 0, "a patch write before the bias read");
 template <int M, int STEP, bool NEXT, bool SAVE>
 __device__ __forceinline__ void t_epi_step_h(const f32x16& x, TPieces<TArH2> (&out)[2], TEpi& st) {
     constexpr int j = STEP / 12, s = STEP % 12, half = j / 4, q = j % 4, r0 = 2 * j;
@@ -178,20 +193,20 @@ __device__ __forceinline__ void t_epi_step_h(const f32x16& x, TPieces<TArH2> (&o
     else if constexpr (s == 7) { st.x[0] = fmaf(st.e[0], C7, st.t[0]); st.x[1] = fmaf(st.e[1], C7, st.t[1]); }
     else if constexpr (s == 8) {
         const unsigned h = pack_f16x2(st.x); out[half].p[0][q] = h; st.u = resid_f16x2(st.x, h);
-        if constexpr (SAVE && j == 1) t_lds_write_b32<0>(st.patch_wr, st.hd[0]);                    // pair 0's, deferred
+        if constexpr (SAVE && t_epi_writes_h(j, s)) t_lds_write_b32<0>(st.patch_wr, st.hd[0]);       // pair 0's, deferred
     }
     else if constexpr (s == 9) {
         out[half].p[1][q] = pack_f16x2(st.u);
-        if constexpr (SAVE && j == 1) t_lds_write_b32<T_PATCH_LD * 4>(st.patch_wr, st.hd[1]);
+        if constexpr (SAVE && t_epi_writes_h(j, s)) t_lds_write_b32<T_PATCH_LD * 4>(st.patch_wr, st.hd[1]);
     }
     else if constexpr (s == 10) {
         if constexpr (SAVE) {
             st.t[0] = st.x[0] * (1.f / H2_XS); st.t[1] = st.x[1] * (1.f / H2_XS);
-            if constexpr (j == 0) st.hd = st.t;
+            if constexpr (!t_epi_writes_h(j, s)) st.hd = st.t;
             else t_lds_write_b32<PW>(st.patch_wr, st.t[0]);
         }
     }
-    else { if constexpr (SAVE && j > 0) t_lds_write_b32<PW + T_PATCH_LD * 4>(st.patch_wr, st.t[1]); }
+    else { if constexpr (SAVE && t_epi_writes_h(j, s)) t_lds_write_b32<PW + T_PATCH_LD * 4>(st.patch_wr, st.t[1]); }
 }
 template <class AR, int M, int STEP, bool NEXT, bool SAVE>
 __device__ __forceinline__ void t_epi_step(const f32x16& x, TPieces<AR> (&out)[2], TEpi& st) {
@@ -208,22 +223,22 @@ __device__ __forceinline__ void t_epi_step(const f32x16& x, TPieces<AR> (&out)[2
     else if constexpr (s == 3) { st.e[0] = __builtin_amdgcn_exp2f(st.t[0]); st.e[1] = __builtin_amdgcn_exp2f(st.t[1]); }
     else if constexpr (s == 4) {
         st.e[0] = 1.f + st.e[0]; st.e[1] = 1.f + st.e[1];
-        if constexpr (SAVE && j == 1) t_lds_write_b32<0>(st.patch_wr, st.hd[0]);                    // pair 0's, deferred (below)
+        if constexpr (SAVE && t_epi_writes_b(j, s)) t_lds_write_b32<0>(st.patch_wr, st.hd[0]);       // pair 0's, deferred (below)
     }
     else if constexpr (s == 5) {
         st.e[0] = __builtin_amdgcn_logf(st.e[0]); st.e[1] = __builtin_amdgcn_logf(st.e[1]);
-        if constexpr (SAVE && j == 1) t_lds_write_b32<T_PATCH_LD * 4>(st.patch_wr, st.hd[1]);
+        if constexpr (SAVE && t_epi_writes_b(j, s)) t_lds_write_b32<T_PATCH_LD * 4>(st.patch_wr, st.hd[1]);
     }
     else if constexpr (s == 6) { st.t[0] = fmaxf(st.x[0], 0.f); st.t[1] = fmaxf(st.x[1], 0.f); }
     else if constexpr (s == 7) {
         st.x[0] = fmaf(st.e[0], 0.69314718055995f / SOFTPLUS_BETA, st.t[0]); st.x[1] = fmaf(st.e[1], 0.69314718055995f / SOFTPLUS_BETA, st.t[1]);
         // pair 0 is finished in group 0 while the PREVIOUS m-tile's patch is still being read (its last two float4 leave in group
         // 1, slots 2-3): pair 0's two values wait in hd until pair 1's steps 4 and 5 (group 1, slots 4-5)
-        if constexpr (SAVE && j == 0) st.hd = st.x;
+        if constexpr (SAVE && !t_epi_writes_b(j, s)) st.hd = st.x;
         else if constexpr (SAVE) t_lds_write_b32<PW>(st.patch_wr, st.x[0]);
     }
     else if constexpr (s == 8) {
-        if constexpr (SAVE && j > 0) t_lds_write_b32<PW + T_PATCH_LD * 4>(st.patch_wr, st.x[1]);
+        if constexpr (SAVE && t_epi_writes_b(j, s)) t_lds_write_b32<PW + T_PATCH_LD * 4>(st.patch_wr, st.x[1]);
         const unsigned h = pack_bf16x2(st.x); out[half].p[0][q] = h; st.u = unpack_bf16x2(h);
     }
     else if constexpr (s == 9) { st.x[0] -= st.u[0]; st.x[1] -= st.u[1]; }
@@ -333,11 +348,14 @@ __device__ __forceinline__ void t_group_steps(TAcc& A, const TFrag<typename K::C
 // operations of a wave complete in order, so a counted lgkmcnt leaves exactly those in flight; waiting for them too (lgkmcnt(0))
 // exposed a write's LDS latency four times per k-step: 0.98 -> 0.70 ms of the training forward in the probe that removed the
 // writes (profiles/r05_chain_t_stamps.json).
+// The count comes from the emitters' own table (t_epi_writes above): group G of half EH deals exactly the 12 micro-steps of pair j.
 template <class K, int G>
 constexpr int t_late_writes() {
     constexpr int j = 4 * K::EH + G;
-    return (K::C::TRAIN && K::EM >= 0 && K::EM < T_NM) ? (j == 0 ? 0 : j == 1 ? 4 : 2) : 0;
+    return (K::C::TRAIN && K::EM >= 0 && K::EM < T_NM) ? t_epi_pair_writes<K::C::AR::H>(j) : 0;
 }
+static_assert(t_epi_pair_writes<true>(0) == 0 && t_epi_pair_writes<true>(1) == 4 && t_epi_pair_writes<true>(5) == 2 &&
+              t_epi_pair_writes<false>(0) == 0 && t_epi_pair_writes<false>(1) == 4 && t_epi_pair_writes<false>(7) == 2, "round 5's tally");
 template <class K, int G>
 __device__ __forceinline__ void t_group_wait() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(t_late_writes<K, G>()) : "memory"); }
 // one k-step: entering, a0 holds group 0's fragments; leaving, a0 holds group 0 of the NEXT stage of the stream.

@@ -551,7 +551,7 @@ __device__ __forceinline__ void dw_body_pieces_h(const DwJob& J, const DwScales&
 
 // The aux jobs (64-wide B operand: jobs 0, 8, 11) in the two-piece arithmetic: wave w owns output rows [32w, 32w+32) x 64 columns
 // (two accumulators), waves 0 / 1 publish the two B tiles.  Two raw register sets alternate with the two piece buffers.
-// DW_AUX_V_*: development variants of scripts/micro/dw_aux_hazard_micro.hip (the irreproducibility hunt).
+// (The hazard hunt's variants of this body -- round 5, DESIGN.md section 4 -- live in scripts/micro/dw_aux_variants.h, not here.)
 __device__ __forceinline__ void dw_body_aux_h(const DwJob& J, const DwScales& sc, int64_t t0, int64_t t1, float* __restrict__ out,
                                               int wave, int lane, char* lds) {
     constexpr int KQ = MT * 4;
@@ -590,63 +590,11 @@ __device__ __forceinline__ void dw_body_aux_h(const DwJob& J, const DwScales& sc
     auto piece = [&](int par, int tile) {
         H2 f;
         const char* base = lds + par * DWH_BUF + tile * DWH_TILE + lane * 16;
-#ifdef DW_AUX_V_VOLATILE_PIECES
-        DH_UNROLL for (int p = 0; p < 2; ++p) f.p[p] = *reinterpret_cast<const volatile u32x4*>(base + p * 1024);
-#else
         DH_UNROLL for (int p = 0; p < 2; ++p) f.p[p] = *reinterpret_cast<const u32x4*>(base + p * 1024);
-#endif
         return f;
     };
     auto scaled_split = [&](const f32x4& x0, const f32x4& x1, float s) {
-#if defined(DW_AUX_V_SCALAR_MUL)
-        // the scale applied by eight single v_mul_f32 (inline asm: the compiler cannot pair them into v_pk_mul_f32)
-        f32x4 m0, m1;
-        DH_UNROLL for (int i = 0; i < 4; ++i) {
-            asm volatile("v_mul_f32 %0, %1, %2" : "=v"(m0[i]) : "v"(x0[i]), "v"(s));
-            asm volatile("v_mul_f32 %0, %1, %2" : "=v"(m1[i]) : "v"(x1[i]), "v"(s));
-        }
-        return split2(m0, m1);
-#elif defined(DW_AUX_V_PK_OPSEL_HI_DWORD) || defined(DW_AUX_V_PK_OPSEL_LO_DWORD)
-        // packed multiplies that broadcast the scale out of ONE dword of an aligned pair through op_sel, the other dword holding a
-        // constant: HI_DWORD = the form hipcc generates in the failing body (op_sel:[0,1]: both results read src1's high dword),
-        // LO_DWORD = its mirror (op_sel_hi:[1,0]: both results read src1's low dword)
-        f32x2 ss;
-#ifdef DW_AUX_V_PK_OPSEL_HI_DWORD
-        ss[0] = 0.f; ss[1] = s;
-#else
-        ss[0] = s; ss[1] = 0.f;
-#endif
-        asm volatile("" : "+v"(ss));
-        f32x4 m0, m1;
-        DH_UNROLL for (int i = 0; i < 2; ++i) {
-            f32x2 a, b, ra, rb;
-            a[0] = x0[2 * i]; a[1] = x0[2 * i + 1]; b[0] = x1[2 * i]; b[1] = x1[2 * i + 1];
-#ifdef DW_AUX_V_PK_OPSEL_HI_DWORD
-            asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1]" : "=v"(ra) : "v"(a), "v"(ss));
-            asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1]" : "=v"(rb) : "v"(b), "v"(ss));
-#else
-            asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(ra) : "v"(a), "v"(ss));
-            asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(rb) : "v"(b), "v"(ss));
-#endif
-            m0[2 * i] = ra[0]; m0[2 * i + 1] = ra[1]; m1[2 * i] = rb[0]; m1[2 * i + 1] = rb[1];
-        }
-        return split2(m0, m1);
-#elif defined(DW_AUX_V_PK_PLAIN)
-        // packed multiplies by a scale held in BOTH halves of an aligned pair: no op_sel
-        f32x2 ss; ss[0] = s; ss[1] = s;
-        asm volatile("" : "+v"(ss));
-        f32x4 m0, m1;
-        DH_UNROLL for (int i = 0; i < 2; ++i) {
-            f32x2 a, b, ra, rb;
-            a[0] = x0[2 * i]; a[1] = x0[2 * i + 1]; b[0] = x1[2 * i]; b[1] = x1[2 * i + 1];
-            asm volatile("v_pk_mul_f32 %0, %1, %2" : "=v"(ra) : "v"(a), "v"(ss));
-            asm volatile("v_pk_mul_f32 %0, %1, %2" : "=v"(rb) : "v"(b), "v"(ss));
-            m0[2 * i] = ra[0]; m0[2 * i + 1] = ra[1]; m1[2 * i] = rb[0]; m1[2 * i + 1] = rb[1];
-        }
-        return split2(m0, m1);
-#else
         return split2(x0 * s, x1 * s);
-#endif
     };
     auto publish_a = [&](const Raw& r, int par) {
         char* base = lds + par * DWH_BUF + lane * 16;
@@ -673,30 +621,11 @@ __device__ __forceinline__ void dw_body_aux_h(const DwJob& J, const DwScales& sc
             const H2 a = piece(par, wave), b0 = piece(par, 8), b1 = piece(par, 9);
             __builtin_amdgcn_sched_barrier(0);
             publish_a(nxt, par ^ 1);
-#ifdef DW_AUX_V_NO_MFMA
-            // no matrix instruction in the step: the "accumulators" take a cheap function of the same pieces on the vector ALU
-            DH_UNROLL for (int r = 0; r < 16; ++r)
-                acc[0][r] += __builtin_bit_cast(float, ((a.p[r & 1][(r >> 1) & 3] ^ b0.p[(r >> 3) & 1][(r >> 1) & 3]) & 0x007fffffu) | 0x3f800000u);
-#else
             acc[0] = mfma3(a, b0, acc[0]);
-#endif
             __builtin_amdgcn_sched_barrier(0);
-#if defined(DW_AUX_V_LGKM_AFTER_A)
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#elif defined(DW_AUX_V_NOP_AFTER_A)
-            asm volatile("s_nop 15\n s_nop 15" ::: "memory");
-#endif
             publish_b(nxt, par ^ 1);
-#ifdef DW_AUX_V_NO_MFMA
-            DH_UNROLL for (int r = 0; r < 16; ++r)
-                acc[1][r] += __builtin_bit_cast(float, ((a.p[r & 1][(r >> 1) & 3] ^ b1.p[(r >> 3) & 1][(r >> 1) & 3]) & 0x007fffffu) | 0x3f800000u);
-#else
             acc[1] = mfma3(a, b1, acc[1]);
-#endif
             __builtin_amdgcn_sched_barrier(0);
-#if defined(DW_AUX_V_LGKM_BEFORE_LOAD)
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#endif
             load(nxt);
             __builtin_amdgcn_sched_barrier(0);
             __syncthreads();
@@ -734,18 +663,11 @@ __global__ __launch_bounds__(512, 1) void dw_f16x2_kernel(DwJobs jobs, DwGroups 
     for (int job = groups.job0[k]; job < groups.job0[k + 1]; ++job) {
         const DwJob J = jobs.j[job];
         const DwScales sc = dw_job_scales(J, absmax, tmax, ntiles);
-        // The three aux jobs (64-wide B: 6 % of the kernel's bytes, a quarter of a main job's MFMAs) run the three-piece bf16 body.
-        // Their two-piece form was NOT bitwise reproducible: about one launch in 5,000 differed from the others in the 16 output
-        // columns 16..31 of ONE workgroup's slab by ~1e-3 of one k-pair's contribution (the size of a lo piece), with every barrier
-        // and wait in place and under every timing / nop / register variant tried (profiles/r04_dw_aux_reproducibility.json); the
-        // -DDW_AUX_PROBE build above traced it to the packed-fp32 scale multiplies of the B-tile publish (in the shadow of the wave's
-        // own dependent MFMAs).  The main jobs' two-piece body and this body are bitwise reproducible over 350,000 launches.
+        // The three aux jobs (64-wide B: 6 % of the kernel's bytes, a quarter of a main job's MFMAs) run their own two-piece body.  (Round 4
+        // ran them on the three-piece bf16 body because the two-piece form differed in one launch out of 5,000; round 5 traced that to
+        // packed-fp32 multiplies under MFMAs -- layout.h -- and the library is built without them: 0 of 299,999 launches differ.)
         if (J.nb == 8) dw_body_pieces_h<8>(J, sc, t0, t1, base + J.off, wave, lane, pieces);
-#ifdef DW_AUX_THREE_PIECE          // (development: round 4's shipping form, the aux jobs on the three-piece bf16 body)
-        else dw_body_pieces<2>(J, t0, t1, base + J.off, wave, lane, pieces);
-#else
         else dw_body_aux_h(J, sc, t0, t1, base + J.off, wave, lane, pieces);
-#endif
     }
 }
 

@@ -27,3 +27,15 @@ def mean_stats(stats: torch.Tensor) -> torch.Tensor:
         dist.all_reduce(s, op=dist.ReduceOp.SUM)
         s /= world
     return s
+
+
+def max_over_ranks(value: float, device=None) -> float:
+    """MAX of one host scalar over ranks (NaN counts as +inf): the range watch of Runner.report -- every rank must see the SAME verdict,
+    or only the overflowing rank raises and the others hang in the next gradient all-reduce until the collective times out."""
+    _, world = world_info()
+    v = float("inf") if value != value else float(value)
+    if world <= 1:
+        return v
+    t = torch.tensor([v], dtype=torch.float32, device=device if device is not None else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())

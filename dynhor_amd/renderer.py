@@ -187,20 +187,34 @@ class NeuSRenderer:
         T("weight_grads_fold", L.dh_weight_grads_fold, _p(st.packed), _p(st.flat), P, _p(s.ws), _p(grad), _lib.stream())
 
     # ------------------------------------------------------------------ range watch of the two-piece fp16 arithmetic
-    def check_range(self, state=None):
-        """The SPLIT_F16 forward chain carries its softplus activations at a constant fp16 scale (overflow beyond 4094:
-        include/dynhor_hip.h dh_range_words); the input-gradient stage posts the largest activation of the step into the workspace.
-        ONE device read: call at report iterations, not per step.  Returns (max activation, limit) of the last forward, raises
-        DynhorHipError beyond the limit (the step's results are NaN there): switch to arithmetic 'split_bf16', which has no limit."""
+    def range_status(self, state=None):
+        """(max softplus activation of the last SPLIT_F16 forward, limit) -- ONE device read, nothing raised; None for the other
+        arithmetics (no limit) or before the first step."""
         s = state if state is not None else getattr(self, "last_state", None)
         if s is None or getattr(s, "arith", None) != _lib.ARITH_SPLIT_F16:
             return None
         a, _, lim = _lib.range_words()
-        m = float(s.ws[a])
-        if not m < lim:                                    # (NaN compares false)
+        return float(s.ws[a]), lim
+
+    def check_range(self, state=None, max_over_ranks=None):
+        """The SPLIT_F16 forward chain carries its softplus activations at a constant fp16 scale (overflow beyond 4094:
+        include/dynhor_hip.h dh_range_words); the input-gradient stage posts the largest activation of the step into the workspace.
+        ONE device read: call at report iterations, not per step.  Returns (max activation, limit) of the last forward, raises
+        DynhorHipError beyond the limit (the step's results are NaN there): switch to arithmetic 'split_bf16', which has no limit.
+        max_over_ranks: a callable reducing one float with MAX over the data-parallel ranks (Runner.report passes dist.max_over_ranks)
+        so that EVERY rank raises when any rank overflowed -- a rank raising alone leaves the others blocked in the next all-reduce."""
+        st = self.range_status(state)
+        if st is None:
+            if max_over_ranks is not None:
+                max_over_ranks(0.0)                        # (keep the collective matched across ranks)
+            return None
+        m, lim = st
+        g = max_over_ranks(m) if max_over_ranks is not None else m
+        if not g < lim:                                    # (NaN compares false)
+            where = "" if g == m or max_over_ranks is None else f" (this rank: {m:.4g}; the maximum is another rank's)"
             raise _lib.DynhorHipError(
-                f"split_f16 range exceeded: max softplus activation of the SDF network = {m:.4g}, limit {lim:.0f} (fp16 overflow at the "
-                "forward chain's constant scale 16): this step's results are not valid; use model.arithmetic = 'split_bf16'")
+                f"split_f16 range exceeded: max softplus activation of the SDF network = {g:.4g}{where}, limit {lim:.0f} (fp16 overflow at "
+                "the forward chain's constant scale 16): this step's results are not valid; use model.arithmetic = 'split_bf16'")
         return m, lim
 
     # ------------------------------------------------------------------ no-grad SDF queries

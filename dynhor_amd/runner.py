@@ -244,8 +244,9 @@ class Runner:
         v = dh_dist.mean_stats(stats).tolist()
         # loud, never silent: the two-piece fp16 arithmetic's range watch (one device read, report iterations
         # only) and a finite-loss check
+        # (reduced with MAX over the ranks first -- ADVICE r5: a rank that raised alone left the others in the next all-reduce)
         if hasattr(self.renderer, "check_range"):
-            self.renderer.check_range()
+            self.renderer.check_range(max_over_ranks=lambda x: dh_dist.max_over_ranks(x, self.device))
         if not math.isfinite(v[0]):
             from ._lib import DynhorHipError
             raise DynhorHipError(f"non-finite loss at iteration {self.iter_step}: {v[0]}")

@@ -351,18 +351,23 @@ int dh_hash_weight_grads(const float* params, const float* packed, int64_t n, fl
 /* The same in two parts, for data-parallel callers: parts & 1 writes the table gradient (the leading dh_hashgrid_entries() x 2 floats
  * of grad: 49 MB), parts & 2 the five small linears.  Calling the table part, starting its all-reduce on a side stream, then the
  * linears, hides the large collective behind the small weight-gradient GEMMs (dynhor_amd/hash_fields.py).
- * parts & 4 selects how the table scatter adds.  Set (5, 7; dh_hash_weight_grads = 7): every contribution is converted to 2^-48 fixed
+ * parts & 4 selects how the table scatter adds.  Set (5, 7; dh_hash_weight_grads = 7): every contribution is converted to 2^-40 fixed
  * point and added by an INTEGER atomic to an int64 accumulator in the workspace (dh_hash_workspace_floats counts it), converted to
- * float once -- integer addition is associative, so the result is bit-identical from launch to launch; resolution 3.6e-15, range
- * +-32,768; a non-finite contribution or one beyond 16,384 turns the WHOLE table gradient into NaN (never a wrapped sum).  Same speed
- * as the float form on MI355X (both are bound by the memory side's atomic request rate).  Clear (1, 3): float atomics, whose sums
- * depend on the order in which the memory side sees the requests (last-bit differences from launch to launch: the only such sums in
- * the library; kept for comparison). */
+ * float once -- integer addition is associative, so the result is bit-identical from launch to launch; resolution 9.1e-13.  Range: one
+ * contribution below 16,384, a sum exact up to +-4,194,304 (256 same-signed contributions at the limit).  A non-finite contribution or
+ * one beyond 16,384 turns the WHOLE table gradient into NaN; an entry whose accumulator ends at |sum| >= 4,194,304 is NaN itself (the
+ * guard band covers every true sum up to 3 x that; a finite wrong value would need more than 768 same-signed contributions at the
+ * limit on one entry).  Same speed as the float form on MI355X (both are bound by the memory side's atomic request rate).  Clear (1,
+ * 3): float atomics, whose sums depend on the order in which the memory side sees the requests (last-bit differences from launch to
+ * launch: the only such sums in the library; kept for comparison).  The merge ablations of dh_hash_set_scatter_mode apply to the float
+ * form only: with bit 4 set and a scatter mode other than 0 selected the call returns DH_ERR_BAD_ARG instead of ignoring the mode. */
 int dh_hash_weight_grads_parts(const float* params, const float* packed, int64_t n, float* ws, float* grad, const int64_t* n_active,
                                int parts, void* stream);
-/* Diagnosis only (scripts/psnr_parity.py ablations): how dh_hash_weight_grads merges table-gradient adds before they
- * reach memory.  0 (default, shipping) = 7-evaluation blending + ray-run merging + quad-lane packing; 1 = no ray-run
- * merging; 2 = neither (one atomic per evaluation corner, tcnn's scheme).  Same sums up to float-atomic ordering. */
+/* Diagnosis only (scripts/psnr_parity.py ablations): how the FLOAT-atomic table scatter (dh_hash_weight_grads_parts with parts 1 or
+ * 3) merges table-gradient adds before they reach memory.  0 (default, shipping) = 7-evaluation blending + ray-run merging + quad-lane
+ * packing; 1 = no ray-run merging; 2 = neither (one atomic per evaluation corner, tcnn's scheme).  Same sums up to float-atomic
+ * ordering.  The fixed-point form (parts bit 4, dh_hash_weight_grads) always merges: it refuses to run while a mode other than 0 is
+ * selected (DH_ERR_BAD_ARG). */
 int dh_hash_set_scatter_mode(int mode);
 
 #ifdef __cplusplus

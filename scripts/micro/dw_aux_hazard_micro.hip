@@ -1,7 +1,8 @@
 // Standalone repro of the weight-gradient kernel's irreproducible two-piece AUX body (profiles/r04_dw_aux_reproducibility.json,
-// VERDICT r4 "next" 1a).  This file INCLUDES csrc/dw.hip, so the kernel under test is compiled from the product's own source with
-// whatever variant macros the Makefile passes (-DDW_AUX_TWO_PIECE -DDW_AUX_VARIANT=k ...): the code generation of the step loop is
-// the library's, only the job list (run-time data) is synthetic.  No torch, no workspace: synthetic heavy-tailed A tiles, O(1) aux
+// VERDICT r4 "next" 1a).  This file INCLUDES csrc/dw.hip (job tables, scales, the main body) and dw_aux_variants.h (round 6: the aux
+// body WITH its development switches and a kernel identical to dw_f16x2_kernel that calls it -- the product file holds the shipping
+// body only).  With no -DDW_AUX_V_* / -DDW_AUX_THREE_PIECE switch the variants header compiles to the product's body, line for line;
+// only the job list (run-time data) is synthetic.  No torch, no workspace: synthetic heavy-tailed A tiles, O(1) aux
 // B tiles, exact per-tile / per-class maxima.
 //
 //   dw_aux_hazard_micro [launches] [aux_workgroups (1..256; the rest run main jobs)] [ntiles] [aux_jobs]
@@ -9,6 +10,7 @@
 // Every launch's slabs are compared bit for bit with the first launch's; differing launches are counted and the first few are
 // decoded (workgroup, job, output tile, n-tile, accumulator lanes / registers, magnitude).  One JSON line at the end.
 #include "../../dynhor_amd/csrc/dw.hip"
+#include "dw_aux_variants.h"
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -92,7 +94,7 @@ int main(int argc, char** argv) {
     CK(hipMemset(slabs, 0, G * gstride * 4));
     CK(hipDeviceSynchronize());
     auto launch = [&]() {
-        hipLaunchKernelGGL(dw_f16x2_kernel, dim3(G), dim3(512), 0, 0, J, Gp, nt, slabs, gstride, (const unsigned*)absmax, (const unsigned*)tmax);
+        hipLaunchKernelGGL(dw_f16x2_variant_kernel, dim3(G), dim3(512), 0, 0, J, Gp, nt, slabs, gstride, (const unsigned*)absmax, (const unsigned*)tmax);
     };
     launch();
     CK(hipDeviceSynchronize());

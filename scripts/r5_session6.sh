@@ -5,9 +5,9 @@ cd $GRAFT_REPO_ROOT
 O=gpurun_out/s6; mkdir -p $O
 timeout 1500 python3 -m pytest tests/test_gpu_hash_reproducible.py tests/test_gpu_occgrid.py tests/test_gpu_hash_family.py tests/test_gpu_launch.py -x -q -s > $O/pytest.log 2>&1; tail -8 $O/pytest.log
 grep -h "float-atomic launches\|table gradient rel L2\|occupied .* of" $O/pytest.log
-for f in "" "--reproducible-table-grad"; do
+for f in "" "--float-atomic-table-grad"; do   # (round 6: the flag that exists; the default IS the reproducible form)
   for smp in hierarchical occgrid; do
-    tag=${smp}${f:+_fix}
+    tag=${smp}${f:+_float}
     timeout 600 python3 bench.py --family hash --hash-sampler $smp $f --steps 100 --no-cpu-baseline --no-secondary > $O/bench_hash_$tag.json 2> $O/bench_hash_$tag.err
     python3 - $O/bench_hash_$tag.json <<'PY'
 import json, sys

@@ -33,6 +33,23 @@ def _worker(rank, world, port, out_dir):
     mean = grad * (1.0 / world)                       # what dh_adam_step's grad_scale applies
     stats = dh_dist.mean_stats(torch.full((8,), float(rank)))
     assert torch.allclose(stats, torch.full((8,), (world - 1) / 2.0))
+    # the range watch of Runner.report: the verdict is reduced with MAX first, so EVERY rank raises when one overflowed
+    assert dh_dist.max_over_ranks(5000.0 if rank == 1 else 3.0) == 5000.0
+    assert dh_dist.max_over_ranks(float("nan") if rank == 0 else 1.0) == float("inf")
+    from dynhor_amd import _lib
+    from dynhor_amd.renderer import NeuSRenderer
+
+    class _Stub:
+        def __init__(self, m): self.m = m
+        def range_status(self, state=None): return self.m, 4094.0
+    assert NeuSRenderer.check_range(_Stub(10.0 + rank), max_over_ranks=dh_dist.max_over_ranks) == (10.0 + rank, 4094.0)
+    try:
+        NeuSRenderer.check_range(_Stub(9000.0 if rank == 1 else 2.0), max_over_ranks=dh_dist.max_over_ranks)
+        raised = False
+    except _lib.DynhorHipError as e:
+        raised = True
+        assert ("another rank" in str(e)) == (rank == 0)
+    assert raised, "the rank that did NOT overflow must raise too"
     fp = schedules.FramePermutation(64, 4321)
     frames = [fp.frame(schedules.frame_slot(it, rank, world)) for it in range(32)]
     frames2 = [fp.frame(schedules.frame_slot(it, rank, world)) for it in range(32, 64)]      # second epoch: re-drawn
