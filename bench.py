@@ -139,7 +139,10 @@ def committed_psnr_record():
         for path in sorted(glob.glob(os.path.join(ROOT, "profiles", pat))):
             d = json.load(open(path))
             w = d.get("window_delta") or d.get("all_seeds") or d.get("all_59_seeds")
-            out = {"source": "profiles/" + os.path.basename(path), "delta": round(w["mean_db"], 4), "se": round(w["se_db"], 4),
+            out = {"measured_in_this_run": False,
+                   "label": "COMMITTED record quoted from profiles/ (not measured by this run; --psnr measures fresh pairs; this run's own "
+                            "parity measurement is `parity_check`)",
+                   "source": "profiles/" + os.path.basename(path), "delta": round(w["mean_db"], 4), "se": round(w["se_db"], 4),
                    "seeds": w["n"], "median": round(w.get("median_db", float("nan")), 4) if "median_db" in w else None,
                    "window": _delta_stats(w),
                    "final_checkpoint": _delta_stats(d["final_delta"]) if "final_delta" in d else None,
@@ -154,6 +157,67 @@ def committed_psnr_record():
                                           "what": n.get("what")}
             return out
     return None
+
+
+def parity_check_in_this_run(runner, device, iters=50):
+    """`parity_check` of the default line (VERDICT r5 next #5a): ONE lock-step segment HIP path vs the GPU-eager oracle, MEASURED IN THIS
+    RUN, after the timed region (never inside it).  The oracle (the checker, never the thing measured) copies the bench runner's current
+    weights, the HIP arm takes the oracle's (fresh) Adam state, and both train `iters` iterations on the same rays, the same
+    perturbations and the same learning rates.  first_step_loss_diff is pure kernel error (same weights, same rays); a biased kernel
+    would show as a one-sided signed_segment_mean; param_rel_divergence_at_end is the chaotic drift of `iters` steps."""
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import psnr_parity as PP
+    from dynhor_amd import schedules
+    PP.LOG = sys.stderr
+    t0 = time.perf_counter()
+    ds = runner.dataset
+    B = PP.OracleArm("neus", runner, 5e-4, device)
+    runner.store.load_optimizer_state_dict(B.opt.state_dict())
+    runner.store.bump()
+    A = PP.HipArm(runner)
+    gen = torch.Generator(device=device); gen.manual_seed(20261004)
+    fp = schedules.FramePermutation(ds.n_images, 97)
+    it0 = int(runner.iter_step)
+    dl, la0, lb0 = [], None, None
+    n = runner.batch_size
+    for i in range(iters):
+        it = it0 + i
+        frame = fp.frame(i)
+        car = schedules.cos_anneal_ratio(it, PP.ANNEAL_END)
+        lr = 5e-4 * schedules.lr_factor(it, PP.WARM_UP, PP.END_ITER, PP.LR_ALPHA)
+        px = torch.randint(0, ds.W, [n], device=device, generator=gen)
+        py = torch.randint(0, ds.H, [n], device=device, generator=gen)
+        tr = torch.rand([n, 1], device=device, generator=gen)
+        rays = ds.gen_rays_at_pixels(frame, px, py)
+        near, far = ds._last_near_far
+        la, _ = A.step(rays, near, far, ds.R[frame], car, lr, tr)
+        lb, _ = B.step(rays, near, far, ds.R[frame], car, lr, tr)
+        dl.append(float(la) - float(lb))
+        if i == 0:
+            la0, lb0 = float(la), float(lb)
+    fa, fb = A.flat(), B.flat()
+    d = torch.tensor(dl, dtype=torch.float64)
+    return {"measured_in_this_run": True, "what": f"lock-step, {iters} training iterations from this run's weights (iteration {it0}): "
+            "HIP path vs the GPU-eager PyTorch oracle on the same rays; loss differences HIP - oracle",
+            "iters": iters, "rays_per_iter": n, "loss_hip_first_step": round(la0, 7), "loss_oracle_first_step": round(lb0, 7),
+            "first_step_loss_diff": float(d[0]), "signed_segment_mean": float(d.mean()),
+            "signed_segment_se": float(d.std() / len(dl) ** 0.5) if len(dl) > 1 else None, "abs_max": float(d.abs().max()),
+            "param_rel_divergence_at_end": float((fa - fb).norm() / fb.norm()),
+            "tolerance": "first step |diff| <= 5e-6 (committed lock-steps: <= 7.2e-7); see DESIGN.md section 4",
+            "pass": bool(abs(float(d[0])) <= 5e-6), "seconds": round(time.perf_counter() - t0, 1),
+            "oracle": "oracle/neus_oracle.py (this repo's restatement of upstream NeuS: parity unpinned at the reference)"}
+
+
+def occgrid_quality_record():
+    """PSNR at 2k iterations of the occupancy-grid sampler minus the hierarchical sampler (hash family, 8 paired seeds; committed)."""
+    path = os.path.join(ROOT, "profiles", "psnr_r05_hash_occgrid_vs_hierarchical.json")
+    try:
+        w = json.load(open(path))["window_delta"]
+        return {"mean": round(w["mean_db"], 3), "se": round(w["se_db"], 3), "seeds": w["n"], "measured_in_this_run": False,
+                "source": "profiles/" + os.path.basename(path),
+                "note": "equal iterations; the marcher is faster per step and learns less per step (nerfacc's refresh schedule: -0.69 +- 0.09)"}
+    except (OSError, KeyError, ValueError):
+        return None
 
 
 def lib_identity():
@@ -202,6 +266,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-rays", type=int, default=None, help="rays of the cpu_baseline sample (default 2048; hash family 128)")
     ap.add_argument("--psnr", action="store_true", help="add psnr_at_2k: HIP path vs oracle at equal iterations (scripts/psnr_parity.py)")
+    ap.add_argument("--no-parity-check", action="store_true",
+                    help="skip parity_check (one 50-iteration lock-step segment HIP vs GPU-eager oracle after the timed region, ~10 s)")
+    ap.add_argument("--parity-iters", type=int, default=50)
     ap.add_argument("--psnr-seeds", type=int, default=2)
     ap.add_argument("--psnr-iters", type=int, default=2000)
     ap.add_argument("--backend", type=str, default="nccl", help="torch.distributed backend (nccl == RCCL; gloo for tests)")
@@ -485,8 +552,13 @@ def main():
                 d = per_kernel[dom]
                 t_mfma = 2.0 * MACS[dom] * pts.get(dom, P) / (peak * 1e12)
                 t_hbm = d.get("algorithmic_hbm_bytes", 0) / (HBM_PEAK_GBPS * 1e9)
-                roof = {"bound": "mfma", "kernel": names[dom], "stage": dom, "achieved": d["tflops"], "peak": round(peak, 1),
+                roof = {"bound": "mfma", "bound_in_this_design": "hbm" if t_hbm > t_mfma else "mfma",
+                        "kernel": names[dom], "stage": dom, "achieved": d["tflops"], "peak": round(peak, 1),
                         "unit": "TFLOP/s", "frac": round(d["tflops"] / peak, 4),
+                        "bound_basis": "`bound` is SURVEY.md section 8(d)'s (the path, fused, is matrix-bound: `frac` is priced against the "
+                                       "matrix ceiling); `bound_in_this_design` says which ceiling the dominant launch needs longer at "
+                                       "peak rates in THIS save-everything data flow (design_floor.why) -- where that is hbm, `frac` is "
+                                       "measured against a ceiling the kernel cannot reach without changing the data flow",
                         "peak_basis": (f"dense fp16 / bf16 MFMA 2500 TFLOP/s / {int(nprod)} matrix products per fp32 product "
                                        f"(the {'three' if nprod == 3 else 'six'}-product ceiling of this arithmetic)" if split
                                        else "fp32 MFMA v_mfma_f32_32x32x2_f32"),
@@ -526,9 +598,15 @@ def main():
                               "split_f16": "fp32 in / fp32 out everywhere; GEMMs as 2-way fp16 split of both operands scaled by powers of two "
                                            "(3 MFMA products, fp32 accumulate: fp32 accuracy, measured 1.9e-7 vs fp64 against 2.3e-7 for "
                                            "the exact fp32 MFMA)"}[args.arithmetic]
+            # which matrix pipe ran: `dtype` is the I/O, accumulate and optimizer type
+            mfma_dtype = ("f32 (v_mfma_f32_32x32x2_f32, small weight-gradient GEMMs only; the MLPs run on the vector ALU)" if hash_family else
+                          {"split_f16": "f16 (2-piece split, 3 products per fp32 product, fp32 accumulate)",
+                           "split_bf16": "bf16 (3-piece split, 6 products per fp32 product, fp32 accumulate)",
+                           "fp32_mfma": "f32 (v_mfma_f32_32x32x2_f32)"}[args.arithmetic])
             out = {"metric": "training rays/sec", "value": round(value, 1), "unit": "rays/s", "n_gpus": world,
                    "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
-                   "scaling": "weak" if args.rays_per_rank == 2048 else "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                   "scaling": "weak" if args.rays_per_rank == 2048 else "strong", "vs_baseline": None, "dtype": "f32", "mfma_dtype": mfma_dtype,
+                   "data": "synthetic",
                    "config": {"workload": workload, "family": args.family, "frames": args.frames, "rays_per_rank": B,
                               "samples_per_ray": n_samples, "parallelism": f"dp{world}",
                               "loss": "rgb L1 + 0.1 eikonal + 0.1 mask BCE + 0.05 mono-normal"
@@ -545,6 +623,13 @@ def main():
                 rays = runner.dataset.gen_random_rays_at(frame, n_cpu, generator=g)
                 out["cpu_baseline"] = cpu_baseline(rays, runner.dataset.R[frame], runner.renderer.n_samples,
                                                    runner.renderer.n_importance, runner.normal_weight, family=args.family)
+            if (world == 1 and not hash_family and not args.no_parity_check and args.rays_per_rank == 2048 and restore_stdout
+                    and args.loss == "cfg2"):
+                # measured by THIS run, outside the timed region; last, because it replaces the runner's optimizer state
+                try:
+                    out["parity_check"] = parity_check_in_this_run(runner, device, args.parity_iters)
+                except Exception as e:          # noqa: BLE001 -- the check must never take the measured line down; it says so instead
+                    out["parity_check"] = {"measured_in_this_run": False, "error": repr(e)}
             if args.psnr and world == 1:
                 # the oracle is the checker here (never the thing measured): PSNR of both arms on all frames at equal iterations
                 sys.path.insert(0, os.path.join(ROOT, "scripts"))
@@ -579,6 +664,9 @@ def main():
                 try:
                     line = bench_line(a2, False)
                     sec[name] = {k: line[k] for k in ('value', 'unit', 'ms_per_step', 'steps', 'warmup', 'config', 'roofline', 'kernels', 'final_stats')}
+                    if name == 'hash_occgrid':
+                        # a throughput number on a sampler that learns LESS per iteration: never read it without this
+                        sec[name]['psnr_vs_hierarchical_db'] = occgrid_quality_record()
                 except Exception as e:          # noqa: BLE001 -- a secondary line must never take the headline down
                     sec[name] = {'error': repr(e)}
             out['secondary'] = sec

@@ -17,6 +17,12 @@ int hash_scatter_mode() { return __atomic_load_n(&g_hash_scatter, __ATOMIC_RELAX
 namespace {
 inline bool misaligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) != 0; }
 inline bool bad_arith(int a) { return a != DH_ARITH_SPLIT_BF16 && a != DH_ARITH_FP32_MFMA && a != DH_ARITH_SPLIT_F16; }
+// stages with a tile-PAIR form (chain_pair.hip) accept DH_CHAIN_FORM_* flags above the arithmetic byte, with DH_ARITH_SPLIT_F16 only
+inline bool bad_arith_form(int a) {
+    const int form = a & ~0xff;
+    return bad_arith(a & 0xff) || (form != 0 && form != DH_CHAIN_FORM_TILE && form != DH_CHAIN_FORM_PAIR) ||
+           (form != 0 && (a & 0xff) != DH_ARITH_SPLIT_F16);
+}
 inline int cur_arith() { return __atomic_load_n(&dh::g_arith, __ATOMIC_RELAXED); }
 #ifndef DH_GRID_DIV
 #define DH_GRID_DIV 1                    // development macro: 2 = ONE workgroup per CU (what a chain's phases cost without a co-resident partner)
@@ -129,7 +135,7 @@ int dh_sdf_forward_ex(int arithmetic, const float* packed, const float* pts, int
 
 int dh_sdf_gradient_ex(int arithmetic, const float* packed, const float* pts, int64_t npts, float* ws, float* normals, int save,
                        void* stream) {
-    if (bad_arith(arithmetic)) return DH_ERR_BAD_ARG;
+    if (bad_arith_form(arithmetic)) return DH_ERR_BAD_ARG;
     if (npts <= 0) return npts == 0 ? DH_OK : DH_ERR_BAD_ARG;
     if (!packed || !pts || !ws || !normals || misaligned16(packed) || misaligned16(ws)) return DH_ERR_BAD_ARG;
     const Workspace w = carve_workspace(ws, npts);
@@ -140,7 +146,7 @@ int dh_sdf_gradient_ex(int arithmetic, const float* packed, const float* pts, in
 
 int dh_color_forward_ex(int arithmetic, const float* packed, const float* pts, const float* dirs, int n_per_ray, const float* normals,
                         int64_t npts, float* ws, float* color, int save, void* stream) {
-    if (npts < 0 || n_per_ray <= 0 || bad_arith(arithmetic)) return DH_ERR_BAD_ARG;
+    if (npts < 0 || n_per_ray <= 0 || bad_arith_form(arithmetic)) return DH_ERR_BAD_ARG;
     if (npts == 0) return DH_OK;
     if (!packed || !pts || !dirs || !normals || !ws || !color || misaligned16(packed) || misaligned16(ws)) return DH_ERR_BAD_ARG;
     const Workspace w = carve_workspace(ws, npts);
@@ -159,7 +165,7 @@ int dh_mlp_forward_ex(int arithmetic, const float* packed, const float* pts, con
 
 int dh_color_backward_ex(int arithmetic, const float* packed, const float* colors, const float* d_colors, int64_t npts, float* ws,
                          float* d_normals, void* stream) {
-    if (npts <= 0 || bad_arith(arithmetic)) return DH_ERR_BAD_ARG;
+    if (npts <= 0 || bad_arith_form(arithmetic)) return DH_ERR_BAD_ARG;
     if (!packed || !colors || !d_colors || !ws || !d_normals || misaligned16(packed) || misaligned16(ws)) return DH_ERR_BAD_ARG;
     const Workspace w = carve_workspace(ws, npts);
     return launch_color_bwd(packed, colors, d_colors, npts, w.cact, w.czbar, w.featbar, d_normals, w.tpart, w.absmax, DEFAULT_GRID,

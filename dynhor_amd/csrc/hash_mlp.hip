@@ -525,19 +525,20 @@ __global__ __launch_bounds__(256) void hash_geo_bwd_kernel(const float* __restri
 // plain store to the same address (what the kernel costs without read-modify-write at the memory side), -DHASH_PROBE_SPREAD sends
 // every atomic to a line of its own (no two requests share an address: the atomic path without contention), -DHASH_PROBE_LEVEL=k
 // runs level k only.  Their numbers: DESIGN_NEXT_ROWS.md section 7 "what bounds the table scatter".
-// MODE 3, the reproducible scatter (dh_hash_weight_grads_parts, parts bit 4): the same merges, but every add is converted to 2^-40
+// MODE 3, the reproducible scatter (dh_hash_weight_grads_parts, parts bit 4): the same merges, but every add is converted to 2^-48
 // fixed point and added to an int64 accumulator by an INTEGER atomic -- integer addition is associative, so the sums do not depend
 // on the order in which the memory side sees the requests, and two launches on the same inputs agree bit for bit.  Resolution
-// 9.1e-13 (an fp32 sum of that magnitude carries less).  Range (round 6, ADVICE r5: the 2^-48 form of round 5 checked single
-// contributions only and three near-limit adds on one entry wrapped the int64): ONE contribution must be below 16,384 = 2^14 (2^54
-// in fixed point), a SUM is exact up to +-2^22 = 4,194,304 (2^62), i.e. 256 same-signed contributions at the limit.
+// 3.6e-15: the table's gradients are small (a 2^-40 grid, tried first in round 6, read 2e-6 relative against the float form where
+// this one reads 7e-8 -- the float form's own rounding).  Range (round 6, ADVICE r5: round 5 allowed single contributions up to 16,384,
+// so three near-limit adds on one entry wrapped the int64 unnoticed): ONE contribution must be below 64 = 2^6 (2^54 in fixed point), a
+// SUM is exact up to +-16,384 = 2^14 (2^62), i.e. 256 same-signed contributions at the limit.
 //   * a non-finite or out-of-range contribution raises the flag word behind the accumulators and hash_fix_to_float_kernel then
 //     writes NaN to the WHOLE table gradient;
 //   * an accumulator that ends in the guard band |acc| >= 2^62 becomes NaN for ITS entry (what the float form would show as inf):
-//     every true sum of magnitude 2^22 ... 3 x 2^22 lands there, so a finite wrong value needs more than 768 same-signed
+//     every true sum of magnitude 2^14 ... 3 x 2^14 lands there, so a finite wrong value needs more than 768 same-signed
 //     contributions at the limit on one entry.
-constexpr double HG_FIX_ONE = 1099511627776.0;                  // 2^40
-constexpr float HG_FIX_LIMIT = 16384.f;                        // one contribution
+constexpr double HG_FIX_ONE = 281474976710656.0;               // 2^48
+constexpr float HG_FIX_LIMIT = 64.f;                           // one contribution
 constexpr long long HG_FIX_GUARD = 1ll << 62;                  // |accumulator| from here on: the entry is NaN
 constexpr int HG_FIX_FLAG_WORDS = 8;                           // one 64-B line of int64 behind the accumulators
 #if defined(HASH_PROBE_STORE)

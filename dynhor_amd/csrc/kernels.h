@@ -44,6 +44,28 @@ int launch_sdf_bwd_h(const float* packed, const float* d_sdf, const float* pts, 
                      const float* act, const float* rsave, const float* featbar, const float* gesave, float* zbar, float* tpart,
                      float* d_pts, unsigned* absmax, unsigned* tmax, int grid, hipStream_t st);
 
+// chain_pair.hip (two-piece fp16, tile-PAIR form: one workgroup per CU, weights held in registers across two tiles; round 6).
+// The launchers above pick it for launches of at least 2 x #CUs tiles unless the arithmetic word carries a form flag (CHAIN_FORM_*).
+enum : int { CHAIN_FORM_AUTO = 0, CHAIN_FORM_TILE = 1, CHAIN_FORM_PAIR = 2 };
+bool pair_form_available();
+int pair_form_cus();
+// the form a SPLIT_F16 stage launch of npts points takes: forced by the flag, else PAIR once every CU gets at least one pair
+inline bool use_pair_form(int form, int64_t npts) {
+    if (form == CHAIN_FORM_PAIR) return true;
+    if (form == CHAIN_FORM_TILE) return false;
+    const int cus = pair_form_cus();
+    return cus > 0 && (npts + TM - 1) / TM >= 2 * (int64_t)cus;
+}
+int launch_color_fwd_p(const float* packed, const float* pts, const float* dirs, int n_per_ray, const float* normals,
+                       const float* feat, int64_t npts, float* color, float* cact, float* caux, int save, unsigned* absmax,
+                       hipStream_t stream);
+
+int launch_sdf_grad_p(const float* packed, const float* pts, int64_t npts, const float* act, float* asave, float* normals, int save,
+                      float* gesave, unsigned* absmax, hipStream_t stream);
+
+int launch_color_bwd_p(const float* packed, const float* colors, const float* d_colors, int64_t npts, const float* cact, float* czbar,
+                       float* featbar, float* d_normals, float* tpart, unsigned* absmax, unsigned* tmax, hipStream_t stream);
+
 // per-ray kernels (kernels_ray.hip)
 int launch_gen_rays(const uint8_t* rgb, const int8_t* label, const uint8_t* normal, const float* R, const float* T,
                     const float* Kinv, int H, int W, int frame, const int64_t* px, const int64_t* py, int64_t B,

@@ -389,7 +389,12 @@ int launch_sdf_fwd_train(const float* packed, const float* pts, int64_t npts, fl
 }
 int launch_sdf_grad(const float* packed, const float* pts, int64_t npts, const float* act, float* asave, float* normals,
                     int save, float* gesave, float* absmax, int grid, int arith, hipStream_t stream) {
-    if (arith == ARITH_F16) return launch_sdf_grad_h(packed, pts, npts, act, asave, normals, save, gesave, reinterpret_cast<unsigned*>(absmax), grid, stream);
+    const int form = arith >> 8;                              // include/dynhor_hip.h DH_CHAIN_FORM_*: 0 auto, 1 tile, 2 pair
+    arith &= 0xff;
+    if (arith == ARITH_F16) {
+        if (use_pair_form(form, npts)) return launch_sdf_grad_p(packed, pts, npts, act, asave, normals, save, gesave, reinterpret_cast<unsigned*>(absmax), stream);
+        return launch_sdf_grad_h(packed, pts, npts, act, asave, normals, save, gesave, reinterpret_cast<unsigned*>(absmax), grid, stream);
+    }
     if (arith == ARITH_FP32) hipLaunchKernelGGL(sdf_grad_kernel, dim3(grid_for(npts, grid)), dim3(256), 0, stream, make_sdf_ptrs(packed), pts, npts, act, asave, normals, save, gesave);
     else hipLaunchKernelGGL(sdf_grad_s_kernel, dim3(grid_for(npts, grid)), dim3(256), 0, stream, make_sdf16_ptrs(packed), pts, npts, act, asave, normals, save, gesave);
     return ok();
@@ -397,8 +402,14 @@ int launch_sdf_grad(const float* packed, const float* pts, int64_t npts, const f
 int launch_color_fwd(const float* packed, const float* pts, const float* dirs, int n_per_ray, const float* normals,
                      const float* feat, int64_t npts, float* color, float* cact, float* caux, int save, float* absmax, int grid,
                      int arith, hipStream_t stream) {
-    if (arith == ARITH_F16) return launch_color_fwd_h(packed, pts, dirs, n_per_ray, normals, feat, npts, color, cact, caux, save,
-                                                     reinterpret_cast<unsigned*>(absmax), grid, stream);
+    const int form = arith >> 8;                              // include/dynhor_hip.h DH_CHAIN_FORM_*: 0 auto, 1 tile, 2 pair
+    arith &= 0xff;
+    if (arith == ARITH_F16) {
+        if (use_pair_form(form, npts)) return launch_color_fwd_p(packed, pts, dirs, n_per_ray, normals, feat, npts, color, cact, caux, save,
+                                                                 reinterpret_cast<unsigned*>(absmax), stream);
+        return launch_color_fwd_h(packed, pts, dirs, n_per_ray, normals, feat, npts, color, cact, caux, save,
+                                  reinterpret_cast<unsigned*>(absmax), grid, stream);
+    }
     const int g = grid_for(npts, grid);
     if (arith == ARITH_FP32) hipLaunchKernelGGL(color_fwd_kernel, dim3(g), dim3(256), 0, stream, make_col_ptrs(packed), pts, dirs, n_per_ray, normals,
                                                 feat, npts, color, cact, caux, save);

@@ -681,8 +681,15 @@ static inline int grid_for(int64_t npts, int grid) {
 
 int launch_color_bwd(const float* packed, const float* colors, const float* d_colors, int64_t npts, const float* cact,
                      float* czbar, float* featbar, float* d_normals, float* tpart, float* absmax, int grid, int arith, hipStream_t st) {
-    if (arith == ARITH_F16) return launch_color_bwd_h(packed, colors, d_colors, nullptr, 1, npts, cact, czbar, featbar, d_normals, tpart, nullptr,
-                                                     nullptr, reinterpret_cast<unsigned*>(absmax), reinterpret_cast<unsigned*>(absmax) + ABSMAX_FLOATS, grid, st);
+    const int form = arith >> 8;                              // include/dynhor_hip.h DH_CHAIN_FORM_*: 0 auto, 1 tile, 2 pair
+    arith &= 0xff;
+    if (arith == ARITH_F16) {
+        unsigned* am = reinterpret_cast<unsigned*>(absmax);
+        if (use_pair_form(form, npts)) return launch_color_bwd_p(packed, colors, d_colors, npts, cact, czbar, featbar, d_normals, tpart, am,
+                                                                 am + ABSMAX_FLOATS, st);
+        return launch_color_bwd_h(packed, colors, d_colors, nullptr, 1, npts, cact, czbar, featbar, d_normals, tpart, nullptr, nullptr, am,
+                                  am + ABSMAX_FLOATS, grid, st);
+    }
     if (arith == ARITH_FP32) hipLaunchKernelGGL(color_bwd_kernel<false>, dim3(grid_for(npts, grid)), dim3(256), 0, st, make_col_ptrs(packed), colors,
                                                 d_colors, npts, cact, czbar, featbar, d_normals, tpart, nullptr, 1, nullptr, nullptr);
     else hipLaunchKernelGGL(color_bwd_s_kernel<false>, dim3(grid_for(npts, grid)), dim3(256), 0, st, make_col16_ptrs(packed), colors,

@@ -54,6 +54,16 @@ const char* dh_strerror(int status);
  * (csrc/workspace.h ABSMAX_TAG); a SPLIT_F16 dh_weight_grads_gemm that finds no tag writes NaN gradients (loud) instead of
  * gradients scaled by stale words (silently wrong). */
 typedef enum { DH_ARITH_SPLIT_BF16 = 0, DH_ARITH_FP32_MFMA = 1, DH_ARITH_SPLIT_F16 = 2 } dh_arithmetic;
+/* Chain FORM of a DH_ARITH_SPLIT_F16 stage (round 6; csrc/pair16h.h).  The stages listed below exist in two kernel forms that write
+ * bit-identical results: the TILE form (csrc/kernels_mlp_h.hip: one 64-point tile per workgroup, two workgroups per CU, weights
+ * streamed from L2 per tile) and the PAIR form (csrc/chain_pair.hip: one workgroup per CU owns two tiles, holds a layer's weight slice
+ * in registers across both and runs one tile's epilogue under the other's MFMAs: half the L2 -> CU weight bytes per point).  By default
+ * a launch of at least 2 x #CUs tiles (32,768 points on MI355X) runs the PAIR form, a smaller one the TILE form (a pair workgroup
+ * occupies a whole CU).  OR one of these flags into the `arithmetic` argument of the stage's `_ex` entry point to force a form (tests,
+ * A/Bs); the PAIR form returns DH_ERR_UNSUPPORTED on a device without 160 KB of LDS per CU.  Stages with a PAIR form:
+ * dh_sdf_gradient_ex, dh_color_forward_ex, dh_color_backward_ex (not its pose-refinement form dh_color_backward_rays_ex).  Every other
+ * entry point rejects the flags (DH_ERR_BAD_ARG). */
+enum { DH_CHAIN_FORM_TILE = 0x100, DH_CHAIN_FORM_PAIR = 0x200 };
 int dh_set_arithmetic(int mode);
 int dh_get_arithmetic(void);
 
@@ -351,12 +361,12 @@ int dh_hash_weight_grads(const float* params, const float* packed, int64_t n, fl
 /* The same in two parts, for data-parallel callers: parts & 1 writes the table gradient (the leading dh_hashgrid_entries() x 2 floats
  * of grad: 49 MB), parts & 2 the five small linears.  Calling the table part, starting its all-reduce on a side stream, then the
  * linears, hides the large collective behind the small weight-gradient GEMMs (dynhor_amd/hash_fields.py).
- * parts & 4 selects how the table scatter adds.  Set (5, 7; dh_hash_weight_grads = 7): every contribution is converted to 2^-40 fixed
+ * parts & 4 selects how the table scatter adds.  Set (5, 7; dh_hash_weight_grads = 7): every contribution is converted to 2^-48 fixed
  * point and added by an INTEGER atomic to an int64 accumulator in the workspace (dh_hash_workspace_floats counts it), converted to
- * float once -- integer addition is associative, so the result is bit-identical from launch to launch; resolution 9.1e-13.  Range: one
- * contribution below 16,384, a sum exact up to +-4,194,304 (256 same-signed contributions at the limit).  A non-finite contribution or
- * one beyond 16,384 turns the WHOLE table gradient into NaN; an entry whose accumulator ends at |sum| >= 4,194,304 is NaN itself (the
- * guard band covers every true sum up to 3 x that; a finite wrong value would need more than 768 same-signed contributions at the
+ * float once -- integer addition is associative, so the result is bit-identical from launch to launch; resolution 3.6e-15.  Range: one
+ * contribution below 64, a sum exact up to +-16,384 (256 same-signed contributions at the limit).  A non-finite contribution or one
+ * beyond 64 turns the WHOLE table gradient into NaN; an entry whose accumulator ends at |sum| >= 16,384 is NaN itself (the guard band
+ * covers every true sum up to 3 x that; a finite wrong value would need more than 768 same-signed contributions at the
  * limit on one entry).  Same speed as the float form on MI355X (both are bound by the memory side's atomic request rate).  Clear (1,
  * 3): float atomics, whose sums depend on the order in which the memory side sees the requests (last-bit differences from launch to
  * launch: the only such sums in the library; kept for comparison).  The merge ablations of dh_hash_set_scatter_mode apply to the float
