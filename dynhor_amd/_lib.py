@@ -117,7 +117,9 @@ ARITH_NAMES = {"split_f16": ARITH_SPLIT_F16, "split_bf16": ARITH_SPLIT_BF16, "fp
 # cannot leave a stale entry behind.
 STAGE_KERNELS = {
     ARITH_SPLIT_F16: {"weight_grads_gemm": "dw_f16x2_kernel", "sdf_forward": "sdf_fwd_train_h_kernel",
-                      "sdf_gradient": "sdf_grad_h_kernel", "color_forward": "color_fwd_h_kernel",
+                      # (colour forward: the tile-PAIR form, csrc/chain_pair.hip, at the bench's launch size -- include/dynhor_hip.h DH_CHAIN_FORM_*;
+                      #  launches below 2 x #CUs tiles run color_fwd_h_kernel)
+                      "sdf_gradient": "sdf_grad_h_kernel", "color_forward": "color_fwd_p_kernel",
                       "color_backward": "color_bwd_h_kernel", "sdf_tangent": "sdf_tangent_h_kernel",
                       "sdf_backward": "sdf_bwd_h_kernel", "sdf_nograd_coarse": "sdf_nograd_h_kernel",
                       "sdf_nograd_fine": "sdf_nograd_h_kernel"},

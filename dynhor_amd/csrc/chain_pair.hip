@@ -43,57 +43,66 @@ static inline ColPPtrs make_colp_ptrs(const float* packed) {
 // ------------------------------------------------------------------------------------------------ colour forward
 // epilogue of one colour layer for one tile (bias, ReLU, the saved tile, the running maximum) + the hand-off into the tile's image
 template <bool SAVE>
-struct ColFwdEpi : PHandoff {
-    static constexpr int MID = P_NKC / 2;
+struct ColFwdEpi : PEpi<ColFwdEpi<SAVE>, 3, 4> {
     f32x16 (&acc)[MT][2];
-    _Float16* img;
     HScratchP& hs;
     float* lmax;                   // the workgroup's running class maximum (an LDS word), or nullptr
     const int wave, lane, tid;
     const float inv, b0, b1;
-    const rsrc_t st;               // where the layer's activation tile goes
+    const rsrc_t st;               // where the layer's activation tile goes (a 0-record descriptor where this tile stores nothing)
     const int loff;
-    const bool store;
-    float m0 = 0.f, m1 = 0.f, inv_S = 0.f;
-    unsigned hl[2];
     __device__ __forceinline__ ColFwdEpi(f32x16 (&acc_)[MT][2], _Float16* img_, HScratchP& hs_, float* lmax_, int wave_, int lane_, int tid_,
-                                         float inv_, float b0_, float b1_, rsrc_t st_, int loff_, bool store_)
-        : acc(acc_), img(img_), hs(hs_), lmax(lmax_), wave(wave_), lane(lane_), tid(tid_), inv(inv_), b0(b0_), b1(b1_), st(st_),
-          loff(loff_), store(store_) {}
-    template <int SL>
-    __device__ __forceinline__ void step() {
-        if constexpr (SL < P_SLOTS / 2) {
-            constexpr int g = SL / 6, sub = SL % 6, m = g / 8, t = (g / 4) % 2, r4 = g % 4;
-            const float b = t ? b1 : b0;
-            if constexpr (sub == 0 || sub == 1) {
-                constexpr int r = 4 * r4 + 2 * sub;
-                acc[m][t][r] = fmaxf(fmaf(acc[m][t][r], inv, b), 0.f);
-                acc[m][t][r + 1] = fmaxf(fmaf(acc[m][t][r + 1], inv, b), 0.f);
-            } else if constexpr (sub == 2) {
-                if constexpr (SAVE) {                        // (st: a 0-record descriptor where this tile stores nothing)
-                    f32x4 v;
-                    v[0] = acc[m][t][4 * r4 + 0]; v[1] = acc[m][t][4 * r4 + 1]; v[2] = acc[m][t][4 * r4 + 2]; v[3] = acc[m][t][4 * r4 + 3];
-                    tile_st(st, loff, (m * 2 + t) * 4 + r4, v);
-                }
-            } else if constexpr (sub == 3) {
-                m0 = fmaxf(m0, fmaxf(fabsf(acc[m][t][4 * r4 + 0]), fabsf(acc[m][t][4 * r4 + 1])));
-                m1 = fmaxf(m1, fmaxf(fabsf(acc[m][t][4 * r4 + 2]), fabsf(acc[m][t][4 * r4 + 3])));
-            }
+                                         float inv_, float b0_, float b1_, rsrc_t st_, int loff_, bool)
+        : acc(acc_), hs(hs_), lmax(lmax_), wave(wave_), lane(lane_), tid(tid_), inv(inv_), b0(b0_), b1(b1_), st(st_), loff(loff_) {
+        this->handoff_init(img_, wave_, lane_);
+    }
+    template <int G, int SUB>
+    __device__ __forceinline__ void elem() {
+        constexpr int m = G / 8, t = (G / 4) % 2, r4 = G % 4;
+        const float b = t ? b1 : b0;
+        if constexpr (SUB == 0 || SUB == 1) {
+            constexpr int r = 4 * r4 + 2 * SUB;
+            acc[m][t][r] = fmaxf(fmaf(acc[m][t][r], inv, b), 0.f);
+            acc[m][t][r + 1] = fmaxf(fmaf(acc[m][t][r + 1], inv, b), 0.f);
         } else {
-            constexpr int q = SL - P_SLOTS / 2;
-            split_step<q / 3, q % 3>(acc, img, wave, lane, hl);
+            if constexpr (SAVE) {
+                f32x4 v;
+                v[0] = acc[m][t][4 * r4 + 0]; v[1] = acc[m][t][4 * r4 + 1]; v[2] = acc[m][t][4 * r4 + 2]; v[3] = acc[m][t][4 * r4 + 3];
+                tile_st(st, loff, G, v);
+            }
+            this->m0 = fmaxf(this->m0, fmaxf(fabsf(acc[m][t][4 * r4 + 0]), fabsf(acc[m][t][4 * r4 + 1])));
+            this->m1 = fmaxf(this->m1, fmaxf(fabsf(acc[m][t][4 * r4 + 2]), fabsf(acc[m][t][4 * r4 + 3])));
         }
     }
-    __device__ __forceinline__ void mid() {
-        tile_max_publish(hs.sred, wave, lane, wave_max(fmaxf(m0, m1)));
-        pair_barrier();
-        const float m = tile_max_read(hs.sred);
-        if (tid == 0 && lmax) *lmax = fmaxf(*lmax, m);
-        const TileScale ts = scale_for_max(m);
-        S = ts.S;
-        inv_S = ts.inv;
-    }
+    __device__ __forceinline__ void publish(float wm) { tile_max_publish(hs.sred, wave, lane, wm); }
+    __device__ __forceinline__ float read_tile_max() { return tile_max_read(hs.sred); }
+    __device__ __forceinline__ void on_tile_max(float m) { if (tid == 0 && lmax) *lmax = fmaxf(*lmax, m); }
 };
+
+// the colour head: three per-point dots of the image rows (hi + lo) with the rows of lin4 staged in LDS (sw4 [3][256]) -- tile16h.h
+// row_dot256_hp's products in its order, per output; the row segment is read once for the three
+__device__ __forceinline__ void row_dot256x3_hp(const _Float16* img, const float* sw4, int tid, float (&out)[3]) {
+    constexpr int TPP_ = 256 / TM, SEG = 256 / TPP_;
+    const int p = tid / TPP_, part = tid % TPP_;
+    const f16x8* xh = reinterpret_cast<const f16x8*>(img + p * LDH + part * SEG);
+    const f16x8* xl = reinterpret_cast<const f16x8*>(img + PLANE_H + p * LDH + part * SEG);
+    float s[3] = {0.f, 0.f, 0.f};
+    DH_UNROLL for (int i = 0; i < SEG / 8; ++i) {
+        const f16x8 h = xh[i], l = xl[i];
+        float x[8];
+        DH_UNROLL for (int k = 0; k < 8; ++k) x[k] = (float)h[k] + (float)l[k];
+        DH_UNROLL for (int j = 0; j < 3; ++j) {
+            const f32x4* wr = reinterpret_cast<const f32x4*>(sw4 + j * 256 + part * SEG);
+            const f32x4 b0 = wr[2 * i], b1 = wr[2 * i + 1];
+            DH_UNROLL for (int k = 0; k < 4; ++k) s[j] = fmaf(x[k], b0[k], s[j]);
+            DH_UNROLL for (int k = 0; k < 4; ++k) s[j] = fmaf(x[4 + k], b1[k], s[j]);
+        }
+    }
+    DH_UNROLL for (int j = 0; j < 3; ++j) {
+        DH_UNROLL for (int off = 1; off < TPP_; off <<= 1) s[j] += __shfl_xor(s[j], off);
+        out[j] = s[j];
+    }
+}
 
 // the exposed hand-off of a pair's first image (the feature tile): kernels_mlp_h.hip lds_handoff, on this file's scratch
 __device__ __forceinline__ TileScale pair_handoff_exposed(const f32x16 (&acc)[MT][2], _Float16* img, HScratchP& hs, float* lmax, int tid,
@@ -117,6 +126,7 @@ __global__ __launch_bounds__(256, 1) void color_fwd_p_kernel(ColPPtrs C, const f
     __shared__ __attribute__((aligned(16))) _Float16 simg[2][IMG_H];
     __shared__ __attribute__((aligned(16))) float saux[2][TM * LDA];
     __shared__ HScratchP hs;
+    __shared__ float sfb[64];                                     // the view embedding of a one-ray tile (two tiles x [24])
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int loff = tile_loff(wave, lane);
     const int64_t ntiles = (npts + TM - 1) / TM, npairs = (ntiles + 1) / 2;
@@ -127,51 +137,95 @@ __global__ __launch_bounds__(256, 1) void color_fwd_p_kernel(ColPPtrs C, const f
     DH_UNROLL for (int l = 0; l < 4; ++l)
         DH_UNROLL for (int t = 0; t < 2; ++t) bs[l][t] = C.bias0[l * COL_BIAS_STRIDE + acc_col(wave, t, lane)];
     PW<P_NKC> W;
-    pw_load_all(W, C.main0, wave, lane);
     _Float16* imgA = simg[0];
     _Float16* imgB = simg[1];
-    for (int64_t pr = blockIdx.x; pr < npairs; pr += gridDim.x) {
+    int pit = 0;
+    for (int64_t pr = blockIdx.x; pr < npairs; pr += gridDim.x, ++pit) {
+        const bool son = pit == 2;                                // (-DDH_STAMPS: the workgroup's third pair is stamped)
+        (void)son;
+        PSTAMP(son, 0);
         const int64_t tileA = 2 * pr;
         const bool okB = tileA + 1 < ntiles;                      // an odd last tile: B replays A with every output switched off
         const int64_t tileB = okB ? tileA + 1 : tileA;
-        if (tid < 2 * TM) {                                       // waves 0 / 1: the extras [p, embed(view), n] of tile A / B
-            const int which = tid >> 6, p = tid & 63;
-            const int64_t gp = (which ? tileB : tileA) * TM + p;
+        // the feature tiles first: their latency runs under the extras
+        f32x16 accA[MT][2], accB[MT][2];
+        acc_load_native_b(accA, tile_rsrc(feat + tileA * TILE_F), loff);
+        acc_load_native_b(accB, tile_rsrc(feat + tileB * TILE_F), loff);
+        {   // the extras [p, embed(view), n]: waves 0, 1 -> tile A, waves 2, 3 -> tile B.  The view embedding depends on the RAY only: where
+            // a tile's 64 points belong to one ray (training: 128 samples per ray) twelve lanes evaluate its twelve sincosf once and every
+            // row copies them -- the same arguments, the same bits; a tile that spans rays evaluates per point (a tile's two waves split
+            // the four frequencies).  (One wave per SIMD hides nothing: 12 sincosf per point cost a pair ~10,000 exposed cycles.)
+            const int which = tid >> 7, half = (tid >> 6) & 1, p = tid & 63;
+            const int64_t t0 = (which ? tileB : tileA) * TM;
+            const int64_t gp = t0 + p;
+            auto single_ray = [&](int64_t first) {
+                const int64_t last = first + TM - 1 < npts ? first + TM - 1 : npts - 1;
+                return first / n_per_ray == last / n_per_ray;
+            };
+            const bool oneA = single_ray(tileA * TM), oneB = single_ray(tileB * TM);      // (workgroup-uniform)
+            const bool one_ray = which ? oneB : oneA;
             float* row = saux[which] + p * LDA;
+            float* emb = sfb + which * 32;                                    // [24] sin / cos of the tile's one ray
+            if (one_ray && half == 0 && lane < 12) {
+                const int c = lane % 3, k = lane / 3;
+                float sn, co; sincosf(dirs[(t0 / n_per_ray) * 3 + c] * (float)(1 << k), &sn, &co);
+                emb[6 * k + c] = sn;
+                emb[6 * k + 3 + c] = co;
+            }
             float mx = 1.f;                                      // sin / cos of the view embedding
             if (gp < npts) {
                 const int64_t ray = gp / n_per_ray;
                 DH_UNROLL for (int c = 0; c < 3; ++c) {
-                    const float d = dirs[ray * 3 + c], x = pts[gp * 3 + c], nn = normals[gp * 3 + c];
-                    row[c] = x;
-                    row[3 + c] = d;
-                    DH_UNROLL for (int k = 0; k < 4; ++k) {
-                        float s, co; sincosf(d * (float)(1 << k), &s, &co);
-                        row[6 + 6 * k + c] = s;
-                        row[6 + 6 * k + 3 + c] = co;
+                    const float d = dirs[ray * 3 + c];
+                    if (!one_ray) {
+                        DH_UNROLL for (int kk = 0; kk < 2; ++kk) {
+                            const int k = 2 * half + kk;
+                            float sn, co; sincosf(d * (float)(1 << k), &sn, &co);
+                            row[6 + 6 * k + c] = sn;
+                            row[6 + 6 * k + 3 + c] = co;
+                        }
                     }
-                    row[30 + c] = nn;
-                    mx = fmaxf(mx, fmaxf(fabsf(x), fmaxf(fabsf(d), fabsf(nn))));
+                    if (half == 0) {
+                        const float x = pts[gp * 3 + c], nn = normals[gp * 3 + c];
+                        row[c] = x;
+                        row[3 + c] = d;
+                        row[30 + c] = nn;
+                        mx = fmaxf(mx, fmaxf(fabsf(x), fmaxf(fabsf(d), fabsf(nn))));
+                    }
                 }
             } else {
-                DH_UNROLL for (int c = 0; c < CAUX; ++c) row[c] = 0.f;
+                DH_UNROLL for (int c = 0; c < 3; ++c) {
+                    DH_UNROLL for (int kk = 0; kk < 2; ++kk) { row[6 + 6 * (2 * half + kk) + c] = 0.f; row[6 + 6 * (2 * half + kk) + 3 + c] = 0.f; }
+                    if (half == 0) { row[c] = 0.f; row[3 + c] = 0.f; row[30 + c] = 0.f; }
+                }
             }
-            DH_UNROLL for (int c = CAUX; c < LDA; ++c) row[c] = 0.f;
-            mx = wave_max(mx);
-            if (lane == 0) hs.sred2[which] = mx;
+            if (half == 0) {
+                DH_UNROLL for (int c = CAUX; c < LDA; ++c) row[c] = 0.f;
+                mx = wave_max(mx);
+                if (lane == 0) hs.sred2[which] = mx;
+            }
+            if (oneA || oneB) {                                  // (uniform) the tile's other wave must see emb: copy behind a barrier
+                __syncthreads();
+                if (one_ray && gp < npts) { DH_UNROLL for (int j = 0; j < 12; ++j) row[6 + 12 * half + j] = emb[12 * half + j]; }
+            }
         }
-        f32x16 accA[MT][2], accB[MT][2];
-        acc_load_native_b(accA, tile_rsrc(feat + tileA * TILE_F), loff);
-        acc_load_native_b(accB, tile_rsrc(feat + tileB * TILE_F), loff);
         // (the barriers inside also publish saux; the previous pair ended with one, so the images are free).  The extras share layer
         // 0's accumulator with feat: one scale for both, from the larger of the two maxima
+        PSTAMP(son, 88);
         TileScale tsA = pair_handoff_exposed(accA, imgA, hs, SAVE ? &hs.lmax[4] : nullptr, tid, wave, lane, &hs.sred2[0]);
+        PSTAMP(son, 89);
         TileScale tsB = pair_handoff_exposed(accB, imgB, hs, SAVE ? &hs.lmax[4] : nullptr, tid, wave, lane, &hs.sred2[1]);
+        PSTAMP(son, 90);
         if (SAVE && tid == 0) hs.lmax[5] = fmaxf(hs.lmax[5], fmaxf(hs.sred2[0], hs.sred2[1]));
         if (SAVE) {
             aux_lds_to_native(saux[0], caux + tileA * AUXT_F, wave, lane);
             if (okB) aux_lds_to_native(saux[1], caux + tileB * AUXT_F, wave, lane);
         }
+        PSTAMP(son, 91);
+        // layer 0's weight slice: requested here, not by the previous pair's last phase -- 256 registers held across the output stage and
+        // the next prologue (sincosf, two tile loads, two hand-offs) were spilled to scratch and back
+        pw_load_all(W, C.main0, wave, lane);
+        PSTAMP(son, 1);
         _Pragma("unroll 1") for (int l = 0; l < 4; ++l) {
             const float wl = l == 0 ? winv0 : l == 1 ? winv1 : l == 2 ? winv2 : winv3;
             const float wp = l == 1 ? winv0 : l == 2 ? winv1 : winv2;                          // layer l - 1 (l >= 1)
@@ -188,37 +242,52 @@ __global__ __launch_bounds__(256, 1) void color_fwd_p_kernel(ColPPtrs C, const f
             } else {
                 ColFwdEpi<SAVE> e(accB, imgB, hs, SAVE ? &hs.lmax[l - 1] : nullptr, wave, lane, tid, tsB.inv * wp, p0, p1,
                                   tile_rsrc_if(cact + ((int64_t)(l - 1) * ntiles + tileB) * TILE_F, okB), loff, okB);
+                if (son && l == 2) e.stamp = 18;
                 pair_phase<false>(accA, imgA, W, C.main0 + (int64_t)l * COL_MAIN_STRIDE, C.main0, wave, lane, e);
                 tsB.S = e.S; tsB.inv = e.inv_S;
             }
+            PSTAMP(son, 2 + 4 * l);
             pair_barrier();
+            PSTAMP(son, 3 + 4 * l);
             // ---- phase 2: G_B(l) over A's epilogue of layer l; W takes layer l + 1 (after the last layer: the next pair's layer 0)
             acc_zero(accB);
             {
                 ColFwdEpi<SAVE> e(accA, imgA, hs, SAVE ? &hs.lmax[l] : nullptr, wave, lane, tid, tsA.inv * wl, c0, c1,
                                   tile_rsrc(cact + ((int64_t)l * ntiles + tileA) * TILE_F), loff, true);
-                pair_phase<true>(accB, imgB, W, C.main0 + (int64_t)l * COL_MAIN_STRIDE, C.main0 + (int64_t)((l + 1) & 3) * COL_MAIN_STRIDE, wave, lane, e);
+                if (son && l == 2) e.stamp = 52;
+                pair_phase<true>(accB, imgB, W, C.main0 + (int64_t)l * COL_MAIN_STRIDE, C.main0 + (int64_t)(l < 3 ? l + 1 : 3) * COL_MAIN_STRIDE, wave, lane, e);
                 if (l == 0) gemm_rows_aux_h(accB, saux[1], C.aux, wave, lane, tsB.S);
                 tsA.S = e.S; tsA.inv = e.inv_S;
             }
+            PSTAMP(son, 4 + 4 * l);
             pair_barrier();
+            PSTAMP(son, 5 + 4 * l);
         }
+        // the colour head's three rows go to LDS for the output stage (the extras' image of tile A is dead since layer 0): requested
+        // here, written behind B's last epilogue
+        const float w4a = C.w4[tid], w4b = C.w4[256 + tid], w4c = C.w4[512 + tid];
         {   // B's epilogue of the last layer, with nothing above it
             ColFwdEpi<SAVE> e(accB, imgB, hs, SAVE ? &hs.lmax[3] : nullptr, wave, lane, tid, tsB.inv * winv3, bs[3][0], bs[3][1],
                               tile_rsrc_if(cact + ((int64_t)3 * ntiles + tileB) * TILE_F, okB), loff, okB);
             pair_epi_alone_from<0>(e);
             tsB.S = e.S; tsB.inv = e.inv_S;
         }
+        float* sw4 = saux[0];
+        sw4[tid] = w4a; sw4[256 + tid] = w4b; sw4[512 + tid] = w4c;
         __syncthreads();
+        PSTAMP(son, 86);
         DH_UNROLL for (int which = 0; which < 2; ++which) {
             const int64_t gp = (which ? tileB : tileA) * TM + tid / TPP;
             const float sinv = which ? tsB.inv : tsA.inv;
+            float dots[3];
+            row_dot256x3_hp(which ? imgB : imgA, sw4, tid, dots);
             DH_UNROLL for (int j = 0; j < 3; ++j) {
-                const float raw = fmaf(row_dot256_hp(which ? imgB : imgA, C.w4 + j * 256, tid), sinv, C.b4[j]);
+                const float raw = fmaf(dots[j], sinv, C.b4[j]);
                 if (tid % TPP == 0 && gp < npts && (which == 0 || okB)) color[gp * 3 + j] = 1.f / (1.f + __expf(-raw));
             }
         }
         __syncthreads();
+        PSTAMP(son, 87);
     }
     if (SAVE && absmax) {
         if (tid < 4) post_class_max(absmax, ABSMAX_CACT + tid, hs.lmax[tid]);
@@ -248,69 +317,52 @@ static inline SdfGradPPtrs make_sdfgradp_ptrs(const float* packed) {
 // float4s arrive through a register ring, requested RING groups ahead), the saved tile asave[l-1], the running maxima
 // (of the tile for the hand-off, of the activations for the range watch), then the hand-off into the tile's image
 template <bool SAVE>
-struct SdfGradEpi : PHandoff {
-    static constexpr int MID = P_NKC / 2;
+struct SdfGradEpi : PEpi<SdfGradEpi<SAVE>, 5, 3> {
+    static constexpr int RING = 5;  // float4s of the activation tile in flight (5 groups = 25 MFMA gaps ahead)
     f32x16 (&acc)[MT][2];
-    _Float16* img;
     HScratchP& hs;
     float* lmax;
     const int wave, lane, tid;
     const float inv;
-    const rsrc_t hr, st;           // act[l-1] (read), asave[l-1] (written)
+    const rsrc_t hr, st;           // act[l-1] (read), asave[l-1] (written; a 0-record descriptor where this tile stores nothing)
     const int loff;
-    const bool store;
     float& hmax;
-    float m0 = 0.f, m1 = 0.f, inv_S = 0.f;
     float sa = 0.f, sb = 0.f;
-    unsigned hl[2];
-    static constexpr int RING = 5;  // float4s of the activation tile in flight (5 groups = 30 MFMA gaps ~ 1,000 cycles ahead)
     f32x4 hq[RING];
     __device__ __forceinline__ SdfGradEpi(f32x16 (&acc_)[MT][2], _Float16* img_, HScratchP& hs_, float* lmax_, int wave_, int lane_, int tid_,
-                                          float inv_, rsrc_t hr_, rsrc_t st_, int loff_, bool store_, float& hmax_)
-        : acc(acc_), img(img_), hs(hs_), lmax(lmax_), wave(wave_), lane(lane_), tid(tid_), inv(inv_), hr(hr_), st(st_), loff(loff_),
-          store(store_), hmax(hmax_) {
+                                          float inv_, rsrc_t hr_, rsrc_t st_, int loff_, bool, float& hmax_)
+        : acc(acc_), hs(hs_), lmax(lmax_), wave(wave_), lane(lane_), tid(tid_), inv(inv_), hr(hr_), st(st_), loff(loff_), hmax(hmax_) {
+        this->handoff_init(img_, wave_, lane_);
         DH_UNROLL for (int g = 0; g < RING; ++g) hq[g] = tile_ld(hr, loff, g);       // groups 0 .. RING-1 (float4 index == group index)
     }
-    template <int SL>
-    __device__ __forceinline__ void step() {
-        if constexpr (SL < MID * 12) {
-            constexpr int g = SL / 6, sub = SL % 6, m = g / 8, t = (g / 4) % 2, r4 = g % 4;
-            constexpr float C = -SOFTPLUS_BETA * 1.44269504088896f;
-            const f32x4& h = hq[g % RING];
-            if constexpr (sub == 0 || sub == 2) {
-                constexpr int i = sub;                                               // values i, i + 1 of the group
-                if constexpr (sub == 0) { hmax = fmaxf(hmax, fmaxf(h[0], h[1])); hmax = fmaxf(hmax, fmaxf(h[2], h[3])); }
-                sa = 1.f - __builtin_amdgcn_exp2f(h[i] * C);                         // softplus_deriv_from_h
-                sb = 1.f - __builtin_amdgcn_exp2f(h[i + 1] * C);
-            } else if constexpr (sub == 1 || sub == 3) {
-                constexpr int r = 4 * r4 + (sub - 1);
-                acc[m][t][r] *= sa * inv;
-                acc[m][t][r + 1] *= sb * inv;
-            } else if constexpr (sub == 4) {
-                if constexpr (SAVE) {
-                    f32x4 v;
-                    v[0] = acc[m][t][4 * r4 + 0]; v[1] = acc[m][t][4 * r4 + 1]; v[2] = acc[m][t][4 * r4 + 2]; v[3] = acc[m][t][4 * r4 + 3];
-                    tile_st(st, loff, g, v);
-                }
-                if constexpr (g + RING < 16) hq[g % RING] = tile_ld(hr, loff, g + RING);
-            } else {
-                m0 = fmaxf(m0, fmaxf(fabsf(acc[m][t][4 * r4 + 0]), fabsf(acc[m][t][4 * r4 + 1])));
-                m1 = fmaxf(m1, fmaxf(fabsf(acc[m][t][4 * r4 + 2]), fabsf(acc[m][t][4 * r4 + 3])));
-            }
+    template <int G, int SUB>
+    __device__ __forceinline__ void elem() {
+        constexpr int m = G / 8, t = (G / 4) % 2, r4 = G % 4;
+        constexpr float C = -SOFTPLUS_BETA * 1.44269504088896f;
+        const f32x4& h = hq[G % RING];
+        if constexpr (SUB == 0 || SUB == 2) {
+            constexpr int i = SUB;                                               // values i, i + 1 of the group
+            if constexpr (SUB == 0) { hmax = fmaxf(hmax, fmaxf(h[0], h[1])); hmax = fmaxf(hmax, fmaxf(h[2], h[3])); }
+            sa = 1.f - __builtin_amdgcn_exp2f(h[i] * C);                         // softplus_deriv_from_h
+            sb = 1.f - __builtin_amdgcn_exp2f(h[i + 1] * C);
+        } else if constexpr (SUB == 1 || SUB == 3) {
+            constexpr int r = 4 * r4 + (SUB - 1);
+            acc[m][t][r] *= sa * inv;
+            acc[m][t][r + 1] *= sb * inv;
         } else {
-            constexpr int q = SL - MID * 12;
-            split_step<q / 3, q % 3>(acc, img, wave, lane, hl);
+            if constexpr (SAVE) {
+                f32x4 v;
+                v[0] = acc[m][t][4 * r4 + 0]; v[1] = acc[m][t][4 * r4 + 1]; v[2] = acc[m][t][4 * r4 + 2]; v[3] = acc[m][t][4 * r4 + 3];
+                tile_st(st, loff, G, v);
+            }
+            if constexpr (G + RING < 16) hq[G % RING] = tile_ld(hr, loff, G + RING);
+            this->m0 = fmaxf(this->m0, fmaxf(fabsf(acc[m][t][4 * r4 + 0]), fabsf(acc[m][t][4 * r4 + 1])));
+            this->m1 = fmaxf(this->m1, fmaxf(fabsf(acc[m][t][4 * r4 + 2]), fabsf(acc[m][t][4 * r4 + 3])));
         }
     }
-    __device__ __forceinline__ void mid() {
-        tile_max_publish(hs.sred, wave, lane, wave_max(fmaxf(m0, m1)));
-        pair_barrier();
-        const float m = tile_max_read(hs.sred);
-        if (tid == 0 && lmax) *lmax = fmaxf(*lmax, m);
-        const TileScale ts = scale_for_max(m);
-        S = ts.S;
-        inv_S = ts.inv;
-    }
+    __device__ __forceinline__ void publish(float wm) { tile_max_publish(hs.sred, wave, lane, wm); }
+    __device__ __forceinline__ float read_tile_max() { return tile_max_read(hs.sred); }
+    __device__ __forceinline__ void on_tile_max(float m) { if (tid == 0 && lmax) *lmax = fmaxf(*lmax, m); }
 };
 
 #ifndef GRAD_NREG
@@ -338,7 +390,11 @@ __global__ __launch_bounds__(256, 1) void sdf_grad_p_kernel(SdfGradPPtrs P, cons
     pw_load_all(W, P.rev7, wave, lane);
     _Float16* imgA = simg[0];
     _Float16* imgB = simg[1];
-    for (int64_t pr = blockIdx.x; pr < npairs; pr += gridDim.x) {
+    int pit = 0;
+    for (int64_t pr = blockIdx.x; pr < npairs; pr += gridDim.x, ++pit) {
+        const bool son = pit == 2;                                // (-DDH_STAMPS: the workgroup's third pair is stamped)
+        (void)son;
+        PSTAMP(son, 0);
         const int64_t tileA = 2 * pr;
         const bool okB = tileA + 1 < ntiles;
         const int64_t tileB = okB ? tileA + 1 : tileA;
@@ -375,6 +431,7 @@ __global__ __launch_bounds__(256, 1) void sdf_grad_p_kernel(SdfGradPPtrs P, cons
             __syncthreads();
             if (which) tsB = ts; else tsA = ts;
         }
+        PSTAMP(son, 1);
         _Pragma("unroll 1") for (int l = 7; l >= 1; --l) {
             // ---- phase 1: G_A(l) over B's epilogue of GEMM l + 1 (-> a_l of B)
             acc_zero(accA);
@@ -385,22 +442,28 @@ __global__ __launch_bounds__(256, 1) void sdf_grad_p_kernel(SdfGradPPtrs P, cons
                 SdfGradEpi<SAVE> e(accB, imgB, hs, &hs.lmax[l], wave, lane, tid, tsB.inv * winv(l + 1),
                                    tile_rsrc(act + ((int64_t)l * ntiles + tileB) * TILE_F),
                                    tile_rsrc_if(asave + ((int64_t)l * ntiles + tileB) * TILE_F, okB), loff, okB, hmax);
+                if (son && l == 5) e.stamp = 32;
                 pair_phase<false>(accA, imgA, W, rev(l), P.rev7, wave, lane, e);
                 tsB.S = e.S; tsB.inv = e.inv_S;
             }
             if (l == 4) skip_to_lds(0, imgA, tsA.inv * wi[4]);    // skip path of A; image A still holds a_4
+            PSTAMP(son, 2 + 4 * (7 - l));
             pair_barrier();
+            PSTAMP(son, 3 + 4 * (7 - l));
             // ---- phase 2: G_B(l) over A's epilogue of GEMM l (-> a_{l-1} of A); W takes rev[l - 1] (after l = 1: the next pair's rev[7])
             acc_zero(accB);
             {
                 SdfGradEpi<SAVE> e(accA, imgA, hs, &hs.lmax[l - 1], wave, lane, tid, tsA.inv * winv(l),
                                    tile_rsrc(act + ((int64_t)(l - 1) * ntiles + tileA) * TILE_F),
                                    tile_rsrc(asave + ((int64_t)(l - 1) * ntiles + tileA) * TILE_F), loff, true, hmax);
+                if (son && l == 5) e.stamp = 64;
                 pair_phase<true>(accB, imgB, W, rev(l), l == 1 ? P.rev7 : rev(l - 1), wave, lane, e);
                 if (l == 4) skip_to_lds(1, imgB, tsB.inv * wi[4]);    // skip path of B; image B holds a_4 until B's next epilogue
                 tsA.S = e.S; tsA.inv = e.inv_S;
             }
+            PSTAMP(son, 4 + 4 * (7 - l));
             pair_barrier();
+            PSTAMP(son, 5 + 4 * (7 - l));
         }
         {   // B's epilogue of GEMM 1 (-> a_0), with nothing above it
             SdfGradEpi<SAVE> e(accB, imgB, hs, &hs.lmax[0], wave, lane, tid, tsB.inv * wi[1],
@@ -409,6 +472,7 @@ __global__ __launch_bounds__(256, 1) void sdf_grad_p_kernel(SdfGradPPtrs P, cons
             tsB.S = e.S; tsB.inv = e.inv_S;
         }
         __syncthreads();
+        PSTAMP(son, 30);
         DH_UNROLL for (int which = 0; which < 2; ++which) {       // ge += a_0 W_0, then ge -> the tile's LDS aux image
             f32x16 g0[AUX_NTW];
             aux_zero(g0);
@@ -446,6 +510,7 @@ __global__ __launch_bounds__(256, 1) void sdf_grad_p_kernel(SdfGradPPtrs P, cons
             }
         }
         __syncthreads();
+        PSTAMP(son, 31);
     }
     if (SAVE && absmax && tid < 8) post_class_max(absmax, ABSMAX_ASAVE + tid, hs.lmax[tid]);
     if (absmax) {                                      // (also forward-only renders)
@@ -475,11 +540,9 @@ static inline ColBwdPPtrs make_colbwdp_ptrs(const float* packed) {
 // a register ring), the saved tile czbar[l-1], its column sums (bias gradient), the tile maximum (hand-off scale, tmax, class maximum)
 // and the hand-off; LAST (l = 0): featbar = hbar_0 / (S S_w), stored, its maximum published to sred2 -- no hand-off
 template <bool LAST>
-struct ColBwdEpi : PHandoff {
-    static constexpr int MID = P_NKC / 2;
+struct ColBwdEpi : PEpi<ColBwdEpi<LAST>, 4, 3, !LAST> {
     static constexpr int RING = 5;
     f32x16 (&acc)[MT][2];
-    _Float16* img;
     HScratchP& hs;
     float* lmax;
     unsigned* tslot;
@@ -489,73 +552,64 @@ struct ColBwdEpi : PHandoff {
     const rsrc_t hr, st;           // cact[l-1] (read; unused when LAST), czbar[l-1] / featbar (written)
     const int loff;
     const bool store;
-    float m0 = 0.f, m1 = 0.f, inv_S = 0.f, cs0 = 0.f, cs1 = 0.f;
-    unsigned hl[2];
+    float cs0 = 0.f, cs1 = 0.f;
     f32x4 hq[RING];
     __device__ __forceinline__ ColBwdEpi(f32x16 (&acc_)[MT][2], _Float16* img_, HScratchP& hs_, float* lmax_, unsigned* tslot_, float* csum_,
                                          int wave_, int lane_, int tid_, float inv_, rsrc_t hr_, rsrc_t st_, int loff_, bool store_)
-        : acc(acc_), img(img_), hs(hs_), lmax(lmax_), tslot(tslot_), csum(csum_), wave(wave_), lane(lane_), tid(tid_), inv(inv_), hr(hr_),
+        : acc(acc_), hs(hs_), lmax(lmax_), tslot(tslot_), csum(csum_), wave(wave_), lane(lane_), tid(tid_), inv(inv_), hr(hr_),
           st(st_), loff(loff_), store(store_) {
-        if constexpr (!LAST) { DH_UNROLL for (int g = 0; g < RING; ++g) hq[g] = tile_ld(hr, loff, g); }
-    }
-    template <int SL>
-    __device__ __forceinline__ void step() {
-        if constexpr (SL < MID * 12) {
-            constexpr int g = SL / 6, sub = SL % 6, m = g / 8, t = (g / 4) % 2, r4 = g % 4;
-            if constexpr (sub == 0 || sub == 1) {
-                constexpr int i = 2 * sub, r = 4 * r4 + i;
-                if constexpr (LAST) {
-                    acc[m][t][r] *= inv;
-                    acc[m][t][r + 1] *= inv;
-                } else {
-                    const f32x4& h = hq[g % RING];
-                    acc[m][t][r] = h[i] > 0.f ? acc[m][t][r] * inv : 0.f;
-                    acc[m][t][r + 1] = h[i + 1] > 0.f ? acc[m][t][r + 1] * inv : 0.f;
-                }
-            } else if constexpr (sub == 2) {
-                {
-                    f32x4 v;
-                    v[0] = acc[m][t][4 * r4 + 0]; v[1] = acc[m][t][4 * r4 + 1]; v[2] = acc[m][t][4 * r4 + 2]; v[3] = acc[m][t][4 * r4 + 3];
-                    tile_st(st, loff, g, v);
-                }
-                if constexpr (!LAST && g + RING < 16) hq[g % RING] = tile_ld(hr, loff, g + RING);
-            } else if constexpr (sub == 3) {
-                if constexpr (!LAST) {                          // tile_colsum's order: m, then r, per column t
-                    float& cs = t ? cs1 : cs0;
-                    cs += acc[m][t][4 * r4 + 0]; cs += acc[m][t][4 * r4 + 1]; cs += acc[m][t][4 * r4 + 2]; cs += acc[m][t][4 * r4 + 3];
-                }
-            } else if constexpr (sub == 4) {
-                m0 = fmaxf(m0, fmaxf(fabsf(acc[m][t][4 * r4 + 0]), fabsf(acc[m][t][4 * r4 + 1])));
-                m1 = fmaxf(m1, fmaxf(fabsf(acc[m][t][4 * r4 + 2]), fabsf(acc[m][t][4 * r4 + 3])));
-            }
-        } else if constexpr (!LAST) {
-            constexpr int q = SL - MID * 12;
-            split_step<q / 3, q % 3>(acc, img, wave, lane, hl);
+        if constexpr (!LAST) {
+            this->handoff_init(img_, wave_, lane_);
+            DH_UNROLL for (int g = 0; g < RING; ++g) hq[g] = tile_ld(hr, loff, g);
         }
     }
-    __device__ __forceinline__ void mid() {
-        const float wm = wave_max(fmaxf(m0, m1));
+    template <int G, int SUB>
+    __device__ __forceinline__ void elem() {
+        constexpr int m = G / 8, t = (G / 4) % 2, r4 = G % 4;
+        if constexpr (SUB == 0 || SUB == 1) {
+            constexpr int i = 2 * SUB, r = 4 * r4 + i;
+            if constexpr (LAST) {
+                acc[m][t][r] *= inv;
+                acc[m][t][r + 1] *= inv;
+            } else {
+                const f32x4& h = hq[G % RING];
+                acc[m][t][r] = h[i] > 0.f ? acc[m][t][r] * inv : 0.f;
+                acc[m][t][r + 1] = h[i + 1] > 0.f ? acc[m][t][r + 1] * inv : 0.f;
+            }
+        } else if constexpr (SUB == 2) {
+            f32x4 v;
+            v[0] = acc[m][t][4 * r4 + 0]; v[1] = acc[m][t][4 * r4 + 1]; v[2] = acc[m][t][4 * r4 + 2]; v[3] = acc[m][t][4 * r4 + 3];
+            tile_st(st, loff, G, v);
+            if constexpr (!LAST && G + RING < 16) hq[G % RING] = tile_ld(hr, loff, G + RING);
+            if constexpr (!LAST) {                              // tile_colsum's order: m, then r, per column t
+                float& cs = t ? cs1 : cs0;
+                cs += acc[m][t][4 * r4 + 0]; cs += acc[m][t][4 * r4 + 1]; cs += acc[m][t][4 * r4 + 2]; cs += acc[m][t][4 * r4 + 3];
+            }
+        } else {
+            this->m0 = fmaxf(this->m0, fmaxf(fabsf(acc[m][t][4 * r4 + 0]), fabsf(acc[m][t][4 * r4 + 1])));
+            this->m1 = fmaxf(this->m1, fmaxf(fabsf(acc[m][t][4 * r4 + 2]), fabsf(acc[m][t][4 * r4 + 3])));
+        }
+    }
+    __device__ __forceinline__ void publish(float wm) {
         if constexpr (LAST) {
             tile_max_publish(hs.sred2, wave, lane, wm);        // read behind the barrier that ends the pair
         } else {
             cs0 += __shfl_xor(cs0, 32); cs1 += __shfl_xor(cs1, 32);
             if (lane < 32 && store) { csum[64 * wave + lane] = cs0; csum[64 * wave + 32 + lane] = cs1; }
             tile_max_publish(hs.sred, wave, lane, wm);
-            pair_barrier();
-            const float m = tile_max_read(hs.sred);
-            if (tid == 0) {
-                *lmax = fmaxf(*lmax, m);
-                if (store) *tslot = __builtin_bit_cast(unsigned, m);
-            }
-            const TileScale ts = scale_for_max(m);
-            S = ts.S;
-            inv_S = ts.inv;
+        }
+    }
+    __device__ __forceinline__ float read_tile_max() { return tile_max_read(hs.sred); }
+    __device__ __forceinline__ void on_tile_max(float m) {
+        if (tid == 0) {
+            *lmax = fmaxf(*lmax, m);
+            if (store) *tslot = __builtin_bit_cast(unsigned, m);
         }
     }
 };
 
 #ifndef COLBWD_NREG
-#define COLBWD_NREG 10
+#define COLBWD_NREG 8
 #endif
 __global__ __launch_bounds__(256, 1) void color_bwd_p_kernel(ColBwdPPtrs C, const float* __restrict__ colors, const float* __restrict__ d_colors,
                                                             int64_t npts, const float* __restrict__ cact, float* __restrict__ czbar,
@@ -729,6 +783,15 @@ __global__ __launch_bounds__(256, 1) void color_bwd_p_kernel(ColBwdPPtrs C, cons
     }
 }
 
+}  // namespace dh
+#ifdef DH_STAMPS
+extern "C" int dh_dev_read_stamps_p(unsigned long long* host, long long n) {
+    const long long total = (long long)(sizeof(dh::dh_pstamps) / sizeof(unsigned long long));
+    if (n > total) n = total;
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(dh::dh_pstamps), (size_t)n * sizeof(unsigned long long)) == hipSuccess ? 0 : -3;
+}
+#endif
+namespace dh {
 // ------------------------------------------------------------------------------------------------ launchers
 static inline int okp() { return hipGetLastError() == hipSuccess ? 0 : -3; }
 // one workgroup per CU (156 KB of LDS): what the device offers, asked once per device

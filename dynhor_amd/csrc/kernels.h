@@ -49,10 +49,12 @@ int launch_sdf_bwd_h(const float* packed, const float* d_sdf, const float* pts, 
 enum : int { CHAIN_FORM_AUTO = 0, CHAIN_FORM_TILE = 1, CHAIN_FORM_PAIR = 2 };
 bool pair_form_available();
 int pair_form_cus();
-// the form a SPLIT_F16 stage launch of npts points takes: forced by the flag, else PAIR once every CU gets at least one pair
-inline bool use_pair_form(int form, int64_t npts) {
+// the form a SPLIT_F16 stage launch of npts points takes: forced by the flag; otherwise PAIR where the stage's pair form is the faster one
+// on the bench's launch (auto_pair: measured same-process A/Bs, profiles/r06_ab_chain_forms.json -- colour forward yes; input gradient and
+// colour backward no: their epilogues load a saved tile, and with one wave per SIMD nothing hides that latency) and every CU gets a pair
+inline bool use_pair_form(int form, int64_t npts, bool auto_pair) {
     if (form == CHAIN_FORM_PAIR) return true;
-    if (form == CHAIN_FORM_TILE) return false;
+    if (form == CHAIN_FORM_TILE || !auto_pair) return false;
     const int cus = pair_form_cus();
     return cus > 0 && (npts + TM - 1) / TM >= 2 * (int64_t)cus;
 }

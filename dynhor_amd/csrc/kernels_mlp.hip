@@ -392,7 +392,7 @@ int launch_sdf_grad(const float* packed, const float* pts, int64_t npts, const f
     const int form = arith >> 8;                              // include/dynhor_hip.h DH_CHAIN_FORM_*: 0 auto, 1 tile, 2 pair
     arith &= 0xff;
     if (arith == ARITH_F16) {
-        if (use_pair_form(form, npts)) return launch_sdf_grad_p(packed, pts, npts, act, asave, normals, save, gesave, reinterpret_cast<unsigned*>(absmax), stream);
+        if (use_pair_form(form, npts, false)) return launch_sdf_grad_p(packed, pts, npts, act, asave, normals, save, gesave, reinterpret_cast<unsigned*>(absmax), stream);
         return launch_sdf_grad_h(packed, pts, npts, act, asave, normals, save, gesave, reinterpret_cast<unsigned*>(absmax), grid, stream);
     }
     if (arith == ARITH_FP32) hipLaunchKernelGGL(sdf_grad_kernel, dim3(grid_for(npts, grid)), dim3(256), 0, stream, make_sdf_ptrs(packed), pts, npts, act, asave, normals, save, gesave);
@@ -405,7 +405,7 @@ int launch_color_fwd(const float* packed, const float* pts, const float* dirs, i
     const int form = arith >> 8;                              // include/dynhor_hip.h DH_CHAIN_FORM_*: 0 auto, 1 tile, 2 pair
     arith &= 0xff;
     if (arith == ARITH_F16) {
-        if (use_pair_form(form, npts)) return launch_color_fwd_p(packed, pts, dirs, n_per_ray, normals, feat, npts, color, cact, caux, save,
+        if (use_pair_form(form, npts, true)) return launch_color_fwd_p(packed, pts, dirs, n_per_ray, normals, feat, npts, color, cact, caux, save,
                                                                  reinterpret_cast<unsigned*>(absmax), stream);
         return launch_color_fwd_h(packed, pts, dirs, n_per_ray, normals, feat, npts, color, cact, caux, save,
                                   reinterpret_cast<unsigned*>(absmax), grid, stream);

@@ -685,7 +685,7 @@ int launch_color_bwd(const float* packed, const float* colors, const float* d_co
     arith &= 0xff;
     if (arith == ARITH_F16) {
         unsigned* am = reinterpret_cast<unsigned*>(absmax);
-        if (use_pair_form(form, npts)) return launch_color_bwd_p(packed, colors, d_colors, npts, cact, czbar, featbar, d_normals, tpart, am,
+        if (use_pair_form(form, npts, false)) return launch_color_bwd_p(packed, colors, d_colors, npts, cact, czbar, featbar, d_normals, tpart, am,
                                                                  am + ABSMAX_FLOATS, st);
         return launch_color_bwd_h(packed, colors, d_colors, nullptr, 1, npts, cact, czbar, featbar, d_normals, tpart, nullptr, nullptr, am,
                                   am + ABSMAX_FLOATS, grid, st);

@@ -173,6 +173,13 @@ __global__ __launch_bounds__(256, 2) void color_fwd_h_kernel(ColHPtrs C, const f
             const int64_t gp = tile * TM + tid;
             float* row = saux + tid * LDA;
             float mx = 1.f;                              // sin / cos of the view embedding
+            // The view embedding depends on the RAY only.  Where the tile's 64 points belong to one ray (training: 128 samples per ray)
+            // twelve lanes evaluate its twelve sincosf once and every row copies them through the wave -- same arguments, same bits
+            // (round 6: per point they cost this wave ~12 x 64 evaluations' worth of vector-ALU time per tile).
+            const int64_t first = tile * TM, last = first + TM - 1 < npts ? first + TM - 1 : npts - 1;
+            const bool one_ray = first / n_per_ray == last / n_per_ray;       // (wave-uniform)
+            float esin = 0.f, ecos = 0.f;
+            if (one_ray && lane < 12) sincosf(dirs[(first / n_per_ray) * 3 + lane % 3] * (float)(1 << (lane / 3)), &esin, &ecos);
             if (gp < npts) {
                 const int64_t ray = gp / n_per_ray;
                 DH_UNROLL for (int c = 0; c < 3; ++c) {
@@ -180,7 +187,13 @@ __global__ __launch_bounds__(256, 2) void color_fwd_h_kernel(ColHPtrs C, const f
                     row[c] = x;
                     row[3 + c] = d;
                     DH_UNROLL for (int k = 0; k < 4; ++k) {
-                        float s, co; sincosf(d * (float)(1 << k), &s, &co);
+                        float s, co;
+                        if (one_ray) {
+                            s = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, esin), 3 * k + c));
+                            co = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ecos), 3 * k + c));
+                        } else {
+                            sincosf(d * (float)(1 << k), &s, &co);
+                        }
                         row[6 + 6 * k + c] = s;
                         row[6 + 6 * k + 3 + c] = co;
                     }

@@ -17,14 +17,28 @@
 //   * a phase is 16 k-chunks x 12 MFMAs = 192 MFMA slots; the epilogue + hand-off of the other tile is written as 192 micro-steps
 //     (a few vector / LDS / memory instructions each) and dealt one per slot behind a scheduling barrier -- the way chain_t.hip deals
 //     its epilogue -- so nothing depends on how the compiler would interleave two independent instruction streams; the hand-off's
-//     tile-maximum barrier sits in front of chunk E::MID (`mid`: the epilogue type says where its elementwise part ends), the image
-//     barrier at the end of the phase;
+//     wave maximum, its tile-maximum barrier and the scale derivation are micro-steps of that stream too (PEpi below), the image
+//     barrier ends the phase;
 //   * per 128 points a layer costs 256 KB of L2 -> CU weight traffic (was 512), 4 LDS fragment reads per 12 MFMAs and wave (was 4 +
 //     4 weight loads), 4 barriers (was 8).
 // The arithmetic is tile16h.h's, value for value: same scales, same piece planes, same MFMA order inside a k-chunk, same epilogue
 // expressions -- a pair kernel writes bit-identical tiles to its kernels_mlp_h.hip twin (tests/test_gpu_pair_chains.py).
 #pragma once
 #include "tile16h.h"
+
+#ifdef DH_STAMPS                 // diagnostic build (scripts/stamps.sh): s_memtime stamps of the pair kernels' phases and of one phase's k-chunks
+namespace dh {
+constexpr int PSTAMP_SLOTS = 96;
+static __device__ unsigned long long dh_pstamps[256 * 4 * PSTAMP_SLOTS];
+}
+#define PSTAMP(on, slot)                                                                                               \
+    do {                                                                                                               \
+        if ((on) && (threadIdx.x & 63) == 0 && blockIdx.x < 256)                                                        \
+            dh::dh_pstamps[(blockIdx.x * 4 + (threadIdx.x >> 6)) * dh::PSTAMP_SLOTS + (slot)] = __builtin_readcyclecounter(); \
+    } while (0)
+#else
+#define PSTAMP(on, slot) do { } while (0)
+#endif
 
 namespace dh {
 
@@ -69,9 +83,8 @@ __device__ __forceinline__ void pair_barrier() { asm volatile("s_waitcnt lgkmcnt
 
 // an epilogue with nothing to do (phase 1 of a pair's first layer)
 struct PNoEpi {
-    static constexpr int MID = P_NKC / 2;
+    static constexpr int stamp = -1;
     template <int S> __device__ __forceinline__ void step() {}
-    __device__ __forceinline__ void mid() {}
 };
 
 template <int KC, int I, class E>
@@ -93,7 +106,7 @@ template <int KC, bool RELOAD, int NREG, class E>
 __device__ __forceinline__ void pair_chunks(f32x16 (&acc)[MT][2], const _Float16* xrow, PW<NREG>& W, rsrc_t wcur, rsrc_t wnext, int woff,
                                             H2 (&a0)[MT], H2 (&a1)[MT], E& e) {
     if constexpr (KC < P_NKC) {
-        if constexpr (KC == E::MID) { e.mid(); __builtin_amdgcn_sched_barrier(0); }
+        PSTAMP(e.stamp >= 0, e.stamp + 2 * KC);
         if constexpr (KC + 1 < P_NKC) pair_loada((KC & 1) ? a0 : a1, xrow, KC + 1);
         if constexpr (KC + 2 >= NREG && KC + 2 < P_NKC) pw_load_chunk<KC + 2>(W.wb[(KC + 2) % 3], wcur, woff);      // a streamed chunk, two ahead
         __builtin_amdgcn_sched_barrier(0);
@@ -121,41 +134,97 @@ __device__ __forceinline__ void pair_phase(f32x16 (&acc)[MT][2], const _Float16*
 template <int S, class E>
 __device__ __forceinline__ void pair_epi_alone_from(E& e) {
     if constexpr (S < P_SLOTS) {
-        if constexpr (S == E::MID * 12) e.mid();
         e.template step<S>();
         pair_epi_alone_from<S + 1>(e);
     }
 }
 
-// ---------------------------------------------------------------- the hand-off as micro-steps
-// Part 1 (slots 0 .. 95: the caller's elementwise epilogue, 16 groups (m, t, r4) of four values, 6 slots each) leaves the tile's
-// final values in acc and the wave's running maxima in (m0, m1); mid(): wave maximum -> sred[wave] -> barrier -> tile scale;
-// part 2 (slots 96 .. 191): 32 value pairs x 3 slots: scale + convert | residuals + convert | four 16-bit LDS writes
-// (acc_to_lds_split's expressions, pair by pair).
-struct PHandoff {
-    float S;
-    template <int J, int SUB>                        // pair J = 0 .. 31 of the wave's 64 values: (m, t, r = 2 (J % 8)), sub-step 0 .. 2
-    __device__ __forceinline__ void split_step(const f32x16 (&acc)[MT][2], _Float16* img, int wave, int lane, unsigned (&hl)[2]) {
-        constexpr int m = J / 16, t = (J / 8) % 2, r = 2 * (J % 8);
-        if constexpr (SUB == 0) {
-            f32x2 x;
-            x[0] = acc[m][t][r] * S;
-            x[1] = acc[m][t][r + 1] * S;
-            hl[0] = pack_f16x2(x);
-            // (the residual needs x again: recomputed in sub-step 1 from the same product -- bit-identical, one multiply pair more,
-            // two registers less across the MFMA in between)
-        } else if constexpr (SUB == 1) {
-            f32x2 x;
-            x[0] = acc[m][t][r] * S;
-            x[1] = acc[m][t][r + 1] * S;
-            hl[1] = pack_f16x2(resid_f16x2(x, hl[0]));
-        } else {
-            _Float16* base = img + (m * 32 + 4 * (lane >> 5)) * LDH + acc_col(wave, t, lane);
-            _Float16* q = base + ((r & 3) + 8 * (r >> 2)) * LDH;
-            const f16x2v hv = __builtin_bit_cast(f16x2v, hl[0]), lv = __builtin_bit_cast(f16x2v, hl[1]);
-            q[0] = hv[0]; q[LDH] = hv[1];
-            q[PLANE_H] = lv[0]; q[PLANE_H + LDH] = lv[1];
+// ---------------------------------------------------------------- an epilogue + hand-off as 192 micro-steps
+// The slot program of a tile's epilogue (CRTP: D supplies the elementwise part and what happens to the tile's maximum):
+//   slots [0, 16 SPG)            : D::elem<G, SUB>() -- 16 groups G = (m, t, r4) of four accumulator values, SPG slots each; leaves the
+//                                  tile's final values in acc and updates the running maxima m0 / m1;
+//   the next 12 slots (MIDSEQ)   : 0-5 the six DPP steps of the wave maximum, 6 readlane + D::publish(wave max) (-> sred[wave]),
+//                                  7 the tile-maximum barrier, 8 the four maxima read back, 9 D::on_tile_max(max) + the tile scale;
+//   then 32 value pairs x SP2    : scale, convert, residuals, convert (acc_to_lds_split's expressions, the pair = rows R, R+1 of this
+//                                  lane's column packed into one dword per plane) | lanes 2i / 2i+1 (columns n, n+1) trade halves --
+//                                  one DPP quad swap + one v_perm_b32 per plane -- so that the even lane holds row R's two columns and
+//                                  the odd lane row R+1's | each writes ONE 32-bit word per plane: 2 ds_write_b32 instead of 4
+//                                  ds_write_b16, the same halves in the same places.
+// One wave per SIMD hides about five single-issue instructions per MFMA gap (MI355X_MICROARCH.md "one wave per SIMD"): SPG / SP2 spread
+// an epilogue's instructions accordingly.  (Stamps of the first version -- 4 ds_write_b16 in every third slot, the maximum and its
+// barrier between two chunks -- read 600 cycles per hand-off chunk against 384 of MFMA time and ~1,000 exposed at the barrier:
+// profiles/r06_pair_stamps_color_fwd_v1.json.)
+constexpr int P_MIDSEQ = 12;
+template <class D, int SPG_, int SP2_, bool HANDOFF = true>
+struct PEpi {
+    static constexpr int SPG = SPG_, SP2 = SP2_, P1 = 16 * SPG_;
+    static_assert(P1 + P_MIDSEQ + (HANDOFF ? 32 * SP2_ : 0) <= P_SLOTS, "the epilogue's slot program must fit a phase");
+    static_assert(SP2_ == 3 || SP2_ == 4, "");
+    float S = 0.f, inv_S = 0.f, m0 = 0.f, m1 = 0.f, wm = 0.f;
+    unsigned xsel;                 // v_perm_b32 selector of this lane's parity
+    _Float16* wbase;               // this lane's word of image row 4 (lane >> 5) [+ 1 for odd lanes], columns (n & ~1, n | 1) of n-tile 0
+    unsigned hl[2], wd[2];
+    f32x2 xs;
+    int stamp = -1;                // (-DDH_STAMPS: first slot of this phase's k-chunk stamps; -1: none)
+    __device__ __forceinline__ D& d() { return *static_cast<D*>(this); }
+    __device__ __forceinline__ void handoff_init(_Float16* img, int wave, int lane) {
+        xsel = (lane & 1) ? 0x03020706u : 0x05040100u;
+        wbase = img + (4 * (lane >> 5) + (lane & 1)) * LDH + (acc_col(wave, 0, lane) & ~1);
+    }
+    template <int K>
+    __device__ __forceinline__ void mid_stage() {
+        if constexpr (K == 0) wm = wave_max_step<0x111, 0xf>(fmaxf(m0, m1));
+        else if constexpr (K == 1) wm = wave_max_step<0x112, 0xf>(wm);
+        else if constexpr (K == 2) wm = wave_max_step<0x114, 0xf>(wm);
+        else if constexpr (K == 3) wm = wave_max_step<0x118, 0xf>(wm);
+        else if constexpr (K == 4) wm = wave_max_step<0x142, 0xa>(wm);
+        else if constexpr (K == 5) wm = wave_max_step<0x143, 0xc>(wm);
+        else if constexpr (K == 6) { wm = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wm), 63)); d().publish(wm); }
+        else if constexpr (K == 7) { if constexpr (HANDOFF) pair_barrier(); }
+        else if constexpr (K == 8) { if constexpr (HANDOFF) wm = d().read_tile_max(); }
+        else if constexpr (K == 9) {
+            if constexpr (HANDOFF) {
+                d().on_tile_max(wm);
+                const TileScale ts = scale_for_max(wm);
+                S = ts.S;
+                inv_S = ts.inv;
+            }
         }
+    }
+    // the 13 operations of pair J = (m, t, r = 2 (J % 8)) over SP2 slots
+    template <int J, int OP>
+    __device__ __forceinline__ void split_op(const f32x16 (&acc)[MT][2]) {
+        constexpr int m = J / 16, t = (J / 8) % 2, r = 2 * (J % 8);
+        if constexpr (OP == 0) { xs[0] = acc[m][t][r] * S; xs[1] = acc[m][t][r + 1] * S; hl[0] = pack_f16x2(xs); }
+        else if constexpr (OP == 1) hl[1] = pack_f16x2(resid_f16x2(xs, hl[0]));
+        else if constexpr (OP == 2) {
+            DH_UNROLL for (int p = 0; p < 2; ++p) {
+                const unsigned nb = (unsigned)__builtin_amdgcn_update_dpp(0, (int)hl[p], 0xB1, 0xf, 0xf, false);      // quad_perm [1,0,3,2]
+                wd[p] = __builtin_amdgcn_perm(nb, hl[p], xsel);
+            }
+        } else {
+            _Float16* q = wbase + (m * 32 + (r & 3) + 8 * (r >> 2)) * LDH + 32 * t;
+            *reinterpret_cast<unsigned*>(q) = wd[0];
+            *reinterpret_cast<unsigned*>(q + PLANE_H) = wd[1];
+        }
+    }
+    template <int Q>
+    __device__ __forceinline__ void split_slot(const f32x16 (&acc)[MT][2]) {
+        constexpr int J = Q / SP2, sub = Q % SP2;
+        if constexpr (J < 32) {
+            if constexpr (SP2 == 4) split_op<J, sub>(acc);
+            else {                                   // three slots: convert | residual + exchange | write
+                if constexpr (sub == 0) split_op<J, 0>(acc);
+                else if constexpr (sub == 1) { split_op<J, 1>(acc); split_op<J, 2>(acc); }
+                else split_op<J, 3>(acc);
+            }
+        }
+    }
+    template <int SL>
+    __device__ __forceinline__ void step() {
+        if constexpr (SL < P1) d().template elem<SL / SPG, SL % SPG>();
+        else if constexpr (SL < P1 + P_MIDSEQ) mid_stage<SL - P1>();
+        else if constexpr (HANDOFF) split_slot<SL - P1 - P_MIDSEQ>(d().acc);
     }
 };
 

@@ -57,12 +57,13 @@ typedef enum { DH_ARITH_SPLIT_BF16 = 0, DH_ARITH_FP32_MFMA = 1, DH_ARITH_SPLIT_F
 /* Chain FORM of a DH_ARITH_SPLIT_F16 stage (round 6; csrc/pair16h.h).  The stages listed below exist in two kernel forms that write
  * bit-identical results: the TILE form (csrc/kernels_mlp_h.hip: one 64-point tile per workgroup, two workgroups per CU, weights
  * streamed from L2 per tile) and the PAIR form (csrc/chain_pair.hip: one workgroup per CU owns two tiles, holds a layer's weight slice
- * in registers across both and runs one tile's epilogue under the other's MFMAs: half the L2 -> CU weight bytes per point).  By default
- * a launch of at least 2 x #CUs tiles (32,768 points on MI355X) runs the PAIR form, a smaller one the TILE form (a pair workgroup
- * occupies a whole CU).  OR one of these flags into the `arithmetic` argument of the stage's `_ex` entry point to force a form (tests,
- * A/Bs); the PAIR form returns DH_ERR_UNSUPPORTED on a device without 160 KB of LDS per CU.  Stages with a PAIR form:
- * dh_sdf_gradient_ex, dh_color_forward_ex, dh_color_backward_ex (not its pose-refinement form dh_color_backward_rays_ex).  Every other
- * entry point rejects the flags (DH_ERR_BAD_ARG). */
+ * in registers across both and runs one tile's epilogue under the other's MFMAs: half the L2 -> CU weight bytes per point).  OR one of
+ * these flags into the `arithmetic` argument of the stage's `_ex` entry point to force a form (tests, A/Bs); without a flag the stage
+ * takes the form that measured faster on the bench's launch: dh_color_forward_ex the PAIR form for launches of at least 2 x #CUs tiles
+ * (32,768 points on MI355X; a pair workgroup occupies a whole CU), dh_sdf_gradient_ex and dh_color_backward_ex the TILE form (their pair
+ * forms are 5-20 % slower: DESIGN.md section 3).  The PAIR form returns DH_ERR_UNSUPPORTED on a device without 160 KB of LDS per CU.
+ * Stages with a PAIR form: dh_sdf_gradient_ex, dh_color_forward_ex, dh_color_backward_ex (not its pose-refinement form
+ * dh_color_backward_rays_ex).  Every other entry point rejects the flags (DH_ERR_BAD_ARG). */
 enum { DH_CHAIN_FORM_TILE = 0x100, DH_CHAIN_FORM_PAIR = 0x200 };
 int dh_set_arithmetic(int mode);
 int dh_get_arithmetic(void);

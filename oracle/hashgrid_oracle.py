@@ -27,6 +27,8 @@ PRIMES = (1, 2654435761, 805459861)
 
 
 class HashGridEncoding(nn.Module):
+    MAX_ROWS_PER_GATHER = 1 << 18           # points per index_select (x 128 corner rows x 2 features: 256 MB in fp32, 512 MB in fp64)
+
     def __init__(self, n_levels=16, n_features=2, log2_hashmap_size=19, base_resolution=16, max_resolution=2048):
         super().__init__()
         self.L, self.F, self.T = n_levels, n_features, 1 << log2_hashmap_size
@@ -67,6 +69,10 @@ class HashGridEncoding(nn.Module):
         zero-fills a table-sized (98 MB) gradient in its backward, 128 times per evaluation and 7 evaluations per sample -- 0.45 s per
         2048-ray training iteration on a MI355X, which priced a paired PSNR seed of the hash family at 15 GPU-minutes (round 6)."""
         n = x01.shape[0]
+        if n > self.MAX_ROWS_PER_GATHER:
+            # chunked: the gathered rows of one call stay below 2^31 bytes -- round 6: at 1.5 M points in fp64 (3.2 GB of rows) the GPU
+            # index_select returned rows of the wrong entries (the fp32 call of the same size, 1.6 GB, and every CPU call are correct)
+            return torch.cat([self.forward(x01[i:i + self.MAX_ROWS_PER_GATHER]) for i in range(0, n, self.MAX_ROWS_PER_GATHER)], dim=0)
         idxs, ws = [], []
         for l in range(self.L):
             pos = x01 * self.scales[l] + 0.5

@@ -138,39 +138,48 @@ def test_non_finite_or_out_of_range_contributions_turn_the_whole_table_gradient_
 
 
 def test_many_sub_limit_contributions_on_one_entry_end_in_the_guard_band_not_in_a_wrapped_sum():
-    """Coarse-level entries collect thousands of adds per launch.  Scale the adjoint so that the largest entry's SUM passes 2^14 while
-    (for the smaller scales) every single add stays below the per-contribution limit: the entry must be NaN; wherever an entry is
-    finite it must be the scaled float-atomic value (a wrapped int64 would be finite and wrong by ~2^16)."""
+    """16,384 samples at ONE position: every level's eight corner entries collect all of them.  Consecutive samples of a wave are merged
+    before they reach memory (16 per add), so an entry's sum is 1,024 adds of equal size.  Scale the adjoint so that the largest
+    entry's SUM passes 2^14 = 16,384 while every single add stays below the per-contribution limit of 64: the entry must be NaN (a
+    wrapped int64 -- what round 5's limit of 16,384 per contribution allowed -- would be finite and wrong by ~2^16); every entry whose
+    sum stays below the guard band must be finite and equal to the scaled float-atomic value."""
+    from dynhor_amd import _lib
+    from dynhor_amd.renderer import _p
     o_r, p_r = make_hash_pair(seed=7)
-    B = 256
-    rays_o, rays_d, near, far = _rays(B, seed=5)
-    ntab = p_r.store.table_floats
+    L, st = _lib.lib(), p_r.store
+    N = 16384
+    pts = torch.tensor([[0.1234, -0.2345, 0.3456]], device="cuda").repeat(N, 1).contiguous()
+    ws = p_r._workspace(N, infer_only=False)
+    sdf = torch.empty(N, device="cuda"); feat = torch.empty(N, 13, device="cuda"); nrm = torch.empty(N, 3, device="cuda")
+    packed = st.ensure_packed()
+    stream = _lib.stream()
+    _lib.check(L.dh_hash_geo_forward(_p(st.flat), _p(packed), _p(pts), N, p_r.radius, p_r.fd_eps, _p(ws), 1, _p(sdf), _p(feat), _p(nrm), None, stream))
+    ntab = st.table_floats
+    d_feat = torch.zeros(N, 13, device="cuda"); d_n = torch.zeros(N, 3, device="cuda")
 
-    def table_grad(scale, rep):
-        p_r.reproducible_table_grad = rep
-        out = p_r.render(rays_o, rays_d, near, far, cos_anneal_ratio=0.5)
-        (out["color_fine"].sum() * scale).backward()
+    def table_grad(scale, parts):
+        d_sdf = torch.full((N,), float(scale), device="cuda")
+        _lib.check(L.dh_hash_geo_backward(_p(st.flat), _p(packed), _p(pts), _p(d_sdf), _p(d_feat), _p(d_n), N, p_r.radius, p_r.fd_eps, _p(ws),
+                                          None, stream))
+        g = torch.full((st.n,), float("nan"), device="cuda")
+        _lib.check(L.dh_hash_weight_grads_parts(_p(st.flat), _p(packed), N, _p(ws), _p(g), None, parts, stream))
         torch.cuda.synchronize()
-        return p_r.store.grad_flat[:ntab].clone()
-    g1 = table_grad(1.0, False).double()
+        return g[:ntab].clone()
+    g1 = table_grad(1.0, 1).double()                               # float atomics, unit adjoint
     gmax = g1.abs().max().item()
-    seen_guard_only = False
+    assert torch.isfinite(g1).all() and gmax > 0
     for target in (1.2 * 2 ** 14, 2.0 * 2 ** 14, 2.9 * 2 ** 14):
         s = target / gmax
-        got = table_grad(s, True)
+        got = table_grad(s, 5)
         want = g1 * s
         over = want.abs() >= 2 ** 14 * 1.001
         under = want.abs() <= 2 ** 14 * 0.999
         assert over.any()
+        assert not torch.isnan(got).all(), f"target {target:.3g}: a single add of {target / 1024:.1f} tripped the per-contribution limit of 64"
         assert torch.isnan(got[over]).all(), "an entry whose sum passed 2^14 came back finite"
-        if torch.isnan(got).all():
-            print(f"target {target:.3g}: a single add passed 64 -> whole table NaN (flag path)")
-            continue
-        seen_guard_only = True
         fin = torch.isfinite(got)
         assert fin[under].all()
         rel = ((got[fin].double() - want[fin]).abs().max() / want.abs().max()).item()
         print(f"target {target:.3g}: {int(over.sum())} entries in the guard band are NaN, the other {int(fin.sum())} finite, max |d| / max |g| {rel:.2e}")
         assert rel < 1e-5
-    assert seen_guard_only, "no scale exercised the guard band alone: every one tripped the single-contribution flag"
-    assert torch.isfinite(table_grad(1.0, True)).all()
+    assert torch.isfinite(table_grad(1.0, 5)).all()

@@ -129,7 +129,7 @@ def test_the_default_form_follows_the_size_rule_and_the_flags_are_checked(hiplib
     big = 64 * 2 * cus + 64
     packed, pts, dirs = _setup(hiplib, big, 128, seed=4)
     c_auto, ws_auto, n_auto = _forward(hiplib, packed, pts, dirs, 128, 0, 1, 0)
-    c_pair, ws_pair, n_pair = _forward(hiplib, packed, pts, dirs, 128, PAIR, 1, PAIR)
+    c_pair, ws_pair, n_pair = _forward(hiplib, packed, pts, dirs, 128, PAIR, 1, TILE)
     assert torch.equal(n_auto, n_pair)
     assert torch.equal(c_auto, c_pair) and torch.equal(ws_auto, ws_pair)
     # flags with another arithmetic, two flags at once, a flag on a stage without a pair form: refused
