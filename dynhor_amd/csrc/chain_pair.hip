@@ -205,7 +205,7 @@ __global__ __launch_bounds__(256, 1) void color_fwd_p_kernel(ColPPtrs C, const f
                 if (lane == 0) hs.sred2[which] = mx;
             }
             if (oneA || oneB) {                                  // (uniform) the tile's other wave must see emb: copy behind a barrier
-                __syncthreads();
+                pair_barrier();
                 if (one_ray && gp < npts) { DH_UNROLL for (int j = 0; j < 12; ++j) row[6 + 12 * half + j] = emb[12 * half + j]; }
             }
         }
@@ -249,13 +249,13 @@ __global__ __launch_bounds__(256, 1) void color_fwd_p_kernel(ColPPtrs C, const f
             PSTAMP(son, 2 + 4 * l);
             pair_barrier();
             PSTAMP(son, 3 + 4 * l);
-            // ---- phase 2: G_B(l) over A's epilogue of layer l; W takes layer l + 1 (after the last layer: the next pair's layer 0)
+            // ---- phase 2: G_B(l) over A's epilogue of layer l; W takes layer l + 1 (after the last layer: nothing -- a 0-record reload)
             acc_zero(accB);
             {
                 ColFwdEpi<SAVE> e(accA, imgA, hs, SAVE ? &hs.lmax[l] : nullptr, wave, lane, tid, tsA.inv * wl, c0, c1,
                                   tile_rsrc(cact + ((int64_t)l * ntiles + tileA) * TILE_F), loff, true);
                 if (son && l == 2) e.stamp = 52;
-                pair_phase<true>(accB, imgB, W, C.main0 + (int64_t)l * COL_MAIN_STRIDE, C.main0 + (int64_t)(l < 3 ? l + 1 : 3) * COL_MAIN_STRIDE, wave, lane, e);
+                pair_phase<true>(accB, imgB, W, C.main0 + (int64_t)l * COL_MAIN_STRIDE, C.main0 + (int64_t)(l < 3 ? l + 1 : 3) * COL_MAIN_STRIDE, wave, lane, e, l < 3);
                 if (l == 0) gemm_rows_aux_h(accB, saux[1], C.aux, wave, lane, tsB.S);
                 tsA.S = e.S; tsA.inv = e.inv_S;
             }
@@ -274,7 +274,7 @@ __global__ __launch_bounds__(256, 1) void color_fwd_p_kernel(ColPPtrs C, const f
         }
         float* sw4 = saux[0];
         sw4[tid] = w4a; sw4[256 + tid] = w4b; sw4[512 + tid] = w4c;
-        __syncthreads();
+        pair_barrier();
         PSTAMP(son, 86);
         DH_UNROLL for (int which = 0; which < 2; ++which) {
             const int64_t gp = (which ? tileB : tileA) * TM + tid / TPP;
@@ -286,7 +286,7 @@ __global__ __launch_bounds__(256, 1) void color_fwd_p_kernel(ColPPtrs C, const f
                 if (tid % TPP == 0 && gp < npts && (which == 0 || okB)) color[gp * 3 + j] = 1.f / (1.f + __expf(-raw));
             }
         }
-        __syncthreads();
+        pair_barrier();
         PSTAMP(son, 87);
     }
     if (SAVE && absmax) {

@@ -118,9 +118,11 @@ __device__ __forceinline__ void pair_chunks(f32x16 (&acc)[MT][2], const _Float16
 }
 // One phase.  acc += img[TM x 256] x (the linear at wcur, its first NREG chunks from W); e's 192 micro-steps dealt under the MFMAs;
 // RELOAD: W takes the linear at `wnext` chunk by chunk.  The caller places the phase-ending pair_barrier().
+// reload_on = false: the reload's loads go through a 0-record descriptor -- no memory traffic, zeros into registers nobody reads (the
+// pair's last layer: one code form of phase 2 for every layer, see chain_pair.hip)
 template <bool RELOAD, int NREG, class E>
 __device__ __forceinline__ void pair_phase(f32x16 (&acc)[MT][2], const _Float16* img, PW<NREG>& W, const u32x4* wcur, const u32x4* wnext,
-                                           int wave, int lane, E& e) {
+                                           int wave, int lane, E& e, bool reload_on = true) {
     const _Float16* xrow = img + (lane & 31) * LDH + 8 * (lane >> 5);
     const rsrc_t rc = weight_rsrc(wcur);
     const int woff = pw_lane_off(wave, lane);
@@ -128,7 +130,8 @@ __device__ __forceinline__ void pair_phase(f32x16 (&acc)[MT][2], const _Float16*
     pair_loada(a0, xrow, 0);
     if constexpr (NREG < 1) pw_load_chunk<0>(W.wb[0], rc, woff);
     if constexpr (NREG < 2) pw_load_chunk<1>(W.wb[1], rc, woff);
-    pair_chunks<0, RELOAD>(acc, xrow, W, rc, weight_rsrc(wnext), woff, a0, a1, e);
+    const rsrc_t rn = __builtin_amdgcn_make_buffer_rsrc(const_cast<u32x4*>(wnext), 0, reload_on ? 0x40000000 : 0, 0x00020000);
+    pair_chunks<0, RELOAD>(acc, xrow, W, rc, rn, woff, a0, a1, e);
 }
 // the same micro-steps with no GEMM above them (a pair's last epilogue)
 template <int S, class E>

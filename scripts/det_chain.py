@@ -33,6 +33,10 @@ STAGE_REGIONS = {
     "sdf_tangent": ["absmax", "tmax", "t0aux", "tsave", "rsave", "tpart"],
     "sdf_backward": ["absmax", "tmax", "zbar", "tpart"],
 }
+# round 6: the tile-PAIR forms (csrc/chain_pair.hip) by name -- "color_forward" itself runs the pair form at this size by default; the
+# "_tile" / "_pair" names force a form through the DH_CHAIN_FORM_* flags
+for _k in ("sdf_gradient", "color_forward", "color_backward"):
+    STAGE_REGIONS[_k + "_pair"] = STAGE_REGIONS[_k + "_tile"] = STAGE_REGIONS[_k]
 
 
 def main():
@@ -40,7 +44,7 @@ def main():
     ap.add_argument("n", type=int, nargs="?", default=2000)
     ap.add_argument("--lib", type=str, default=None)
     ap.add_argument("--arith", type=int, default=2)
-    ap.add_argument("--stages", type=str, default=",".join(list(STAGE_REGIONS) + ["sdf_nograd"]))
+    ap.add_argument("--stages", type=str, default="sdf_forward,sdf_gradient,color_forward,color_backward,sdf_tangent,sdf_backward,sdf_nograd")
     ap.add_argument("--out", type=str, default=None)
     args = ap.parse_args()
     from dynhor_amd import _lib
@@ -77,9 +81,15 @@ def main():
     dn_work = dn.clone()
     sdf_ng = torch.empty(P, device="cuda:0")
 
-    def col_bwd():
+    def col_bwd(form=0):
         dn_work.copy_(dn)                   # colour backward ACCUMULATES into d_normals
-        return L.dh_color_backward_ex(AR, _p(packed), _p(s.colors), _p(cap["d_colors"]), P, _p(s.ws), _p(dn_work), stream)
+        return L.dh_color_backward_ex(AR | form, _p(packed), _p(s.colors), _p(cap["d_colors"]), P, _p(s.ws), _p(dn_work), stream)
+    TILE, PAIR = 0x100, 0x200
+    forms = {}
+    for tag, fl in (("_tile", TILE), ("_pair", PAIR)):
+        forms["sdf_gradient" + tag] = (lambda fl=fl: L.dh_sdf_gradient_ex(AR | fl, _p(packed), _p(s.pts), P, _p(s.ws), _p(s.normals), 1, stream), [s.normals])
+        forms["color_forward" + tag] = (lambda fl=fl: L.dh_color_forward_ex(AR | fl, _p(packed), _p(s.pts), _p(s.rays_d), s.n, _p(s.normals), P, _p(s.ws), _p(s.colors), 1, stream), [s.colors])
+        forms["color_backward" + tag] = (lambda fl=fl: col_bwd(fl), [dn_work])
     stages = {
         "sdf_forward": (lambda: L.dh_sdf_forward_ex(AR, _p(packed), _p(s.pts), P, _p(s.ws), _p(s.sdf), stream), [s.sdf]),
         "sdf_gradient": (lambda: L.dh_sdf_gradient_ex(AR, _p(packed), _p(s.pts), P, _p(s.ws), _p(s.normals), 1, stream), [s.normals]),
@@ -89,6 +99,7 @@ def main():
         "sdf_backward": (lambda: L.dh_sdf_backward_ex(AR, _p(packed), _p(cap["d_sdf"]), P, _p(s.ws), stream), []),
         "sdf_nograd": (lambda: L.dh_sdf_nograd_ex(AR, _p(packed), _p(s.pts), P, _p(sdf_ng), stream), [sdf_ng]),
     }
+    stages.update(forms)
     regs = regions(nt)
     res = {"lib": args.lib or "libdynhor_hip.so", "arith": AR, "launches": args.n, "points": P, "stages": {}}
     # order matters for the workspace state: a stage's inputs must be what the previous full step left (sdf_forward clears absmax and

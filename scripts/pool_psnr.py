@@ -1,18 +1,22 @@
 """Pool paired-seed PSNR records of scripts/psnr_parity.py into one file (the record bench.py's `psnr_at_2k` cites).
-    python scripts/pool_psnr.py OUT.json IN1.json IN2.json ... [--what "text"] [--arithmetic split_f16]"""
+    python scripts/pool_psnr.py OUT.json IN1.json IN2.json ... [--what "text"] [--arithmetic split_f16] [--family hash] [--note "text"]"""
 import json
 import statistics
 import sys
 
 args = sys.argv[1:]
-what, arith = None, "split_f16"
-for flag in ("--what", "--arithmetic"):
+what, arith, family, note = None, "split_f16", "neus", None
+for flag in ("--what", "--arithmetic", "--family", "--note"):
     if flag in args:
         i = args.index(flag)
         val = args[i + 1]
         del args[i:i + 2]
         if flag == "--what":
             what = val
+        elif flag == "--family":
+            family = val
+        elif flag == "--note":
+            note = val
         else:
             arith = val
 out, ins = args[0], args[1:]
@@ -32,13 +36,14 @@ for f in ins:
     files.append(f.split("/")[-1])
     win += d["window_delta"]["per_seed"]
     fin += d["final_delta"]["per_seed"]
+    seeds += [r["seed"] for r in d.get("seeds", []) if isinstance(r, dict) and "seed" in r]
     if "delta_4f_independent_renderers" in d:
         shared += d["delta_4f_shared_renderer"]["per_seed"]
         indep += d["delta_4f_independent_renderers"]["per_seed"]
-res = {"family": "neus", "mode": "hip_vs_oracle", "arithmetic": arith, "files": files,
+res = {"family": family, "mode": "hip_vs_oracle", "arithmetic": arith, "files": files, **({"note": note} if note else {}),
        "what": what or f"HIP ({arith}) minus oracle (GPU-eager PyTorch), paired seeds (ray stream + initial weights per seed, shared by both "
                        "arms), PSNR = masked MSE over ALL 64 frames in a window of checkpoints at 1800..2000 iterations, 2048 rays x (64+64)",
-       "window_delta": summ(win), "final_delta": summ(fin)}
+       "seeds": seeds, "window_delta": summ(win), "final_delta": summ(fin)}
 if indep:
     res["independent_evaluator_4_frames_final_checkpoint"] = {
         "what": "the same four frames: HIP arm by the HIP renderer minus oracle arm by the HIP renderer (shared) / by the ORACLE's own renderer "

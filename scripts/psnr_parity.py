@@ -15,6 +15,7 @@ handful of low-resolution frames cannot resolve 0.1 dB.  This script therefore
       hip_noise_floor     the HIP path vs itself with initial weights perturbed by 1e-7 relative (chaos only: no kernel differs)
       oracle_noise_floor  the oracle vs itself, same perturbation
       hip_scatter         (hash family) shipping table scatter vs the unmerged per-evaluation scatter
+      hip_torch_adam      the HIP kernels' gradients stepped by torch.optim.Adam vs by the fused dh_adam_step (hybrid: isolates the optimiser)
       hip_occgrid_vs_hierarchical  (hash family) occupancy-grid marching vs the NeuS sampler: a quality report, not parity
   * --lockstep K: the HIP arm takes the oracle's weights and Adam state every K iterations; per segment it reports the loss
     difference on the first step (pure kernel error), its growth over the segment (chaos) and the SIGNED mean difference
@@ -48,10 +49,13 @@ def make_runner(family, weight_seed, batch, frames, res, dev, tag, hash_sampler=
 
 class HipArm:
     """The product path: HIP fused training step + fused Adam."""
-    def __init__(self, runner, arithmetic=None, scatter_mode=None):
+    def __init__(self, runner, arithmetic=None, scatter_mode=None, torch_adam=False):
         self.r, self.arith, self.scatter = runner, arithmetic, scatter_mode
         self.seconds = 0.0
         self.eval_through_scratch = False
+        # torch_adam: the HIP kernels' flat gradient stepped by stock torch.optim.Adam on the flat vector instead of the fused dh_adam_step
+        # (a hybrid arm: separates the optimiser from the kernels when an HIP-vs-oracle difference is being located)
+        self.torch_adam, self._opt, self._p = torch_adam, None, None
 
     def _modes(self):
         if self.arith is not None:
@@ -63,7 +67,18 @@ class HipArm:
     def step(self, rays, near, far, R, car, lr, t_rand):
         self._modes()
         stats = self.r.renderer.train_step_core(rays, near, far, R, car, *LOSS_W, t_rand=t_rand)
-        self.r.store.adam_step(lr)
+        if self.torch_adam:
+            st = self.r.store
+            if self._opt is None:
+                self._p = torch.nn.Parameter(st.flat)            # shares the flat vector's storage
+                self._opt = torch.optim.Adam([self._p], lr=lr)
+            for g in self._opt.param_groups:
+                g["lr"] = lr
+            self._p.grad = st.grad_flat
+            self._opt.step()
+            st.bump()
+        else:
+            self.r.store.adam_step(lr)
         return stats[0], stats[5]
 
     def eval_runner(self, scratch):
@@ -166,6 +181,7 @@ def oracle_render_psnr(arm, ds, it, frames, level):
 ARM_NAMES = {"hip_vs_oracle": ("hip", "oracle_gpu_eager"), "oracle_noise_floor": ("oracle_perturbed_1e-7", "oracle"),
              "hip_vs_hip_f32": ("hip_split_f16", "hip_fp32_mfma"), "hip_vs_hip_bf16": ("hip_split_f16", "hip_split_bf16"), "hip_noise_floor": ("hip_perturbed_1e-7", "hip"),
              "hip_scatter": ("hip_scatter_merged", "hip_scatter_per_evaluation"),
+             "hip_torch_adam": ("hip_kernels_torch_adam", "hip_kernels_fused_adam"),
              "hip_occgrid_vs_hierarchical": ("hip_occgrid_sampler", "hip_hierarchical_sampler")}
 
 
@@ -197,6 +213,8 @@ def run_seed(args, seed, dev):
             A, B = HipArm(r_a), HipArm(r_b); A.perturb(1e-7, 5)
         elif mode == "hip_scatter":
             A, B = HipArm(r_a, scatter_mode=0), HipArm(r_b, scatter_mode=2)
+        elif mode == "hip_torch_adam":
+            A, B = HipArm(r_a, torch_adam=True), HipArm(r_b)
         elif mode == "hip_occgrid_vs_hierarchical":      # a QUALITY report of the two samplers (hash family), not a parity claim
             A, B = HipArm(r_a), HipArm(r_b)
             if args.eval_sampler == "hierarchical":      # both arms' weights rendered by the hierarchical sampler

@@ -13,7 +13,7 @@ import os
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LINES = sorted(glob.glob(os.path.join(ROOT, "profiles", "r05_bench_n1*.json")))
+LINES = sorted(glob.glob(os.path.join(ROOT, "profiles", "r05_bench_n1*.json")) + glob.glob(os.path.join(ROOT, "profiles", "r06_bench_n1*.json")))
 
 
 def _load(path):
@@ -23,6 +23,27 @@ def _load(path):
 
 def test_a_round_5_bench_line_is_committed():
     assert LINES, "profiles/r05_bench_n1*.json: the verbatim line(s) of `python bench.py` on one MI355X"
+
+
+def test_the_round_6_headline_carries_its_own_parity_measurement_and_names_the_matrix_pipe():
+    """Round 6 (VERDICT r5 next #5a, #8): `parity_check` is MEASURED by the run that printed the line (a 50-iteration lock-step segment
+    against the GPU-eager oracle, outside the timed region), `psnr_at_2k` says that it is a committed quote, `mfma_dtype` names the pipe
+    beside `dtype`, `bound_in_this_design` rides beside section 8(d)'s `bound`, and the occupancy-grid line carries its PSNR deficit."""
+    path = os.path.join(ROOT, "profiles", "r06_bench_n1.json")
+    if not os.path.exists(path):
+        pytest.skip("profiles/r06_bench_n1.json not committed yet")
+    d = _load(path)
+    assert d["dtype"] == "f32" and d["mfma_dtype"].startswith("f16 (2-piece split, 3 products")
+    pc = d["parity_check"]
+    assert pc["measured_in_this_run"] is True and pc["iters"] == 50 and pc["pass"] is True
+    assert abs(pc["first_step_loss_diff"]) <= 5e-6 and abs(pc["signed_segment_mean"]) <= 1e-4
+    assert d["psnr_at_2k"]["measured_in_this_run"] is False and "COMMITTED" in d["psnr_at_2k"]["label"]
+    r = d["roofline"]
+    assert r["bound"] == "mfma" and r["bound_in_this_design"] in ("hbm", "mfma") and "bound_basis" in r
+    assert (r["bound_in_this_design"] == "hbm") == ("HBM-bound" in r["design_floor"]["why"])
+    occ = d["secondary"]["hash_occgrid"]["psnr_vs_hierarchical_db"]
+    assert occ["measured_in_this_run"] is False and occ["mean"] < -0.3 and occ["seeds"] >= 8
+    assert d["kernels"]["color_forward"]["kernel"] == "color_fwd_p_kernel"
 
 
 @pytest.mark.parametrize("path", LINES, ids=[os.path.basename(p) for p in LINES])
@@ -44,7 +65,7 @@ def test_bench_line_schema(path):
     if "split_f16" in path or "2-way fp16" in d["config"]["arithmetic"]:
         assert abs(r["peak"] - 2500.0 / 3.0) < 0.1 and "three-product" in r["peak_basis"]
     assert abs(r["achieved"] - r["algorithmic_flop"] / (r["avg_launch_ms"] * 1e-3) / 1e12) < 0.02 * r["achieved"]
-    assert r["algorithmic_flop"] == 2 * 1254656 * 2048 * 128 or r["stage"] != "weight_grads_gemm"
+    assert r["algorithmic_flop"] == 2 * 1254656 * d["config"]["rays_per_rank"] * 128 or r["stage"] != "weight_grads_gemm"
     # the design's own HBM floor beside it, under its own name
     f = r["design_floor"]
     assert set(f) >= {"design_bytes", "achieved_gbps", "frac_of_hbm_peak_8000", "frac_of_achievable_6290", "why"}

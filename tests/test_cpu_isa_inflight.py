@@ -102,6 +102,53 @@ def test_tile_resident_chains_fit_two_workgroups_per_cu_and_do_not_spill_in_thei
     _no_register_soffset_on_wide_stores(text)
 
 
+@pytest.mark.skipif(shutil.which("hipcc") is None, reason="hipcc not installed")
+def test_pair_chains_keep_scratch_out_of_their_phases_and_fit_one_workgroup_per_cu(tmp_path):
+    """The tile-pair chains (chain_pair.hip, round 6): one workgroup per CU -- two piece-plane images + two aux images within 160 KB --
+    and a weight slice held in registers across a layer's two phases.  A phase is 192 MFMAs with the other tile's epilogue dealt
+    between them: whatever the compiler keeps in scratch (a few loop invariants; the slice itself once was: 250 registers through
+    scratch and back, until the first layer's slice was requested per pair) must stay OUTSIDE the phases -- a scratch reload inside
+    one waits on vmcnt(0) and drains every tile load, tile store and weight reload in flight, with ONE wave per SIMD to hide it."""
+    import re
+    out = tmp_path / "chain_pair.s"
+    subprocess.run(LISTING + [os.path.join(ROOT, "dynhor_amd", "csrc", "chain_pair.hip"), "-o", str(out)], check=True, timeout=900,
+                   stderr=subprocess.DEVNULL)
+    text = out.read_text()
+    kernels = re.findall(r"^(_ZN2dh\w+):(.*?); ScratchSize: (\d+).*?; LDSByteSize: (\d+)", text, flags=re.S | re.M)
+    want = ("color_fwd_p_kernel", "sdf_grad_p_kernel", "color_bwd_p_kernel")
+    seen = set()
+    for name, body, scratch, lds in kernels:
+        hit = [w for w in want if w in name]
+        if not hit:
+            continue
+        seen.add(hit[0])
+        assert int(lds) <= 160 * 1024, (name, lds)
+        assert int(scratch) <= 128, (name, scratch)
+        lines = [l.strip() for l in body.split("\n")]
+        idx = [i for i, l in enumerate(lines) if l.startswith("v_mfma")]
+        assert len(idx) >= 3 * 192, (name, len(idx))
+        # runs of MFMAs no more than 40 lines apart = phases (a k-chunk boundary carries 4 LDS reads, 4 weight loads and waits)
+        runs, start = [], 0
+        for j in range(1, len(idx) + 1):
+            if j == len(idx) or idx[j] - idx[j - 1] > 40:
+                runs.append((idx[start], idx[j - 1], j - start))
+                start = j
+        phases = [r for r in runs if r[2] >= 150]
+        # between two MFMAs of a k-chunk (its 12 slots carry a few epilogue instructions each) nothing touches scratch -- in any pair
+        # kernel; the form that SHIPS by default (colour forward) keeps its phases free of scratch altogether, chunk boundaries included
+        # (the other two reload one loop invariant between two phases)
+        for a, b in zip(idx, idx[1:]):
+            if b - a <= 12:
+                assert not any(l.startswith("scratch_") for l in lines[a:b]), (name, lines[a:b])
+        if "color_fwd_p_kernel" in name:
+            assert len(phases) >= 2 and sum(r[2] for r in phases) >= 3 * 192, (name, [r[2] for r in runs])
+            for a, b, n in phases:
+                bad = [l for l in lines[a:b] if l.startswith("scratch_")]
+                assert not bad, (name, n, bad[:3])
+    assert seen == set(want), seen
+    _no_register_soffset_on_wide_stores(text)
+
+
 def _no_register_soffset_on_wide_stores(text):
     """hipcc (ROCm 7.2) guards the data registers of a buffer_store_dwordx3/x4 against an immediately following vector write only
     when soffset is an immediate; with a REGISTER soffset gfx950 stored the overwritten values (profiles/r04_ab_chain_io.json).
