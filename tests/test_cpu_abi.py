@@ -148,11 +148,11 @@ def test_committed_profiles_name_the_shipping_kernels():
     for stage, e in traffic.items():
         assert ship.get(stage) == e["kernel"], (stage, e["kernel"], ship.get(stage))
     names = set()
-    for r in csv.DictReader(open(os.path.join(ROOT, "profiles", "r04_kernel_stats.csv"))):
+    for r in csv.DictReader(open(os.path.join(ROOT, "profiles", "r06_kernel_stats.csv"))):
         names.add(re.sub(r"[<(].*", "", re.sub(r"^dh::", "", re.sub(r"^void ", "", r["Name"]))))
     missing = sorted(set(ship.values()) - names)
-    assert not missing, f"profiles/r04_kernel_stats.csv lacks shipping kernels {missing}"
-    line = json.loads(open(os.path.join(ROOT, "profiles", "r04_bench_n1.json")).read().strip().split("\n")[-1])
+    assert not missing, f"profiles/r06_kernel_stats.csv lacks shipping kernels {missing}"
+    line = json.loads(open(os.path.join(ROOT, "profiles", "r06_bench_n1.json")).read().strip().split("\n")[-1])
     assert line["roofline"]["kernel"] == ship[line["roofline"]["stage"]]
     for stage, v in line["kernels"].items():
         if "kernel" in v:
