@@ -19,6 +19,8 @@
 //   (10 KB); the embedding image of a wave's 32 points stays in LDS for the skip layer.
 //   The training kernel writes the tiles of sdf_fwd_train_kernel (tile.h native layout, 64 points): an m-tile's activations are
 //   transposed through a wave-private LDS patch (lane-per-point -> four consecutive points per lane) on their way out.
+//   (Round 6, the fp16 form: the transposition runs on the matrix pipe instead -- T_SAVE_MFMA below -- and only the feature tile
+//   still crosses the patch.)
 // Arithmetic (template parameter AR): TArB3 = the same six bf16 products per fp32 product, smallest terms first, as tile16.h;
 // TArH2 (round 4) = tile16h.h's two fp16 pieces / three products: a stage is 16 KB (two pieces), the chain carries its activations
 // scaled by H2_XS = 16 (bias rows pre-scaled, softplus evaluated in the scaled variable: same operation count, bit-identical
@@ -55,6 +57,16 @@ struct TArH2 {                                   // two fp16 pieces, three produ
 };
 constexpr int T_EMB_LD = 52;                     // floats per point of the embedding image (48 + pad: b128 reads of 16 rows conflict free)
 constexpr int T_EMB_BYTES = 32 * T_EMB_LD * 4;   // per wave: its 32 points x [39 embedding values, zero padded to 48]
+// How the training kernel's fp16 form turns an m-tile (lane-per-point) into a native tile (lane-per-feature).  1 (round 6): on the
+// MATRIX pipe -- the m-tile's finished pieces (the next layer's B operand: lane = point, slots = features) are fed as the A operand
+// of four more MFMAs against a constant selector (1/16 where slot and output column name the same feature): D[point][feature] =
+// (hi + lo) / 16 in accumulator layout, which IS the native tile's layout; no LDS patch, no vector instruction.  The saved value is
+// the activation the next layer consumed (hi + lo: the fp32 activation to 2^-22, each product and both adds exact), and a consumer
+// that splits it again gets the same two pieces back.  0: through the wave-private LDS patch (16 ds_write_b32 + 4 ds_read_b128 per
+// m-tile; rounds 3-5; bf16x3 always) -- the fp32 activation itself.
+#ifndef T_SAVE_MFMA
+#define T_SAVE_MFMA 1
+#endif
 constexpr int T_PATCH_LD = 40;                   // floats per feature row of the transposition patch (4 * 40 % 64 == 32: the two half-waves' writes hit different banks)
 constexpr int T_PATCH_BYTES = 32 * T_PATCH_LD * 4;
 static_assert(T_STREAM_STAGES_TRAIN * TArB3::STAGE_BYTES == PACKT_STREAM_FLOATS * 4, "layout.h PACKT");
@@ -80,11 +92,15 @@ struct TAcc { f32x16 s[2][T_NM]; };
 // epilogue state.  b = the pair's biases (the next pair's are read into the same registers right after their last use).  Training
 // kernel only: patch_wr = the lane's write address in the patch, hd = pair 0's activations on their way to the patch
 // (TArH2: isw = 1 / S_w of the layer whose accumulators the epilogue reads)
-struct TEpi { f32x2 x, t, e, u, b, hd; unsigned bias_addr, patch_wr; float isw; };
+// (DOT -- the training kernel's lin8 layer, T_SAVE_MFMA form: w = the pair's weights of lin8's row 0, s0 / s1 = the sdf's two partial sums)
+struct TEpi { f32x2 x, t, e, u, b, hd, w; unsigned bias_addr, patch_wr; float isw, s0, s1; };
 // saving an m-tile as a native tile (tile.h): patch_rd = the lane's read address in the patch, v = two float4 in flight, rsrc =
 // buffer descriptor of the native tile (wave-uniform; zero records when the tile does not exist -- ragged last tile -- so the
 // hardware drops the stores), loff = the lane's byte offset in it (its half of the tile and its lane slot)
-struct TSave { f32x4 v[2]; unsigned patch_rd, loff; __amdgpu_buffer_rsrc_t rsrc; };
+// (T_SAVE_MFMA form: d = the transposed m-tile, sel = the selector fragments of the m-tile's two k-steps; v / patch_rd unused)
+struct TSave { f32x4 v[2]; unsigned patch_rd, loff; __amdgpu_buffer_rsrc_t rsrc; f32x16 d; u32x4 sel[2]; };
+template <class C> constexpr bool t_save_mfma() { return C::TRAIN && C::AR::H && T_SAVE_MFMA; }
+template <class C> constexpr bool t_save_patch() { return C::TRAIN && !t_save_mfma<C>(); }
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t t_tile_rsrc(const void* tile, bool ok, int bytes) {
 #ifdef T_PROBE_DROP_STORES                               // timing probe: zero records, the hardware drops every tile store (same instructions)
     ok = false;
@@ -174,7 +190,11 @@ constexpr int t_epi_pair_writes(int j) {                 // all writes of pair j
     return n;
 }
 static_assert(t_epi_writes<true>(1, 0) + t_epi_writes<true>(1, 1) + t_epi_writes<false>(1, 0) + t_epi_writes<false>(1, 1) == 0, "a patch write before the bias read");
-template <int M, int STEP, bool NEXT, bool SAVE>
+// DOT: the layer is lin8 of the training kernel -- its epilogue's activations are softplus(lin7), and lin8's row 0 (the sdf; bias
+// table row 8, one row behind lin7's biases) is formed on them as they pass: even values into s0, odd into s1, m-tiles and values
+// ascending -- t_final_dot's order, bit for bit, without evaluating the softplus a second time.  The pair's weights are read in
+// step 9 of the previous pair (behind their last use in step 8) and have landed by the wait that ends that pair's group.
+template <int M, int STEP, bool NEXT, bool SAVE, bool DOT>
 __device__ __forceinline__ void t_epi_step_h(const f32x16& x, TPieces<TArH2> (&out)[2], TEpi& st) {
     constexpr int j = STEP / 12, s = STEP % 12, half = j / 4, q = j % 4, r0 = 2 * j;
     constexpr int PW = (8 * (r0 / 4) + r0 % 4) * T_PATCH_LD * 4;
@@ -194,9 +214,14 @@ __device__ __forceinline__ void t_epi_step_h(const f32x16& x, TPieces<TArH2> (&o
     else if constexpr (s == 8) {
         const unsigned h = pack_f16x2(st.x); out[half].p[0][q] = h; st.u = resid_f16x2(st.x, h);
         if constexpr (SAVE && t_epi_writes_h(j, s)) t_lds_write_b32<0>(st.patch_wr, st.hd[0]);       // pair 0's, deferred
+        if constexpr (DOT) { st.s0 = fmaf(st.x[0], st.w[0], st.s0); st.s1 = fmaf(st.x[1], st.w[1], st.s1); }
     }
     else if constexpr (s == 9) {
         out[half].p[1][q] = pack_f16x2(st.u);
+        if constexpr (DOT) {
+            if constexpr (j < 7) t_bias_read<M, j + 1, 1024>(st.w, st.bias_addr);
+            else if constexpr (NEXT) t_bias_read<M + 1, 0, 1024>(st.w, st.bias_addr);
+        }
         if constexpr (SAVE && t_epi_writes_h(j, s)) t_lds_write_b32<T_PATCH_LD * 4>(st.patch_wr, st.hd[1]);
     }
     else if constexpr (s == 10) {
@@ -208,9 +233,10 @@ __device__ __forceinline__ void t_epi_step_h(const f32x16& x, TPieces<TArH2> (&o
     }
     else { if constexpr (SAVE && t_epi_writes_h(j, s)) t_lds_write_b32<PW + T_PATCH_LD * 4>(st.patch_wr, st.t[1]); }
 }
-template <class AR, int M, int STEP, bool NEXT, bool SAVE>
+template <class AR, int M, int STEP, bool NEXT, bool SAVE, bool DOT>
 __device__ __forceinline__ void t_epi_step(const f32x16& x, TPieces<AR> (&out)[2], TEpi& st) {
-    if constexpr (AR::H) { t_epi_step_h<M, STEP, NEXT, SAVE>(x, out, st); return; } else {
+    static_assert(AR::H || !DOT, "the fp16 form only");
+    if constexpr (AR::H) { t_epi_step_h<M, STEP, NEXT, SAVE, DOT>(x, out, st); return; } else {
     constexpr int j = STEP / 12, s = STEP % 12, half = j / 4, q = j % 4, r0 = 2 * j;
     constexpr int PW = (8 * (r0 / 4) + r0 % 4) * T_PATCH_LD * 4;           // patch row of value r0 (this lane's 4 h rows are in patch_wr)
     if constexpr (s == 0) { st.x[0] = x[r0] + st.b[0]; }
@@ -294,6 +320,31 @@ template <int M, int R4>
 __device__ __forceinline__ void t_save_store(const TSave& sv) {
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, sv.v[R4 & 1]), sv.rsrc, sv.loff + 4 * t_native_off(M, R4), 0, 2);     // nt, as DH_TILE_ST
 }
+// T_SAVE_MFMA form: float4 R4 of the transposed m-tile = points 8 R4 + 4 h + (0..3) of this lane's feature
+template <int M, int R4>
+__device__ __forceinline__ void t_save_store_d(const TSave& sv) {
+    const f32x4 v = {sv.d[4 * R4 + 0], sv.d[4 * R4 + 1], sv.d[4 * R4 + 2], sv.d[4 * R4 + 3]};
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), sv.rsrc, sv.loff + 4 * t_native_off(M, R4), 0, 2);
+}
+// transposition MFMA I (0..3) of the m-tile whose pieces are bs (k-steps 2M, 2M+1): lo of k-step 0, lo of k-step 1, hi, hi --
+// every output element receives exactly one non-zero product per MFMA: lo / 16, then + hi / 16 (exact in fp32)
+template <int I>
+__device__ __forceinline__ void t_save_mfma_step(TSave& sv, const TPieces<TArH2> (&bs)[2]) {
+    constexpr int ks = I % 2, piece = I < 2 ? 1 : 0;
+    if constexpr (I == 0) {
+        const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        sv.d = mfma_h(bs[ks].p[piece], sv.sel[ks], z);
+    } else sv.d = mfma_h(bs[ks].p[piece], sv.sel[ks], sv.d);
+}
+// selector fragment of k-step ks (0, 1) of an m-tile, as a B operand: lane (n, h) slot i = 1/16 iff n == 16 ks + 8 (i / 4) + 4 h + i % 4
+__device__ __forceinline__ u32x4 t_selector(int n, int h, int ks) {
+    const int t = n - 16 * ks - 4 * h;                     // 0..3 -> slot t, 8..11 -> slot t - 4
+    const bool ok = (t >= 0 && t < 4) || (t >= 8 && t < 12);
+    const int i = t < 8 ? t : t - 4;
+    u32x4 e;
+    DH_UNROLL for (int q = 0; q < 4; ++q) e[q] = (ok && (i >> 1) == q) ? (0x2C00u << (16 * (i & 1))) : 0u;      // fp16 1/16 = 0x2C00
+    return e;
+}
 
 // MFMA I (0 .. 2 NPROD - 1) of group G (m-tiles 2G, 2G+1) into set NB: product-major, consecutive MFMAs hit different accumulators
 template <class AR, int NB, int G, int I>
@@ -305,17 +356,18 @@ __device__ __forceinline__ void t_mfma_step(TAcc& A, const TFrag<AR> (&a)[2], co
 // set (-1: none) and which half EH of its 96 micro-steps; ENEXT: m-tile EM + 1 follows; SM (training kernel): the m-tile whose
 // patch is complete -- two of its float4 are read in group 0 and stored in group 1, the other two read in group 1 and stored in
 // group 2 (-1: none)
-template <class C_, int NB_, int EM_, int EH_, bool ENEXT_, int SM_>
+template <class C_, int NB_, int EM_, int EH_, bool ENEXT_, int SM_, bool DOT_ = false>
 struct TK {
     using C = C_;
     static constexpr int NB = NB_, EM = EM_, EH = EH_, SM = SM_;
-    static constexpr bool ENEXT = ENEXT_;
+    static constexpr bool ENEXT = ENEXT_, DOT = DOT_;
 };
 // the 2 NPROD MFMAs of group G, each followed by its share of the dealt work (12 / (2 NPROD) epilogue micro-steps); DA / DB: the
 // LDS-DMA piece issued after MFMA 3 / 9 (TArB3) or DA after MFMA 2 (TArH2)   (-1: none)
 template <class K, int G, int DA, int DB, int I>
 __device__ __forceinline__ void t_group_steps(TAcc& A, const TFrag<typename K::C::AR> (&a)[2], const TPieces<typename K::C::AR>& b,
-                                              TPieces<typename K::C::AR> (&bn)[2], TEpi& st, TRing& R, TSave& sv) {
+                                              const TPieces<typename K::C::AR> (&bs)[2], TPieces<typename K::C::AR> (&bn)[2], TEpi& st,
+                                              TRing& R, TSave& sv) {
     using AR = typename K::C::AR;
     constexpr int NMF = 2 * AR::NPROD, EPS = 12 / NMF, DAI = AR::H ? 2 : 3;
     if constexpr (I < NMF) {
@@ -326,7 +378,12 @@ __device__ __forceinline__ void t_group_steps(TAcc& A, const TFrag<typename K::C
 #ifdef T_PROBE_NO_SAVE_READS_STORES                      // timing probe: no patch reads, no tile stores in the dealt stream
         if constexpr (false) {
 #else
-        if constexpr (K::C::TRAIN && K::SM >= 0 && I < 4) {
+        if constexpr (t_save_mfma<typename K::C>() && K::SM >= 0 && I < 4) {
+            // the m-tile on the matrix pipe: four MFMAs behind group 0's first four, the stores where the patch form has them
+            if constexpr (G == 0) { t_save_mfma_step<I>(sv, bs); __builtin_amdgcn_sched_barrier(0); }
+            if constexpr (G == 1 && I < 2) { t_save_store_d<K::SM, I>(sv); __builtin_amdgcn_sched_barrier(0); }
+            if constexpr (G == 2 && I < 2) { t_save_store_d<K::SM, I + 2>(sv); __builtin_amdgcn_sched_barrier(0); }
+        } else if constexpr (K::C::TRAIN && K::SM >= 0 && I < 4) {
 #endif
             if constexpr (G == 0 && I < 2) { t_lds_read<32 * I>(sv.v[I], sv.patch_rd); __builtin_amdgcn_sched_barrier(0); }
             if constexpr (G == 1 && I < 2) { t_save_store<K::SM, I>(sv); __builtin_amdgcn_sched_barrier(0); }
@@ -334,11 +391,11 @@ __device__ __forceinline__ void t_group_steps(TAcc& A, const TFrag<typename K::C
             if constexpr (G == 2 && I < 2) { t_save_store<K::SM, I + 2>(sv); __builtin_amdgcn_sched_barrier(0); }
         }
         if constexpr (K::EM >= 0 && K::EM < T_NM) {
-            t_epi_step<AR, K::EM, K::EH * 48 + 12 * G + EPS * I, K::ENEXT, K::C::TRAIN>(A.s[1 - K::NB][K::EM], bn, st);
-            if constexpr (EPS == 2) t_epi_step<AR, K::EM, K::EH * 48 + 12 * G + EPS * I + 1, K::ENEXT, K::C::TRAIN>(A.s[1 - K::NB][K::EM], bn, st);
+            t_epi_step<AR, K::EM, K::EH * 48 + 12 * G + EPS * I, K::ENEXT, t_save_patch<typename K::C>(), K::DOT>(A.s[1 - K::NB][K::EM], bn, st);
+            if constexpr (EPS == 2) t_epi_step<AR, K::EM, K::EH * 48 + 12 * G + EPS * I + 1, K::ENEXT, t_save_patch<typename K::C>(), K::DOT>(A.s[1 - K::NB][K::EM], bn, st);
             __builtin_amdgcn_sched_barrier(0);
         }
-        t_group_steps<K, G, DA, DB, I + 1>(A, a, b, bn, st, R, sv);
+        t_group_steps<K, G, DA, DB, I + 1>(A, a, b, bs, bn, st, R, sv);
     }
 }
 
@@ -352,7 +409,7 @@ __device__ __forceinline__ void t_group_steps(TAcc& A, const TFrag<typename K::C
 template <class K, int G>
 constexpr int t_late_writes() {
     constexpr int j = 4 * K::EH + G;
-    return (K::C::TRAIN && K::EM >= 0 && K::EM < T_NM) ? t_epi_pair_writes<K::C::AR::H>(j) : 0;
+    return (t_save_patch<typename K::C>() && K::EM >= 0 && K::EM < T_NM) ? t_epi_pair_writes<K::C::AR::H>(j) : 0;
 }
 static_assert(t_epi_pair_writes<true>(0) == 0 && t_epi_pair_writes<true>(1) == 4 && t_epi_pair_writes<true>(5) == 2 &&
               t_epi_pair_writes<false>(0) == 0 && t_epi_pair_writes<false>(1) == 4 && t_epi_pair_writes<false>(7) == 2, "round 5's tally");
@@ -361,19 +418,20 @@ __device__ __forceinline__ void t_group_wait() { asm volatile("s_waitcnt lgkmcnt
 // one k-step: entering, a0 holds group 0's fragments; leaving, a0 holds group 0 of the NEXT stage of the stream.
 // LDS-DMA pieces of the stage being issued: TArB3 6 per wave and k-step (3, 4 | 5 | barrier | 0, 1 | 2), TArH2 4 (2 | 3 | barrier | 0 | 1)
 template <class K>
-__device__ __forceinline__ void t_kstep(TAcc& A, const TPieces<typename K::C::AR>& b, TPieces<typename K::C::AR> (&bn)[2], TEpi& st,
+__device__ __forceinline__ void t_kstep(TAcc& A, const TPieces<typename K::C::AR>& b, const TPieces<typename K::C::AR> (&bs)[2],
+                                        TPieces<typename K::C::AR> (&bn)[2], TEpi& st,
                                         TFrag<typename K::C::AR> (&a0)[2], TFrag<typename K::C::AR> (&a1)[2], TRing& R, TSave& sv) {
     using C = typename K::C;
     using AR = typename C::AR;
     constexpr bool B3 = !AR::H;
     t_read_group<AR, 1>(a1, R.rd_addr);
     __builtin_amdgcn_sched_barrier(0);
-    t_group_steps<K, 0, B3 ? 3 : 2, B3 ? 4 : -1, 0>(A, a0, b, bn, st, R, sv);        // the second half of the stage begun last k-step
+    t_group_steps<K, 0, B3 ? 3 : 2, B3 ? 4 : -1, 0>(A, a0, b, bs, bn, st, R, sv);        // the second half of the stage begun last k-step
     t_group_wait<K, 0>();
     __builtin_amdgcn_sched_barrier(0);
     t_read_group<AR, 2>(a0, R.rd_addr);
     __builtin_amdgcn_sched_barrier(0);
-    t_group_steps<K, 1, B3 ? 5 : 3, -1, 0>(A, a1, b, bn, st, R, sv);                 // the stage is fully issued
+    t_group_steps<K, 1, B3 ? 5 : 3, -1, 0>(A, a1, b, bs, bn, st, R, sv);                 // the stage is fully issued
     t_group_wait<K, 1>();
     __builtin_amdgcn_sched_barrier(0);
     // the NEXT k-step's pieces: this wave's DMAs for it have landed once at most DEPTH-1 younger groups are outstanding (tile
@@ -383,13 +441,13 @@ __device__ __forceinline__ void t_kstep(TAcc& A, const TPieces<typename K::C::AR
     asm volatile("s_barrier" ::: "memory");
     t_read_group<AR, 3>(a1, R.rd_addr);
     __builtin_amdgcn_sched_barrier(0);
-    t_group_steps<K, 2, 0, B3 ? 1 : -1, 0>(A, a0, b, bn, st, R, sv);                 // a new stage: its slot was freed by the barrier
+    t_group_steps<K, 2, 0, B3 ? 1 : -1, 0>(A, a0, b, bs, bn, st, R, sv);                 // a new stage: its slot was freed by the barrier
     t_group_wait<K, 2>();
     __builtin_amdgcn_sched_barrier(0);
     t_ring_advance_read<C>(R);
     t_read_group<AR, 0>(a0, R.rd_addr);
     __builtin_amdgcn_sched_barrier(0);
-    t_group_steps<K, 3, B3 ? 2 : 1, -1, 0>(A, a1, b, bn, st, R, sv);
+    t_group_steps<K, 3, B3 ? 2 : 1, -1, 0>(A, a1, b, bs, bn, st, R, sv);
     t_group_wait<K, 3>();
     __builtin_amdgcn_sched_barrier(0);
 }
@@ -408,10 +466,12 @@ __device__ __forceinline__ float softplus100_xs(float zs) {
 }
 // the one exposed epilogue of a layer: m-tile 0 of the source set, outside the MFMA stream -- the same arithmetic as t_epi_step, its
 // sixteen biases fetched with ONE LDS latency; leaves m-tile 1's first pair in st.b
-template <class AR, bool SAVE>
+template <class AR, bool SAVE, bool DOT>
 __device__ __forceinline__ void t_epi_exposed(const f32x16& x, TPieces<AR> (&out)[2], TEpi& st) {
     f32x4 bb[4];
     t_lds_read4_w<0, 32, 64, 96>(bb[0], bb[1], bb[2], bb[3], st.bias_addr);
+    [[maybe_unused]] f32x4 ww[4];
+    if constexpr (DOT) t_lds_read4_w<1024, 1024 + 32, 1024 + 64, 1024 + 96>(ww[0], ww[1], ww[2], ww[3], st.bias_addr);
     DH_UNROLL for (int j = 0; j < 8; ++j) {
         const int g = j / 2, i0 = 2 * (j % 2), r0 = 2 * j, half = j / 4, q = j % 4;
         f32x2 v, sv2;
@@ -419,6 +479,7 @@ __device__ __forceinline__ void t_epi_exposed(const f32x16& x, TPieces<AR> (&out
             v[0] = softplus100_xs(fmaf(x[r0], st.isw, bb[g][i0]));
             v[1] = softplus100_xs(fmaf(x[r0 + 1], st.isw, bb[g][i0 + 1]));
             sv2 = v * (1.f / H2_XS);
+            if constexpr (DOT) { st.s0 = fmaf(v[0], ww[g][i0], st.s0); st.s1 = fmaf(v[1], ww[g][i0 + 1], st.s1); }
         } else {
             v[0] = softplus100(x[r0] + bb[g][i0]);
             v[1] = softplus100(x[r0 + 1] + bb[g][i0 + 1]);
@@ -440,39 +501,40 @@ __device__ __forceinline__ void t_epi_exposed(const f32x16& x, TPieces<AR> (&out
         }
     }
     t_bias_read_w<1, 0>(st.b, st.bias_addr);
+    if constexpr (DOT) t_bias_read_w<1, 0, 1024>(st.w, st.bias_addr);
 }
 // k-steps 2M, 2M+1 (input pieces = the epilogue of m-tile M of the source set) with the epilogue of m-tile M+1 dealt under them
 // and (training kernel) m-tile M saved; MEND: m-tiles of the source the layer consumes (8; the skip layer takes 7 of lin3's)
-template <class C, int NB, int M, int MEND>
+template <class C, int NB, int M, int MEND, bool DOT>
 __device__ __forceinline__ void t_mpair(TAcc& A, TPieces<typename C::AR> (&bA)[2], TPieces<typename C::AR> (&bB)[2], TEpi& st,
                                         TFrag<typename C::AR> (&a0)[2], TFrag<typename C::AR> (&a1)[2], TRing& R, TSave& sv) {
     if constexpr (M < MEND) {
         constexpr int EM = M + 1 < MEND ? M + 1 : -1;
         constexpr bool EN = M + 2 < MEND;                 // m-tile EM + 1 will have its epilogue dealt too
-        using K0 = TK<C, NB, EM, 0, EN, M>;
-        using K1 = TK<C, NB, EM, 1, EN, -1>;
+        using K0 = TK<C, NB, EM, 0, EN, M, DOT>;
+        using K1 = TK<C, NB, EM, 1, EN, -1, DOT>;
         if constexpr (M % 2 == 0) {
-            t_kstep<K0>(A, bA[0], bB, st, a0, a1, R, sv);
-            t_kstep<K1>(A, bA[1], bB, st, a0, a1, R, sv);
+            t_kstep<K0>(A, bA[0], bA, bB, st, a0, a1, R, sv);
+            t_kstep<K1>(A, bA[1], bA, bB, st, a0, a1, R, sv);
         } else {
-            t_kstep<K0>(A, bB[0], bA, st, a0, a1, R, sv);
-            t_kstep<K1>(A, bB[1], bA, st, a0, a1, R, sv);
+            t_kstep<K0>(A, bB[0], bB, bA, st, a0, a1, R, sv);
+            t_kstep<K1>(A, bB[1], bB, bA, st, a0, a1, R, sv);
         }
-        t_mpair<C, NB, M + 1, MEND>(A, bA, bB, st, a0, a1, R, sv);
+        t_mpair<C, NB, M + 1, MEND, DOT>(A, bA, bB, st, a0, a1, R, sv);
     }
 }
 // the main part of a layer: accumulates MEND * 32 input features into set NB from the finished set 1 - NB, whose bias row is
 // at bias_row (LDS byte address, + 16 h); training kernel: the source layer's activations go to the native tile sv.base points at
-template <class C, int NB, int MEND>
+template <class C, int NB, int MEND, bool DOT = false>
 __device__ __forceinline__ void t_layer(TAcc& A, TPieces<typename C::AR> (&bA)[2], TPieces<typename C::AR> (&bB)[2], TEpi& st,
                                         TFrag<typename C::AR> (&a0)[2], TFrag<typename C::AR> (&a1)[2], TRing& R, TSave& sv,
                                         unsigned bias_row, float isw) {
     t_zero<NB>(A);
     st.bias_addr = bias_row;
     st.isw = isw;
-    t_epi_exposed<typename C::AR, C::TRAIN>(A.s[1 - NB][0], bA, st);
+    t_epi_exposed<typename C::AR, t_save_patch<C>(), DOT>(A.s[1 - NB][0], bA, st);
     __builtin_amdgcn_sched_barrier(0);
-    t_mpair<C, NB, 0, MEND>(A, bA, bB, st, a0, a1, R, sv);
+    t_mpair<C, NB, 0, MEND, DOT>(A, bA, bB, st, a0, a1, R, sv);
 }
 
 // Embedding image of the wave's 32 points in its private LDS rows: [x, sin(2^k x), cos(2^k x)]_{k<6}, zero padded to 48
@@ -664,8 +726,10 @@ __device__ __forceinline__ void sdf_chain_t_body(const void* __restrict__ stream
     TFrag<AR> a0[2], a1[2];
     if constexpr (C::TRAIN) {
         const unsigned patch = R.lds_base + C::NSTAGE * SB + BB + 4 * T_EMB_BYTES + wave * T_PATCH_BYTES;
-        st.patch_wr = patch + (4 * h * T_PATCH_LD + p) * 4;
-        sv.patch_rd = patch + (p * T_PATCH_LD + 4 * h) * 4;
+        if constexpr (t_save_patch<C>()) {
+            st.patch_wr = patch + (4 * h * T_PATCH_LD + p) * 4;
+            sv.patch_rd = patch + (p * T_PATCH_LD + 4 * h) * 4;
+        } else { sv.sel[0] = t_selector(p, h, 0); sv.sel[1] = t_selector(p, h, 1); }
     }
     // ring prologue: DEPTH full stages + the first half of the next (the steady state enters a k-step with half a stage issued)
     for (int d = 0; d < C::DEPTH; ++d) t_ring_issue_range<C, 0, AR::DMA>(R);
@@ -712,9 +776,9 @@ __device__ __forceinline__ void sdf_chain_t_body(const void* __restrict__ stream
         T_STAMP(1);
         // lin0: 3 k-steps of the embedding into set 0
         t_zero<0>(A);
-        t_kstep<TBare<C, 0>>(A, bA[0], bB, st, a0, a1, R, sv);
-        t_kstep<TBare<C, 0>>(A, bA[1], bB, st, a0, a1, R, sv);
-        t_kstep<TBare<C, 0>>(A, bB[0], bA, st, a0, a1, R, sv);
+        t_kstep<TBare<C, 0>>(A, bA[0], bA, bB, st, a0, a1, R, sv);
+        t_kstep<TBare<C, 0>>(A, bA[1], bA, bB, st, a0, a1, R, sv);
+        t_kstep<TBare<C, 0>>(A, bB[0], bB, bA, st, a0, a1, R, sv);
         T_DUMP(0, 0);
         T_STAMP(2);
         _Pragma("unroll 1") for (int q = 0; q < 2; ++q) {
@@ -738,31 +802,60 @@ __device__ __forceinline__ void sdf_chain_t_body(const void* __restrict__ stream
                 if constexpr (C::TRAIN) {
                     // columns 224..255 of lin3's tile: its rows 217.. have zero weights and bias, the activation is softplus(0)
                     const float c0 = 0.69314718055995f / SOFTPLUS_BETA;
-                    sv.v[0] = sv.v[1] = f32x4{c0, c0, c0, c0};
-                    t_save_store<7, 0>(sv); t_save_store<7, 1>(sv); t_save_store<7, 2>(sv); t_save_store<7, 3>(sv);
+                    TSave sc;
+                    sc.rsrc = sv.rsrc; sc.loff = sv.loff;
+                    sc.v[0] = sc.v[1] = f32x4{c0, c0, c0, c0};
+                    t_save_store<7, 0>(sc); t_save_store<7, 1>(sc); t_save_store<7, 2>(sc); t_save_store<7, 3>(sc);
                 }
                 t_embed_pieces<AR>(emb_row + 16 * h, bA[0], bA[1], bB[0]);
                 __builtin_amdgcn_sched_barrier(0);
-                t_kstep<TBare<C, 0>>(A, bA[0], bB, st, a0, a1, R, sv);
-                t_kstep<TBare<C, 0>>(A, bA[1], bB, st, a0, a1, R, sv);
-                t_kstep<TBare<C, 0>>(A, bB[0], bA, st, a0, a1, R, sv);
+                t_kstep<TBare<C, 0>>(A, bA[0], bA, bB, st, a0, a1, R, sv);
+                t_kstep<TBare<C, 0>>(A, bA[1], bA, bB, st, a0, a1, R, sv);
+                t_kstep<TBare<C, 0>>(A, bB[0], bB, bA, st, a0, a1, R, sv);
                 T_DUMP(0, 4);
                 T_STAMP(6);
             }
         }
-        // lin8 row 0 (the sdf) on softplus(lin7 + bias): per lane 128 features of its point, the two half-waves add up.  The training
-        // kernel does this too, before lin8's rows 1..256 consume set 1 (forming row 0 inside that layer's dealt epilogue needs two
-        // more in-flight LDS registers, and those were the first thing the compiler spilled)
-        {
+        // lin8 row 0 (the sdf) on softplus(lin7 + bias): per lane 128 features of its point, the two half-waves add up.  The patch-form
+        // training kernels do this too, before lin8's rows 1..256 consume set 1 (forming row 0 inside that layer's dealt epilogue needs
+        // two more in-flight LDS registers, and those were the first thing the compiler spilled there); the T_SAVE_MFMA form has the
+        // registers and forms the row inside the layer (DOT), on the activations its epilogue evaluates anyway.
+        if constexpr (t_save_mfma<C>()) {
+            (void)t_next_points(pts, npts, tile, wave * 32 + p, xn);
+            st.s0 = 0.f; st.s1 = 0.f;
+            sv.rsrc = t_tile_rsrc(act_tile + 7 * lstride, tile_ok, TILE_F * 4);
+            t_layer<C, 0, 8, true>(A, bA, bB, st, a0, a1, R, sv, bias_base + 7 * 1024, isw[7]);
+            T_STAMP(10);
+            {
+                float s = (st.s0 + st.s1) * (1.f / H2_XS);
+                s += __shfl_xor(s, 32);
+                int lp = wave * 32 + p;
+                asm volatile("" : "+v"(lp));
+                const int64_t gp = tile * T_PTS + lp;
+                if (h == 0 && gp < npts) sdf_out[gp] = s + b8_0[0];
+            }
+            sv.rsrc = t_tile_rsrc(feat + tile64 * TILE_F, tile_ok, TILE_F * 4);
+            {
+                // the feature tile still goes through the patch (raw fp32 accumulators, not pieces); its two lane addresses are formed
+                // here, from a value the compiler cannot hoist, instead of living in two registers through the tile loop
+                int pl = p, hl = h;
+                asm volatile("" : "+v"(pl), "+v"(hl));
+                const unsigned patch = R.lds_base + C::NSTAGE * SB + BB + 4 * T_EMB_BYTES + wave * T_PATCH_BYTES;
+                st.patch_wr = patch + (4 * hl * T_PATCH_LD + pl) * 4;
+                sv.patch_rd = patch + (pl * T_PATCH_LD + 4 * hl) * 4;
+            }
+            t_store_feat<0>(A, bias_base, st, sv, isw[8] * (1.f / H2_XS));
+            T_STAMP(11);
+        } else {
             const int64_t gp = t_next_points(pts, npts, tile, wave * 32 + p, xn);
             float s0 = 0.f, s1 = 0.f;
             t_final_dot<AR, 0>(A, bias_base, isw[7], s0, s1);
             float s = (s0 + s1) * (AR::H ? 1.f / H2_XS : 1.f);
             s += __shfl_xor(s, 32);
             if (h == 0 && gp < npts) sdf_out[gp] = s + b8_0[0];
+            T_STAMP(10);
         }
-        T_STAMP(10);
-        if constexpr (C::TRAIN) {
+        if constexpr (t_save_patch<C>()) {
             // lin8 rows 1..256 from softplus(lin7 + bias) into set 0 (its epilogue saves act[7]), then the feature tile
             sv.rsrc = t_tile_rsrc(act_tile + 7 * lstride, tile_ok, TILE_F * 4);
             t_layer<C, 0, 8>(A, bA, bB, st, a0, a1, R, sv, bias_base + 7 * 1024, isw[7]);
