@@ -1,6 +1,6 @@
 """Per-kernel roofline table of DESIGN.md section 4 from the committed artefacts (markdown on stdout).
 
-    python scripts/kernel_table.py [profiles/r05_bench_n1.json profiles/r05_pmc_summary.json]
+    python scripts/kernel_table.py [profiles/r06_bench_n1.json profiles/r06_pmc_summary.json]
 
 ms (HIP events), TFLOP/s and fraction come from the bench line; ms (rocprofv3) from the --kernel-trace --stats pass; MFMA-busy =
 SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8); clock = GRBM_GUI_ACTIVE / 8 / rocprofv3 time (a profiled pass runs
@@ -9,8 +9,8 @@ L2 -> CU = TCP_TCC_READ_REQ_sum x 128 B; hit rate = TCC_HIT / (TCC_HIT + TCC_MIS
 """
 import json, os, re, sys
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-bench = sys.argv[1] if len(sys.argv) > 1 else os.path.join(R, "profiles", "r05_bench_n1.json")
-pmc = sys.argv[2] if len(sys.argv) > 2 else os.path.join(R, "profiles", "r05_pmc_summary.json")
+bench = sys.argv[1] if len(sys.argv) > 1 else os.path.join(R, "profiles", "r06_bench_n1.json")
+pmc = sys.argv[2] if len(sys.argv) > 2 else os.path.join(R, "profiles", "r06_pmc_summary.json")
 b = json.loads(open(bench).read().strip().split("\n")[-1])
 d = json.load(open(pmc))
 ks = {}
