@@ -24,7 +24,8 @@
 // Arithmetic (template parameter AR): TArB3 = the same six bf16 products per fp32 product, smallest terms first, as tile16.h;
 // TArH2 (round 4) = tile16h.h's two fp16 pieces / three products: a stage is 16 KB (two pieces), the chain carries its activations
 // scaled by H2_XS = 16 (bias rows pre-scaled, softplus evaluated in the scaled variable: same operation count, bit-identical
-// values after the exact division by 16 on the way to a saved tile), the weights by the linear's power of two (its reciprocal
+// values after the exact division by 16 on the way to a saved tile -- of which the T_SAVE_MFMA form saves the two-piece sum hi + lo,
+// 2^-22 apart), the weights by the linear's power of two (its reciprocal
 // multiplies the accumulator in the epilogue's first fma), and the dealt epilogue runs two micro-steps per MFMA.
 #include "mlp_common.h"
 #include "tile16h.h"
@@ -66,6 +67,9 @@ constexpr int T_EMB_BYTES = 32 * T_EMB_LD * 4;   // per wave: its 32 points x [3
 // m-tile; rounds 3-5; bf16x3 always) -- the fp32 activation itself.
 #ifndef T_SAVE_MFMA
 #define T_SAVE_MFMA 1
+#endif
+#ifndef T_TILE_ST_AUX              // cache policy of the T_SAVE_MFMA form's tile stores (2 = nt, as DH_TILE_ST; development: A/B of the others)
+#define T_TILE_ST_AUX 2
 #endif
 constexpr int T_PATCH_LD = 40;                   // floats per feature row of the transposition patch (4 * 40 % 64 == 32: the two half-waves' writes hit different banks)
 constexpr int T_PATCH_BYTES = 32 * T_PATCH_LD * 4;
@@ -324,7 +328,7 @@ __device__ __forceinline__ void t_save_store(const TSave& sv) {
 template <int M, int R4>
 __device__ __forceinline__ void t_save_store_d(const TSave& sv) {
     const f32x4 v = {sv.d[4 * R4 + 0], sv.d[4 * R4 + 1], sv.d[4 * R4 + 2], sv.d[4 * R4 + 3]};
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), sv.rsrc, sv.loff + 4 * t_native_off(M, R4), 0, 2);
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), sv.rsrc, sv.loff + 4 * t_native_off(M, R4), 0, T_TILE_ST_AUX);
 }
 // transposition MFMA I (0..3) of the m-tile whose pieces are bs (k-steps 2M, 2M+1): lo of k-step 0, lo of k-step 1, hi, hi --
 // every output element receives exactly one non-zero product per MFMA: lo / 16, then + hi / 16 (exact in fp32)
