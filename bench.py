@@ -134,7 +134,8 @@ def committed_psnr_record():
     per seed: `--psnr` does that instead).  The newest round's file wins.  Both statistics of the record are carried: the WINDOW of
     checkpoints at 1800..2000 iterations (`delta` / `se`: the protocol's headline) and the FINAL checkpoint at exactly 2000."""
     import glob
-    for pat in ("psnr_parity_r05_neus_hip_vs_oracle_f16_pooled.json", "psnr_parity_r04_neus_hip_vs_oracle_f16_pooled.json",
+    for pat in ("psnr_parity_r06_neus_hip_vs_oracle_f16_pooled.json", "psnr_parity_r05_neus_hip_vs_oracle_f16_pooled.json",
+                "psnr_parity_r04_neus_hip_vs_oracle_f16_pooled.json",
                 "psnr_parity_r03_neus_hip_vs_oracle_59seeds.json"):
         for path in sorted(glob.glob(os.path.join(ROOT, "profiles", pat))):
             d = json.load(open(path))
