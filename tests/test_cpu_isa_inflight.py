@@ -71,6 +71,20 @@ def test_chain_t_listing_is_clean(tmp_path):
     for scratch, lds in nograd + train + nograd_h + train_h:
         assert lds <= 160 * 1024, "one workgroup per CU: the LDS image must fit 160 KB"
     _no_register_soffset_on_wide_stores(text)
+    # Round 6: the fp16 training forward transposes its m-tiles on the MATRIX pipe (csrc/chain_t.hip T_SAVE_MFMA).  What the form is
+    # worth rests on three things the compiler does today -- guard them: the selector MFMAs are there (4 per saved m-tile on top of
+    # the 2,016 of the patch form), the LDS patch is gone from the dealt stream (the patch form had 771 ds_write_b32; what remains is the
+    # embedding image and the once-per-tile feature tile), and the tile stores read the transposed tile straight from the accumulator
+    # registers it was formed in (no copy into vector registers)
+    m = re.search(r"^_ZN2dh22sdf_fwd_train_h_kernel\w*:[^\n]*\n(.*?)s_endpgm", text, flags=re.S | re.M)
+    assert m, "sdf_fwd_train_h_kernel not found in the listing"
+    body = m.group(1)
+    n_mfma = len(re.findall(r"^\s+v_mfma_f32_32x32x16_f16 ", body, flags=re.M))
+    n_w32 = len(re.findall(r"^\s+ds_write_b32 ", body, flags=re.M))
+    n_acc_stores = len(re.findall(r"^\s+buffer_store_dwordx4 a\[", body, flags=re.M))
+    assert n_mfma >= 2016 + 4 * 39, n_mfma
+    assert n_w32 <= 200, n_w32
+    assert n_acc_stores >= 4 * 39, n_acc_stores
 
 
 @pytest.mark.skipif(shutil.which("hipcc") is None, reason="hipcc not installed")
